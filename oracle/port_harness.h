@@ -1,0 +1,95 @@
+// TEST INFRASTRUCTURE ONLY -- CPU restatement ("port") of the reference's compiled hot path.
+//
+// A generated translation unit defines ZA_NV / ZA_NCH / ZA_HAS_SAMPLE, includes csrc/zart.h and the zajit
+// section code, then this header, giving a scalar f64 CPU build of the same lowering the reference's LLVM AOT
+// object has (dsp_jsfx_aot.py:3310-5905) -- the stand-in for that object, which cannot be produced here
+// (llvmlite absent). Call sequence restated from:
+//   prepareToPlay ............ src/JSFXJuceProcessor.cpp:3297-3318 (sliders -> @init -> alias re-apply -> @slider)
+//   jsfx_process_block ....... dsp_jsfx_aot.py:5713-5905 (@block; pending masks -> @slider; per-sample f32<->f64)
+//   consumeDspSliderChanges .. src/JSFXJuceProcessor.cpp:3745 (pending masks cleared after each host block)
+// Never linked into the product.
+#pragma once
+
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+struct ZaPort {
+  ZaState<ZA_NV> s;
+  std::vector<double> mem;
+  std::vector<uint32_t> mt;
+  int alias[64];
+};
+
+extern "C" {
+
+ZaPort* port_create(double srate, int64_t mem_cap) {
+  ZaPort* p = new ZaPort();
+  memset(&p->s, 0, sizeof(p->s));
+  p->mem.assign((size_t)mem_cap, 0.0);
+  p->mt.assign(624, 0u);
+  p->s.mem = p->mem.data();
+  p->s.mem_stride = 1;
+  p->s.mem_cap = mem_cap;
+  p->s.mt = p->mt.data();
+  p->s.mt_stride = 1;
+  p->s.srate = srate;
+  p->s.instance_id = 1;
+  for (int i = 0; i < 64; ++i) p->alias[i] = -1;
+  return p;
+}
+void port_destroy(ZaPort* p) { delete p; }
+void port_bind_alias(ZaPort* p, int idx0, int var_index) { if (idx0 >= 0 && idx0 < 64) p->alias[idx0] = var_index; }
+static void port_sync_alias(ZaPort* p) {
+  for (int i = 0; i < 64; ++i) if (p->alias[i] >= 0 && p->alias[i] < ZA_NV) p->s.v[p->alias[i]] = p->s.sl[i];
+}
+void port_set_sliders(ZaPort* p, const double* v, int n) {
+  for (int i = 0; i < n && i < 64; ++i) p->s.sl[i] = v[i];
+  port_sync_alias(p);
+}
+void port_prepare(ZaPort* p) {
+  port_sync_alias(p);
+  za_section_init(p->s);
+  port_sync_alias(p);
+  za_section_slider(p->s);
+}
+void port_run_slider(ZaPort* p) { port_sync_alias(p); za_section_slider(p->s); }
+
+// planar float [nCh][ch_stride]; processes `frames` frames in host blocks of `block`.
+void port_process(ZaPort* p, const float* in, float* out, int nCh, int64_t frames, int block, int64_t ch_stride) {
+  ZaState<ZA_NV>& s = p->s;
+  if (nCh < 0) nCh = 0;
+  if (nCh > 64) nCh = 64;
+  for (int64_t pos = 0; pos < frames; pos += block) {
+    int n = (int)((frames - pos < block) ? frames - pos : block);
+    s.samplesblock = (double)n;
+    s.block_size = n;
+    za_section_block(s);
+    if (s.pend_change | s.pend_automate | s.pend_automate_end) za_section_slider(s);
+#if ZA_HAS_SAMPLE
+    for (int i = 0; i < n; ++i) {
+      for (int ch = 0; ch < nCh; ++ch) s.spl[ch] = (double)in[ch * ch_stride + pos + i];
+      za_section_sample(s);
+      for (int ch = 0; ch < nCh; ++ch) out[ch * ch_stride + pos + i] = (float)s.spl[ch];
+    }
+#endif
+    s.pend_change = s.pend_automate = s.pend_automate_end = 0;
+  }
+}
+
+int port_nvars(void) { return ZA_NV; }
+void port_get_vars(ZaPort* p, double* dst) { memcpy(dst, p->s.v, sizeof(double) * ZA_NV); }
+void port_set_var(ZaPort* p, int i, double v) { if (i >= 0 && i < ZA_NV) p->s.v[i] = v; }
+void port_get_sliders(ZaPort* p, double* dst) { memcpy(dst, p->s.sl, sizeof(double) * 64); }
+void port_get_spl(ZaPort* p, double* dst) { memcpy(dst, p->s.spl, sizeof(double) * 64); }
+int64_t port_mem_read(ZaPort* p, int64_t start, int64_t n, double* dst) {
+  int64_t k = 0;
+  for (; k < n && start + k < p->s.mem_cap; ++k) dst[k] = p->mem[(size_t)(start + k)];
+  for (int64_t j = k; j < n; ++j) dst[j] = 0.0;
+  return k;
+}
+int64_t port_mem_high(ZaPort* p) { return p->s.mem_high; }
+int64_t port_mem_need(ZaPort* p) { return p->s.mem_need; }
+uint32_t port_err(ZaPort* p) { return p->s.err; }
+
+}  // extern "C"

@@ -1,0 +1,276 @@
+// zart.h -- per-instance runtime that zajit-generated section code executes against.
+//
+// One header, two compilers: hipcc --offload-arch=gfx950 (device functions, the product) and g++ (the CPU
+// restatement under oracle/, test infrastructure). It restates the *lowering semantics* of the reference's
+// AOT emitter so generated code can stay a thin expression tree:
+//   value model / truthiness / ordered compares ..... dsp_jsfx_aot.py:3725, 4349-4352, 4315-4317
+//   i32 integer ops (| & ~ % << >>) .................. dsp_jsfx_aot.py:4107-4114, 4355-4381
+//   mem[] addressing (trunc(base+idx+1e-5), clamp) ... dsp_jsfx_aot.py:4062-4103
+//   slider(i)/spl(i) ................................. dsp_jsfx_aot.py:3789-3837
+//   loop() count ..................................... dsp_jsfx_aot.py:5663-5709
+//   min/max/sign/sqr/invsqrt ......................... dsp_jsfx_aot.py:5223-5277
+//   rand (MT19937, per instance) ..................... dsp_jsfx_aot.py:3880-4060, 5294-5323
+//   memset ........................................... dsp_jsfx_aot.py:5439-5495
+//   memcpy / convolve_c .............................. src/JSFXJuceProcessor.cpp:1341-1413
+//   sliderchange / slider_automate / slider_show ..... src/JSFXJuceProcessor.cpp:2448-2475, dsp_jsfx_aot.py:5393-5437
+//
+// Differences from the reference that are deliberate: the arena is fixed-capacity (no realloc on
+// device); reads past the capacity yield 0 exactly like a fresh zero-filled growth would, writes past it are dropped
+// and latch ZA_ERR_MEM_OVERFLOW (+ the size that would have been needed) so the host fails loudly.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define ZA_FN __device__ __forceinline__
+#define ZA_NOINLINE __device__ __noinline__
+#else
+#define ZA_FN static inline __attribute__((always_inline))
+#define ZA_NOINLINE static __attribute__((noinline))
+#endif
+
+enum : uint32_t {
+  ZA_ERR_MEM_OVERFLOW = 1u,   // a store addressed mem[] beyond the arena capacity
+  ZA_ERR_LOOP_CAP = 2u,       // a loop()/while exceeded ZA_LOOP_CAP iterations and was cut
+  ZA_ERR_UNSUPPORTED = 4u,    // a host-only builtin was reached on the device
+  ZA_ERR_FFT_ARGS = 8u,       // informational: fft call ignored (bad size / page crossing), as the reference does
+};
+
+#ifndef ZA_LOOP_CAP
+#define ZA_LOOP_CAP (int64_t(1) << 26)
+#endif
+
+#define ZA_STRING_BASE 1099511627776.0 /* 2^40: opaque string-literal handles, dsp_jsfx_aot.py:3681-3695 */
+
+struct ZaGmemView;   // zart_gmem.h
+struct ZaPoolView;   // zart_pool.h
+
+template <int NV>
+struct ZaState {
+  double v[NV];
+  double sl[64];
+  double spl[64];
+  double srate, samplesblock, midi_bus, ext_midi_bus;
+  double* mem;           // element a lives at mem[a * mem_stride]
+  int64_t mem_stride;
+  int64_t mem_cap;
+  int64_t mem_high;      // 1 + highest element stored so far (the oracle's write-trace high-water mark)
+  int64_t mem_need;      // capacity that would have satisfied every store seen
+  uint32_t* mt;          // MT19937 words, word k at mt[k * mt_stride]
+  int64_t mt_stride;
+  uint32_t mti;
+  uint32_t err;
+  uint64_t pend_change, pend_automate, pend_automate_end;
+  uint64_t vis_mask;
+  int32_t vis_init;
+  int32_t block_size;
+  const ZaGmemView* gmem;
+  const ZaPoolView* pool;
+  uint64_t instance_id;
+  double sink;
+  double memtop;
+};
+
+// ---------------------------------------------------------------------------------------------
+// scalars
+// ---------------------------------------------------------------------------------------------
+ZA_FN bool za_truthy(double x) { return x < 0.0 || x > 0.0; }             // ordered x != 0
+ZA_FN double za_b(bool c) { return c ? 1.0 : 0.0; }
+ZA_FN double za_ne(double a, double b) { return (a < b || a > b) ? 1.0 : 0.0; }  // ordered !=
+ZA_FN double za_not(double a) { return a == 0.0 ? 1.0 : 0.0; }
+ZA_FN double za_neg(double a) { return 0.0 - a; }
+
+ZA_FN int64_t za_f2i64(double x) {
+  // fptosi: truncation toward zero. Out-of-range / NaN inputs are undefined in the reference's IR; pin them to the
+  // x86 "integer indefinite" result (INT64_MIN) so CPU and GPU builds of this header agree with each other.
+  if (!(x > -9.2233720368547758e18 && x < 9.2233720368547758e18)) return INT64_MIN;
+  return (int64_t)x;
+}
+ZA_FN int32_t za_i32(double x) { return (int32_t)(uint32_t)(uint64_t)za_f2i64(x); }
+ZA_FN double za_or(double a, double b) { return (double)(za_i32(a) | za_i32(b)); }
+ZA_FN double za_and(double a, double b) { return (double)(za_i32(a) & za_i32(b)); }
+ZA_FN double za_xor(double a, double b) { return (double)(za_i32(a) ^ za_i32(b)); }
+ZA_FN double za_shl(double a, double b) { return (double)(int32_t)((uint32_t)za_i32(a) << (za_i32(b) & 31)); }
+ZA_FN double za_shr(double a, double b) { return (double)(za_i32(a) >> (za_i32(b) & 31)); }
+ZA_FN double za_mod(double a, double b) {
+  int32_t l = za_i32(a), r = za_i32(b);
+  if (r == 0 || (l == INT32_MIN && r == -1)) return 0.0;  // srem traps/UB in the reference; defined as 0 here
+  return (double)(l % r);
+}
+ZA_FN double za_min(double a, double b) { return a < b ? a : b; }   // olt select: NaN -> second operand
+ZA_FN double za_max(double a, double b) { return a > b ? a : b; }
+ZA_FN double za_sign(double a) { return a > 0.0 ? 1.0 : (a < 0.0 ? -1.0 : 0.0); }
+ZA_FN double za_sqr(double a) { return a * a; }
+ZA_FN double za_invsqrt(double a) {
+  float f = (float)a;
+  int32_t bits;
+  __builtin_memcpy(&bits, &f, 4);
+  bits = (int32_t)0x5f3759df - (bits >> 1);
+  float y;
+  __builtin_memcpy(&y, &bits, 4);
+  double y0 = (double)y;
+  return y0 * (1.5 - (0.5 * a) * (y0 * y0));
+}
+ZA_FN int64_t za_loopcount(double n) { int64_t c = za_f2i64(n); return c < 0 ? 0 : c; }
+
+// ---------------------------------------------------------------------------------------------
+// mem[]
+// ---------------------------------------------------------------------------------------------
+ZA_FN int64_t za_addr1(double x) { int64_t a = za_f2i64(x + 1.0e-5); return a < 0 ? 0 : a; }
+ZA_FN int64_t za_addr(double base, double idx) { return za_addr1(base + idx); }
+
+template <class S>
+ZA_FN double za_ld(S& s, int64_t a) { return a < s.mem_cap ? s.mem[a * s.mem_stride] : 0.0; }
+
+template <class S>
+ZA_FN void za_note_store(S& s, int64_t end) {
+  if (end > s.mem_high) s.mem_high = end;
+  if (end > s.mem_cap) { s.err |= ZA_ERR_MEM_OVERFLOW; if (end > s.mem_need) s.mem_need = end; }
+}
+template <class S>
+ZA_FN double za_st(S& s, int64_t a, double v) {
+  za_note_store(s, a + 1);
+  if (a < s.mem_cap) s.mem[a * s.mem_stride] = v;
+  return v;
+}
+
+template <class S>
+ZA_FN double* za_mem_ptr(S& s, int64_t a) {    // lvalue for builtins with output arguments
+  za_note_store(s, a + 1);
+  return a < s.mem_cap ? &s.mem[a * s.mem_stride] : &s.sink;
+}
+
+// slider(i) 1-based, spl(i) 0-based; out of range reads 0, writes are ignored (value still returned).
+ZA_FN double za_dyn_ld64(const double* arr, double i, int off) {
+  int64_t k = za_f2i64(i + 1.0e-5) - off;
+  return (k >= 0 && k < 64) ? arr[k] : 0.0;
+}
+ZA_FN void za_dyn_st64(double* arr, double i, int off, double v) {
+  int64_t k = za_f2i64(i + 1.0e-5) - off;
+  if (k >= 0 && k < 64) arr[k] = v;
+}
+
+template <class S>
+ZA_FN double za_memset(S& s, double dest, double value, double len) {
+  int64_t d = za_addr1(dest);
+  int64_t n = za_f2i64(len);
+  if (n < 0) n = 0;
+  if (n > 0) za_note_store(s, d + n);
+  int64_t e = d + n;
+  if (e > s.mem_cap) e = s.mem_cap;
+  for (int64_t i = d; i < e; ++i) s.mem[i * s.mem_stride] = value;
+  return dest;
+}
+
+ZA_FN int64_t za_round_idx(double v) { return za_f2i64(v + (v >= 0.0 ? 1.0e-5 : -1.0e-5)); }
+
+template <class S>
+ZA_FN double za_memcpy(S& s, double destD, double srcD, double lenD) {
+  int64_t d = za_round_idx(destD), r = za_round_idx(srcD), n = za_round_idx(lenD);
+  if (d < 0) d = 0;
+  if (r < 0) r = 0;
+  if (n <= 0) return 0.0;
+  if (d + n < d || r + n < r) return 0.0;
+  int64_t need = (d + n > r + n) ? d + n : r + n;
+  if (need > s.mem_cap) {           // the reference grows here; a fixed arena cannot -> fail loudly, copy nothing
+    s.err |= ZA_ERR_MEM_OVERFLOW;
+    if (need > s.mem_need) s.mem_need = need;
+    return 0.0;
+  }
+  if (d + n > s.mem_high) s.mem_high = d + n;
+  const int64_t st = s.mem_stride;
+  if (d <= r) for (int64_t i = 0; i < n; ++i) s.mem[(d + i) * st] = s.mem[(r + i) * st];
+  else for (int64_t i = n - 1; i >= 0; --i) s.mem[(d + i) * st] = s.mem[(r + i) * st];
+  return 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// rand()
+// ---------------------------------------------------------------------------------------------
+template <class S>
+ZA_NOINLINE uint32_t za_mt_next(S& s) {
+  const int N = 624, M = 397;
+  uint32_t* mt = s.mt;
+  const int64_t st = s.mt_stride;
+  uint32_t i = s.mti;
+  if (i == 0) {
+    uint32_t prev = 0x4141F00Du;
+    mt[0] = prev;
+    for (int k = 1; k < N; ++k) { prev = 1812433253u * (prev ^ (prev >> 30)) + (uint32_t)k; mt[k * st] = prev; }
+    i = N;
+  }
+  if (i >= (uint32_t)N) {
+    for (int k = 0; k < N; ++k) {
+      uint32_t a = mt[k * st], b = mt[((k + 1) % N) * st];
+      uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+      mt[k * st] = mt[((k + M) % N) * st] ^ (y >> 1) ^ ((y & 1u) ? 0x9908B0DFu : 0u);
+    }
+    s.mti = 1;
+    i = 0;
+  } else {
+    s.mti = i + 1;
+  }
+  uint32_t y = mt[i * st];
+  y ^= y >> 11;
+  y ^= (y << 7) & 0x9D2C5680u;
+  y ^= (y << 15) & 0xEFC60000u;
+  y ^= y >> 18;
+  return y;
+}
+template <class S>
+ZA_FN double za_rand(S& s, double mx) {
+  double m = floor(mx);
+  if (m < 1.0) m = 1.0;
+  return ((double)za_mt_next(s) * (1.0 / 4294967295.0)) * m;
+}
+
+// ---------------------------------------------------------------------------------------------
+// slider bookkeeping
+// ---------------------------------------------------------------------------------------------
+ZA_FN int64_t za_change_mask(double m) {
+  // (m > 0) ? llround(m) : 0, non-positive results select nothing (src/JSFXJuceProcessor.cpp:2448-2475)
+  if (!(m > 0.0)) return 0;
+  if (m >= 9.2233720368547758e18) return 0;
+  int64_t k = (int64_t)(m + 0.5);
+  return k > 0 ? k : 0;
+}
+template <class S> ZA_FN double za_sliderchange(S& s, double m) {
+  int64_t k = za_change_mask(m);
+  if (k <= 0) return 0.0;
+  s.pend_change |= (uint64_t)k;
+  return 1.0;
+}
+template <class S> ZA_FN double za_slider_automate(S& s, double m, double end) {
+  int64_t k = za_change_mask(m);
+  if (k <= 0) return 0.0;
+  s.pend_change |= (uint64_t)k;
+  if (end != 0.0) s.pend_automate_end |= (uint64_t)k; else s.pend_automate |= (uint64_t)k;
+  return 1.0;
+}
+ZA_FN uint64_t za_mask_arg(double m) {     // slider_show: fptoui(max(m, 0))
+  if (!(m > 0.0)) return 0;
+  if (m >= 18446744073709551615.0) return ~0ull;
+  return (uint64_t)m;
+}
+template <class S> ZA_FN void za_vis_init(S& s) { if (!s.vis_init) { s.vis_mask = ~0ull; s.vis_init = 1; } }
+template <class S> ZA_FN double za_slider_show1(S& s, double m) {
+  za_vis_init(s);
+  uint64_t k = (m < 0.0) ? 0 : za_mask_arg(m);
+  return (double)(s.vis_mask & k);
+}
+template <class S> ZA_FN double za_slider_show2(S& s, double m, double mode) {
+  za_vis_init(s);
+  uint64_t k = (m < 0.0) ? 0 : za_mask_arg(m);
+  if (mode == 0.0) s.vis_mask &= ~k;
+  else if (mode == -1.0) s.vis_mask ^= k;
+  else s.vis_mask |= k;
+  return (double)(s.vis_mask & k);
+}
+template <class S> ZA_FN double za_slider_next_chg(S& s, double idx, double* out) {
+  // reference: writes the current value, reports no further change point (src/JSFXJuceProcessor.cpp:137-152)
+  int32_t k = (int32_t)za_f2i64(idx + 1.0e-5) - 1;
+  if (out) *out = (k >= 0 && k < 64) ? s.sl[k] : 0.0;
+  return 0.0;
+}
+template <class S> ZA_FN double za_unsupported(S& s) { s.err |= ZA_ERR_UNSUPPORTED; return 0.0; }
