@@ -1,0 +1,138 @@
+/* zabatch.h -- C ABI of the MI355X batch audio-DSP engine (libzabatch.so).
+ *
+ * Drop-in boundary for ONE path of ZorakAudio-Experimental-Plugins: the generated-object interface
+ * `jsfx_init / jsfx_slider / jsfx_block / jsfx_sample / jsfx_process_block (DSPJSFX_State*, ...)`
+ * that dsp_jsfx_aot.py emits per plugin (prototype: dsp_jsfx_aot.py:6090-6102; struct: :5991-6025) and that
+ * JSFXJuceProcessor::prepareToPlay / processBlock call (src/JSFXJuceProcessor.cpp:3305,3318,3547,3733).
+ * The reference has no batch axis -- one DSPJSFX_State per plugin instance, one audio thread each. Here N
+ * instances of one leaf are one object on one GPU and every entry point acts on all of them:
+ *
+ *   reference (per instance)                                  this ABI (N instances)
+ *   --------------------------------------------------------  ------------------------------------------
+ *   DSPJSFX_State st; calloc mem (JSFXJuceProcessor.cpp:8958)  zab_create()
+ *   pushParamsToStateSliders() (:9286-9357)                    zab_set_sliders()
+ *   jsfx_init(&st); alias re-apply; jsfx_slider(&st) (:3305-18) zab_prepare()
+ *   jsfx_slider(&st) when sliders changed (:3545-3547)         implicit in zab_process() for touched instances
+ *   jsfx_process_block(&st, in, out, nCh, n) (:3733)           zab_process()
+ *   st.vars[DSPJSFX_VARS[i].index], st.mem[...]                zab_read_vars() / zab_read_mem()
+ *
+ * All functions return ZAB_OK (0) or a negative ZAB_E_* code; zab_last_error() gives the text. Nothing here
+ * takes or returns a torch/JUCE/C++ type. Device pointers are plain `void*` HIP device addresses.
+ * A compute call made without a GPU, or with a missing plugin module, fails loudly -- there is no CPU fallback.
+ */
+#ifndef ZABATCH_H
+#define ZABATCH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct zab_engine zab_engine;
+
+enum {
+  ZAB_OK = 0,
+  ZAB_E_ARG = -1,          /* bad argument */
+  ZAB_E_MODULE = -2,       /* plugin module missing / not loadable / ABI mismatch */
+  ZAB_E_HIP = -3,          /* HIP runtime error (no device, allocation, launch) */
+  ZAB_E_MEM_OVERFLOW = -4, /* a script stored to mem[] beyond the arena: recreate with a larger mem_cap */
+  ZAB_E_UNSUPPORTED = -5,  /* script reached a host-only builtin (MIDI, file, msg_*) on the device */
+  ZAB_E_LOOP_CAP = -6,     /* a loop()/while ran past the safety cap and was cut */
+  ZAB_E_STATE = -7         /* call sequence error (process before prepare, ...) */
+};
+
+/* which kernels zab_process may use */
+enum {
+  ZAB_PATH_AUTO = 0,       /* hand-written leaf kernel when the module has one and it applies, else generic */
+  ZAB_PATH_GENERIC = 1,    /* translator-generated serial-per-instance kernel (one lane per instance) */
+  ZAB_PATH_FAST = 2        /* require the hand-written kernel; error if it does not apply */
+};
+
+/* audio buffer placement for zab_process */
+enum {
+  ZAB_BUF_DEVICE = 0,      /* in/out are device pointers (HBM resident) */
+  ZAB_BUF_HOST = 1         /* in/out are host pointers; staged over PCIe by the call */
+};
+
+typedef struct zab_config {
+  int32_t n_instances;     /* batch size N (> 0) */
+  int32_t device;          /* HIP device ordinal */
+  double srate;            /* engine sample rate (st.srate) */
+  int32_t max_block;       /* largest host block `block` that zab_process will be given */
+  int32_t path;            /* ZAB_PATH_* */
+  int64_t mem_cap;         /* doubles of mem[] per instance; 0 = module default (65536, the reference's initial
+                              calloc, src/JSFXJuceProcessor.cpp:8958-8963) */
+  uint64_t first_instance_id; /* instance_id() of instance 0; instance i reports first_instance_id + i */
+} zab_config;
+
+typedef struct zab_info {
+  char name[64];
+  int32_t nvars;           /* entries of vars[] (DSPJSFX_State::vars) */
+  int32_t n_channels;      /* channels processed per instance (DSPJSFX_PROCESS_CHANNELS) */
+  int32_t n_inputs, n_outputs;
+  int32_t has_init, has_slider, has_block, has_sample;
+  int32_t has_fast_path;
+  int64_t mem_cap;
+  int32_t n_instances;
+  int32_t layout_instance_major; /* 1: mem/vars of one instance contiguous; 0: interleaved across instances */
+} zab_info;
+
+const char* zab_last_error(void);
+int zab_abi_version(void);
+
+/* Load plugin module `libzab_<name>.so` (path or bare leaf name resolved next to libzabatch.so) and allocate
+ * state for cfg->n_instances instances: vars/sliders/spl zeroed, mem zeroed (resetStateStructOnly + calloc). */
+int zab_create(const char* module, const zab_config* cfg, zab_engine** out);
+int zab_destroy(zab_engine* e);
+int zab_get_info(zab_engine* e, zab_info* out);
+
+/* name <-> vars[] index table of the leaf (DSPJSFX_VARS, dsp_jsfx_aot.py:6028-6046). */
+int zab_var_count(zab_engine* e);
+const char* zab_var_name(zab_engine* e, int index);
+int zab_var_index(zab_engine* e, const char* name);   /* -1 if unknown */
+
+/* Slider values as the host bridge would write them into st.sliders[] (already clamped/quantised by the caller,
+ * zajit.sliders mirrors src/JSFXJuceProcessor.cpp:5556-5596). values = count x 64 doubles for instances
+ * [first, first+count); count = 0 with first = 0 broadcasts one row of 64 to every instance.
+ * Instances whose values changed run @slider at the start of the next zab_process (processBlock :3545-3547). */
+int zab_set_sliders(zab_engine* e, int32_t first, int32_t count, const double* values);
+int zab_get_sliders(zab_engine* e, int32_t first, int32_t count, double* values);
+
+/* prepareToPlay(): @init, slider-alias re-apply, @slider on every instance (sliders must be set before). */
+int zab_prepare(zab_engine* e);
+
+/* processBlock() x ceil(frames/block): for each host block of `block` frames (last one short) run
+ * jsfx_process_block semantics on every instance. Audio is planar float32, instance-major:
+ *   sample (i, ch, t) at buf[(i * n_channels + ch) * frame_stride + t],  0 <= t < frames <= frame_stride.
+ * out may equal in (Faust-style in-place). placement = ZAB_BUF_*. Asynchronous on the engine's stream when
+ * placement is ZAB_BUF_DEVICE; zab_sync() waits and reports device-side errors. */
+int zab_process(zab_engine* e, const void* in, void* out, int64_t frames, int64_t frame_stride, int32_t block,
+                int32_t placement);
+int zab_sync(zab_engine* e);
+
+/* State read-back (synchronises). vars: [count][nvars]; mem: [count][n] doubles starting at element `start`. */
+int zab_read_vars(zab_engine* e, int32_t first, int32_t count, double* dst);
+int zab_read_mem(zab_engine* e, int32_t first, int32_t count, int64_t start, int64_t n, double* dst);
+int zab_write_mem(zab_engine* e, int32_t first, int32_t count, int64_t start, int64_t n, const double* src);
+int zab_read_mem_high(zab_engine* e, int32_t first, int32_t count, int64_t* dst); /* write high-water marks */
+
+/* Device buffer helpers so hosts without a HIP binding (ctypes, cgo, JNI) can keep audio HBM-resident. */
+int zab_device_alloc(zab_engine* e, int64_t bytes, void** out);
+int zab_device_free(zab_engine* e, void* p);
+int zab_device_upload(zab_engine* e, void* dst, const void* src, int64_t bytes);
+int zab_device_download(zab_engine* e, void* dst, const void* src, int64_t bytes);
+/* Fill a planar [n_instances][n_channels][frame_stride] float buffer with the benchmark's white noise
+ * (xorshift64 per instance) on the device; the noise id of instance i is id_offset + i. */
+int zab_device_noise(zab_engine* e, void* dst, int64_t frames, int64_t frame_stride, uint64_t id_offset);
+
+/* Timing of the most recent zab_process: HIP events recorded on the engine's stream around the kernel launches.
+ * kernel_ms = sum over launches; launches = number of kernel launches. */
+int zab_last_timing(zab_engine* e, double* kernel_ms, int32_t* launches);
+void* zab_stream(zab_engine* e);   /* hipStream_t of the engine */
+int zab_used_fast_path(zab_engine* e); /* 1 if the most recent zab_process ran the leaf's hand-written kernel */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZABATCH_H */

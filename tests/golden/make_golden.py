@@ -1,0 +1,142 @@
+"""Generates the committed golden vectors from the REFERENCE ITSELF, in the dev container only.
+
+  * <leaf>_<case>.npz -- the reference's WDL/EEL2 VM (oracle/_ref, built from /root/reference/src/WDL) driven through
+    the shadow-runtime call sequence on seeded noise: float32 outputs, final vars by name, touched mem[], high-water.
+  * frontend.json -- per leaf: vars-table hash/count, specialised-function count, inferred I/O, obtained by importing
+    the reference's own front end (dsp_jsfx_aot.py; `llvmlite` is absent here, so an empty placeholder module object
+    is registered under that name first -- only code that never touches LLVM is called).
+  * wdl_fft.npz -- known-answer vectors of the reference WDL_fft / WDL_real_fft / permutation tables.
+
+Run:  python tests/golden/make_golden.py          (needs /root/reference; never runs on the GPU box)
+Fixtures are data only: inputs are regenerated from the seed (zajit/noise.py), nothing of the reference's text is stored.
+"""
+from __future__ import annotations
+
+import hashlib
+import json
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parent.parent
+REF = Path("/root/reference")
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "zorakaudio-experimental-plugins_amd"))
+
+from oracle import eel_oracle  # noqa: E402
+from zajit import noise, program, sliders  # noqa: E402
+
+# (leaf, case, slider overrides {index0: host value}, frames, block)
+CASES = [
+    ("DDT", "default", {}, 4096, 512),
+    ("DDT", "far_extreme", {0: 85, 1: 70, 2: 65, 3: 80, 4: 4, 5: 60, 6: -3.0, 8: 90}, 3072, 512),
+    ("DDT", "near_eco_direct", {0: 5, 1: 10, 4: 0, 7: 1, 8: 10}, 2048, 256),
+    ("DDT", "diffuse_ragged", {0: 55, 4: 3, 7: 2, 8: 35}, 1500, 500),
+    ("DPT", "default", {}, 2048, 512),
+    ("ADS", "default", {}, 2048, 512),
+    ("ATTACK", "default", {}, 2048, 512),
+    ("RTT", "default", {}, 2048, 512),
+    ("SaliencePush", "default", {}, 2048, 512),
+    ("EasyExpander", "default", {}, 2048, 512),
+    ("Roomalizer", "default", {}, 2048, 512),
+    ("ERBTilt", "default", {}, 2048, 512),
+    ("SpectralStabilizer", "default", {}, 2048, 512),
+    ("TSEQ", "default", {}, 2048, 512),
+]
+
+
+def leaf_path(leaf: str) -> Path:
+    hits = list((REF / "plugins").glob(f"*/{leaf}/src/*.jsfx"))
+    assert hits, leaf
+    return hits[0]
+
+
+def slider_row(decls, overrides):
+    row = sliders.default_slider_values(decls)
+    for i, hv in overrides.items():
+        row[i] = decls[i].to_slider_value(hv)
+    return row
+
+
+def make_case(leaf, case, overrides, frames, block):
+    path = leaf_path(leaf)
+    text = program.expand_imports(path)
+    prog = program.analyse(text, leaf)
+    decls = prog.slider_decls
+    row = slider_row(decls, overrides)
+    nch = max(1, prog.io["process"])
+    x = noise.white_noise([0], frames, channels=nch)[0]
+    o = eel_oracle.EelOracle(text, prog.aliases)
+    o.set_sliders(row)
+    o.prepare(48000.0)
+    vars_prep = {n: o.var(n) for n in prog.vars}
+    y = o.process(x, block)
+    names = sorted(prog.vars, key=lambda n: prog.vars[n])
+    vals = np.array([np.nan if o.var(n) is None else o.var(n) for n in names])
+    prep = np.array([np.nan if vars_prep[n] is None else vars_prep[n] for n in names])
+    high = o.mem_high
+    mem = o.mem(0, high) if high else np.zeros(0)
+    nz = np.flatnonzero(mem)
+    np.savez_compressed(HERE / f"{leaf}_{case}.npz", out=y, sliders=row, var_names=np.array(names), vars=vals,
+                        vars_prepared=prep, mem_idx=nz.astype(np.int64), mem_val=mem[nz], mem_high=np.int64(high),
+                        frames=np.int64(frames), block=np.int64(block), srate=np.float64(48000.0), nch=np.int64(nch),
+                        seed_instance=np.int64(0))
+    print(f"{leaf}_{case}: frames={frames} high={high} nonzero_mem={len(nz)} rms={np.sqrt(np.mean(y.astype(float) ** 2)):.6f}")
+
+
+def frontend_pins():
+    ll = types.ModuleType("llvmlite")
+    ll.ir = types.ModuleType("llvmlite.ir")
+    ll.binding = types.ModuleType("llvmlite.binding")
+    sys.modules.update({"llvmlite": ll, "llvmlite.ir": ll.ir, "llvmlite.binding": ll.binding})
+    sys.path.insert(0, str(REF))
+    import dsp_jsfx_aot as A  # the reference front end
+    out = {}
+    for path in sorted((REF / "plugins").glob("*/*/src/*.jsfx")):
+        leaf = path.parent.parent.name
+        txt = A.preprocess_jsfx_imports(path.read_text(encoding="utf-8", errors="replace"), path)
+        pipe = A.prepare_jsfx_pipeline(txt)
+        uv = A.collect_user_vars(pipe["programs"], pipe["fn_defs"])
+        io = A.infer_spl_io(pipe["programs"], pipe["fn_defs"], A.parse_pin_hints(txt))
+        out[leaf] = {
+            "nvars": len(uv),
+            "vars_sha1": hashlib.sha1(json.dumps(sorted(uv.items())).encode()).hexdigest(),
+            "nfns": len(pipe["fn_defs"]),
+            "fns_sha1": hashlib.sha1(json.dumps(sorted(pipe["fn_defs"].keys())).encode()).hexdigest(),
+            "io": {k: int(io[k]) for k in ("inputs", "outputs", "process", "max_read", "max_write")},
+            "memtop": int(A.resolve_jsfx_memtop_slots(A.parse_jsfx_options(txt))),
+            "sections": {k: bool(v) for k, v in pipe["programs"].items()},
+        }
+    (HERE / "frontend.json").write_text(json.dumps(out, indent=1, sort_keys=True))
+    print(f"frontend.json: {len(out)} leaves")
+
+
+def fft_vectors():
+    rng = np.random.default_rng(20261003)
+    d = {}
+    for n in (16, 32, 64, 128, 256, 512, 1024, 2048, 4096):
+        z = rng.standard_normal(2 * n)
+        d[f"c{n}_in"] = z
+        d[f"c{n}_fwd"] = eel_oracle.wdl_fft(z, n, False)
+        d[f"c{n}_inv"] = eel_oracle.wdl_fft(z, n, True)
+        d[f"perm{n}"] = eel_oracle.wdl_fft_permute(n)
+        r = rng.standard_normal(n)
+        d[f"r{n}_in"] = r
+        d[f"r{n}_fwd"] = eel_oracle.wdl_real_fft(r, n, False)
+        d[f"r{n}_inv"] = eel_oracle.wdl_real_fft(r, n, True)
+    np.savez_compressed(HERE / "wdl_fft.npz", **d)
+    print("wdl_fft.npz written")
+
+
+if __name__ == "__main__":
+    only = set(sys.argv[1:])
+    for c in CASES:
+        if not only or c[0] in only:
+            make_case(*c)
+    if not only or "frontend" in only:
+        frontend_pins()
+    if not only or "fft" in only:
+        fft_vectors()

@@ -1,0 +1,197 @@
+// zab_generic.hip.h -- translator back end: the generic gfx950 kernels every leaf module gets.
+//
+// Included at the end of a generated module source, after the ZA_* defines, zart.h and the zajit section code.
+// Mapping: ONE LANE PER INSTANCE, 64 instances per single-wave workgroup. Each lane keeps its DSPJSFX_State
+// (vars / used sliders / used spl) in registers for the whole launch and walks the host blocks serially, exactly
+// as jsfx_process_block does (dsp_jsfx_aot.py:5713-5905):
+//     samplesblock = n; @block; if any pending slider mask -> @slider; for each frame: f32->f64 spl[], @sample,
+//     f64->f32 out.
+// Audio is instance-major planar (include/zabatch.h), so a wave stages a [64 instances][NCH][TT frames] tile
+// through LDS: global reads/writes are 128-byte row segments (coalesced), the per-lane walk over its own row is
+// conflict-free thanks to the +1 padding (bank = (row*(TT+1)+t) mod 32).
+// vars/sliders/mem use the strides in ZabBatch, so the same code serves the interleaved layout (lanes of a wave
+// touch consecutive addresses whenever instances share control flow and indices) and the instance-major one.
+#pragma once
+
+#include "zab_module.h"
+
+#ifndef ZA_NCH
+#error "generated defines missing"
+#endif
+
+#if ZA_NCH <= 4
+#define ZA_TT 32
+#elif ZA_NCH <= 8
+#define ZA_TT 16
+#elif ZA_NCH <= 16
+#define ZA_TT 8
+#elif ZA_NCH <= 32
+#define ZA_TT 4
+#else
+#define ZA_TT 2
+#endif
+
+typedef ZaState<ZA_NV> ZaS;
+
+__device__ __forceinline__ void za_state_bind(ZaS& s, const ZabBatch& b, int inst) {
+  s.srate = b.srate;
+  s.samplesblock = 0.0;
+  s.midi_bus = 0.0;
+  s.ext_midi_bus = 0.0;
+  s.mem = b.mem + (int64_t)inst * b.mem_si;
+  s.mem_stride = b.mem_se;
+  s.mem_cap = b.mem_cap;
+  s.mem_high = b.mem_high[inst];
+  s.mem_need = b.mem_need[inst];
+  s.mt = b.mt + (int64_t)inst * b.mt_si;
+  s.mt_stride = b.mt_se;
+  s.mti = b.mti[inst];
+  s.err = b.err[inst];
+  s.pend_change = b.pend[inst];
+  s.pend_automate = b.pend[b.n_pad + inst];
+  s.pend_automate_end = b.pend[2 * b.n_pad + inst];
+  s.vis_mask = b.vis_mask[inst];
+  s.vis_init = b.vis_init[inst];
+  s.block_size = 0;
+  s.gmem = (const ZaGmemView*)b.gmem;
+  s.pool = (const ZaPoolView*)b.pool;
+  s.instance_id = b.first_id + (uint64_t)inst;
+  s.sink = 0.0;
+  s.memtop = ZA_MEMTOP;
+}
+
+__device__ __forceinline__ void za_state_load(ZaS& s, const ZabBatch& b, int inst) {
+  za_state_bind(s, b, inst);
+#pragma unroll
+  for (int k = 0; k < ZA_NV; ++k) s.v[k] = b.vars[k * b.var_se + inst * b.var_si];
+#define ZA_X(k) s.sl[k] = b.sliders[(k) * b.sl_se + inst * b.sl_si];
+  ZA_FOR_USED_SL(ZA_X)
+#undef ZA_X
+#define ZA_X(k) s.spl[k] = b.spl[(k) * b.sl_se + inst * b.sl_si];
+  ZA_FOR_USED_SPL(ZA_X)
+#undef ZA_X
+}
+
+__device__ __forceinline__ void za_state_store(const ZaS& s, const ZabBatch& b, int inst) {
+#pragma unroll
+  for (int k = 0; k < ZA_NV; ++k) b.vars[k * b.var_se + inst * b.var_si] = s.v[k];
+#define ZA_X(k) b.sliders[(k) * b.sl_se + inst * b.sl_si] = s.sl[k];
+  ZA_FOR_USED_SL(ZA_X)
+#undef ZA_X
+#define ZA_X(k) b.spl[(k) * b.sl_se + inst * b.sl_si] = s.spl[k];
+  ZA_FOR_USED_SPL(ZA_X)
+#undef ZA_X
+  b.mem_high[inst] = s.mem_high;
+  b.mem_need[inst] = s.mem_need;
+  b.mti[inst] = s.mti;
+  b.err[inst] = s.err;
+  b.pend[inst] = s.pend_change;
+  b.pend[b.n_pad + inst] = s.pend_automate;
+  b.pend[2 * b.n_pad + inst] = s.pend_automate_end;
+  b.vis_mask[inst] = s.vis_mask;
+  b.vis_init[inst] = s.vis_init;
+}
+
+// sliderN:var=... aliases: the host keeps the named var equal to the slider (src/JSFXJuceProcessor.cpp:9349-9353)
+__device__ __forceinline__ void za_alias_sync(ZaS& s) {
+#define ZA_X(sl_idx, var_idx) s.v[var_idx] = s.sl[sl_idx];
+  ZA_FOR_ALIAS(ZA_X)
+#undef ZA_X
+}
+
+// prepareToPlay(): resetStateStructOnly (vars/spl zeroed, mem kept) -> sliders already pushed -> @init ->
+// alias re-apply -> @slider.   src/JSFXJuceProcessor.cpp:3251,3302-3318
+extern "C" __global__ void __launch_bounds__(64) ZA_KERNEL(prepare)(ZabBatch b) {
+  const int inst = blockIdx.x * 64 + threadIdx.x;
+  if (inst >= b.n_inst) return;
+  ZaS s;
+  za_state_bind(s, b, inst);
+#pragma unroll
+  for (int k = 0; k < ZA_NV; ++k) s.v[k] = 0.0;
+#define ZA_X(k) s.sl[k] = b.sliders[(k) * b.sl_se + inst * b.sl_si];
+  ZA_FOR_USED_SL(ZA_X)
+#undef ZA_X
+#define ZA_X(k) s.spl[k] = 0.0;
+  ZA_FOR_USED_SPL(ZA_X)
+#undef ZA_X
+  s.mti = 0;
+  s.pend_change = s.pend_automate = s.pend_automate_end = 0;
+  s.vis_mask = 0;
+  s.vis_init = 0;
+  za_alias_sync(s);
+  za_section_init(s);
+  za_alias_sync(s);
+  za_section_slider(s);
+  za_state_store(s, b, inst);
+  b.flags[inst] = ZAB_FLAG_PREPARED;
+}
+
+extern "C" __global__ void __launch_bounds__(64) ZA_KERNEL(process)(ZabBatch b, ZabAudio a) {
+#if ZA_NCH > 0
+  __shared__ float tile[ZA_NCH][64][ZA_TT + 1];
+#endif
+  const int lane = threadIdx.x;
+  const int inst0 = blockIdx.x * 64;
+  const int inst = inst0 + lane;
+  const bool active = inst < b.n_inst;
+  ZaS s;
+  if (active) {
+    za_state_load(s, b, inst);
+    if (b.flags[inst] & ZAB_FLAG_SLIDER_DIRTY) {      // processBlock: sliders changed -> jsfx_slider (:3545-3547)
+      za_alias_sync(s);
+      za_section_slider(s);
+      b.flags[inst] &= ~ZAB_FLAG_SLIDER_DIRTY;
+    }
+  }
+  for (int64_t pos = 0; pos < a.frames; pos += a.block) {
+    const int n = (int)((a.frames - pos < a.block) ? (a.frames - pos) : a.block);
+    if (active) {
+      s.samplesblock = (double)n;
+      s.block_size = n;
+      za_section_block(s);
+      if (s.pend_change | s.pend_automate | s.pend_automate_end) za_section_slider(s);
+    }
+#if ZA_HAS_SAMPLE && ZA_NCH > 0
+    for (int t0 = 0; t0 < n; t0 += ZA_TT) {
+      const int tn = (n - t0 < ZA_TT) ? (n - t0) : ZA_TT;
+      for (int idx = lane; idx < 64 * ZA_NCH * ZA_TT; idx += 64) {
+        const int t = idx % ZA_TT, rc = idx / ZA_TT, ch = rc % ZA_NCH, row = rc / ZA_NCH;
+        float x = 0.0f;
+        if (t < tn && inst0 + row < b.n_inst)
+          x = a.in[((int64_t)(inst0 + row) * ZA_NCH + ch) * a.frame_stride + pos + t0 + t];
+        tile[ch][row][t] = x;
+      }
+      __syncthreads();
+      if (active) {
+        for (int t = 0; t < tn; ++t) {
+#define ZA_X(ch) s.spl[ch] = (double)tile[ch][lane][t];
+          ZA_FOR_CH(ZA_X)
+#undef ZA_X
+          za_section_sample(s);
+#define ZA_X(ch) tile[ch][lane][t] = (float)s.spl[ch];
+          ZA_FOR_CH(ZA_X)
+#undef ZA_X
+        }
+      }
+      __syncthreads();
+      for (int idx = lane; idx < 64 * ZA_NCH * ZA_TT; idx += 64) {
+        const int t = idx % ZA_TT, rc = idx / ZA_TT, ch = rc % ZA_NCH, row = rc / ZA_NCH;
+        if (t < tn && inst0 + row < b.n_inst)
+          a.out[((int64_t)(inst0 + row) * ZA_NCH + ch) * a.frame_stride + pos + t0 + t] = tile[ch][row][t];
+      }
+      __syncthreads();
+    }
+#endif
+    if (active) s.pend_change = s.pend_automate = s.pend_automate_end = 0;   // consumeDspSliderChanges (:3745)
+  }
+  if (active) za_state_store(s, b, inst);
+}
+
+static hipError_t za_launch_prepare(const ZabBatch* b, hipStream_t st) {
+  hipLaunchKernelGGL(ZA_KERNEL(prepare), dim3((b->n_inst + 63) / 64), dim3(64), 0, st, *b);
+  return hipGetLastError();
+}
+static hipError_t za_launch_process(const ZabBatch* b, const ZabAudio* a, hipStream_t st) {
+  hipLaunchKernelGGL(ZA_KERNEL(process), dim3((b->n_inst + 63) / 64), dim3(64), 0, st, *b, *a);
+  return hipGetLastError();
+}

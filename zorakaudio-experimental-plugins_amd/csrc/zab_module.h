@@ -1,0 +1,68 @@
+// zab_module.h -- internal contract between libzabatch.so (host runtime, C ABI) and a plugin module
+// (libzab_<leaf>.so: zajit-generated section code + generic kernels [+ a hand-written leaf kernel]).
+// Not part of the public boundary (include/zabatch.h is).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define ZAB_MODULE_ABI 3
+
+enum { ZAB_FLAG_SLIDER_DIRTY = 1u, ZAB_FLAG_PREPARED = 2u };
+
+// Device-resident state of N instances of one leaf. Plain strides so one generated kernel serves both layouts:
+//   interleaved   (generic default): element e of instance i at base[e * n_pad + i]        (se = n_pad, si = 1)
+//   instance-major (leaf kernels):   element e of instance i at base[i * extent + e]       (se = 1, si = extent)
+struct ZabBatch {
+  int32_t n_inst;        // live instances
+  int32_t n_pad;         // allocation width, multiple of 64
+  int32_t instance_major;
+  int32_t nvars;
+  double* vars;   int64_t var_se, var_si;      // DSPJSFX_State::vars
+  double* sliders; int64_t sl_se, sl_si;       // DSPJSFX_State::sliders[64]
+  double* spl;                                 // DSPJSFX_State::spl[64], strides as sliders
+  double* mem;    int64_t mem_se, mem_si, mem_cap;   // DSPJSFX_State::mem / memN
+  uint32_t* mt;   int64_t mt_se, mt_si;        // randMT[624]
+  uint32_t* mti;                               // randIndex            [n_pad]
+  int64_t* mem_high;                           // write high-water     [n_pad]
+  int64_t* mem_need;                           // capacity wanted      [n_pad]
+  uint32_t* err;                               // ZA_ERR_* bits        [n_pad]
+  uint32_t* flags;                             // ZAB_FLAG_*           [n_pad]
+  uint64_t* pend;                              // pendingSlider{Change,Automate,AutomateEnd}Mask  [3][n_pad]
+  uint64_t* vis_mask;                          // sliderVisibleMask    [n_pad]
+  int32_t* vis_init;                           // sliderVisibilityInit [n_pad]
+  double srate;
+  uint64_t first_id;
+  const void* gmem;                            // ZaGmemView* (device) or null
+  const void* pool;                            // ZaPoolView* (device) or null
+  uint64_t epoch;                              // bumped by the runtime whenever host calls may have changed state
+};
+
+struct ZabAudio {
+  const float* in;       // planar [n_inst][nch][frame_stride]
+  float* out;
+  int64_t frames;
+  int64_t frame_stride;
+  int32_t block;         // host block size (jsfx_process_block numSamples), last block short
+};
+
+struct ZabModule {
+  int32_t abi;
+  const char* name;
+  int32_t nvars, nch, n_in, n_out;
+  int32_t has_init, has_slider, has_block, has_sample;
+  int32_t prefer_instance_major;
+  int64_t default_mem_cap;
+  const char* const* var_names;      // [nvars], index order
+  // generic (translator-generated) kernels
+  hipError_t (*launch_prepare)(const ZabBatch*, hipStream_t);
+  hipError_t (*launch_process)(const ZabBatch*, const ZabAudio*, hipStream_t);
+  // optional hand-written leaf kernel; applies() decides from host-visible config, launch may still defer
+  // per instance to the generic kernel through `fallback_mask` semantics documented by the leaf
+  int32_t (*fast_applies)(const ZabBatch*, const ZabAudio*);
+  hipError_t (*launch_fast)(const ZabBatch*, const ZabAudio*, hipStream_t);
+  const char* fast_kernel_name;
+  const char* generic_kernel_name;
+};
+
+extern "C" const ZabModule* zab_module_get(void);

@@ -1,0 +1,448 @@
+// zabatch.hip -- libzabatch.so: the C ABI of include/zabatch.h over HIP.
+//
+// Host side only orchestrates: it owns device allocations, loads a plugin module (libzab_<leaf>.so), launches the
+// module's kernels on one stream and surfaces device-latched errors. All DSP -- @init/@slider/@block/@sample --
+// runs on the GPU; there is no CPU execution path in this library.
+//
+// Reference call sites this replaces: src/JSFXJuceProcessor.cpp:3239-3342 (prepareToPlay),
+// :3435-3772 (processBlock), :8958-8971 (mem calloc), :9286-9357 (slider push).
+#include "../../include/zabatch.h"
+#include "zab_module.h"
+
+#include <dlfcn.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess) return fail(ZAB_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));   \
+  } while (0)
+
+std::string lib_dir() {
+  Dl_info info;
+  if (dladdr((void*)&lib_dir, &info) && info.dli_fname) {
+    std::string p = info.dli_fname;
+    size_t k = p.rfind('/');
+    return k == std::string::npos ? "." : p.substr(0, k);
+  }
+  return ".";
+}
+
+// ---- white-noise generator for benchmarks / tests (host twin: zajit/noise.py) ----------
+__global__ void zab_k_noise(float* dst, int n_inst, int nch, int64_t frames, int64_t stride, uint64_t id0) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_inst) return;
+  uint64_t x = 0x9E3779B97F4A7C15ull ^ ((id0 + (uint64_t)i) * 0xD1B54A32D192ED03ull);
+  if (x == 0) x = 0x9E3779B97F4A7C15ull;
+  float* base = dst + (int64_t)i * nch * stride;
+  for (int64_t t = 0; t < frames; ++t)
+    for (int c = 0; c < nch; ++c) {
+      x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+      const double u = (double)(x >> 11) * (1.0 / 9007199254740992.0);
+      base[(int64_t)c * stride + t] = (float)((u * 2.0 - 1.0) * 0.5);
+    }
+}
+
+}  // namespace
+
+struct zab_engine {
+  void* dl = nullptr;
+  const ZabModule* mod = nullptr;
+  zab_config cfg{};
+  ZabBatch b{};
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool prepared = false;
+  bool timing_valid = false;
+  int launches = 0;
+  bool used_fast = false;
+  std::vector<void*> owned;
+  float* stage_in = nullptr;
+  float* stage_out = nullptr;
+  int64_t stage_bytes = 0;
+
+  template <class T>
+  int alloc(T** p, size_t count) {
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, count * sizeof(T));
+    if (e != hipSuccess) return fail(ZAB_E_HIP, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+    e = hipMemsetAsync(q, 0, count * sizeof(T), stream);
+    if (e != hipSuccess) return fail(ZAB_E_HIP, "hipMemset failed: %s", hipGetErrorString(e));
+    owned.push_back(q);
+    *p = (T*)q;
+    return ZAB_OK;
+  }
+};
+
+extern "C" {
+
+const char* zab_last_error(void) { return g_err.c_str(); }
+int zab_abi_version(void) { return ZAB_MODULE_ABI; }
+
+int zab_create(const char* module, const zab_config* cfg, zab_engine** out) {
+  if (!module || !cfg || !out) return fail(ZAB_E_ARG, "zab_create: null argument");
+  if (cfg->n_instances <= 0) return fail(ZAB_E_ARG, "zab_create: n_instances must be > 0");
+  if (!(cfg->srate > 0.0)) return fail(ZAB_E_ARG, "zab_create: srate must be > 0");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t de = hipGetDeviceCount(&ndev);
+  if (de != hipSuccess || ndev <= 0)
+    return fail(ZAB_E_HIP, "no HIP device available (%s): the engine has no CPU fallback",
+                de == hipSuccess ? "device count 0" : hipGetErrorString(de));
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(ZAB_E_ARG, "device %d out of range (%d devices)", cfg->device, ndev);
+
+  std::string path = module;
+  if (path.find('/') == std::string::npos && path.find(".so") == std::string::npos)
+    path = lib_dir() + "/libzab_" + path + ".so";
+  void* dl = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+  if (!dl) return fail(ZAB_E_MODULE, "cannot load plugin module %s: %s", path.c_str(), dlerror());
+  typedef const ZabModule* (*getter)(void);
+  getter g = (getter)dlsym(dl, "zab_module_get");
+  if (!g) { dlclose(dl); return fail(ZAB_E_MODULE, "%s exports no zab_module_get", path.c_str()); }
+  const ZabModule* m = g();
+  if (!m || m->abi != ZAB_MODULE_ABI) {
+    dlclose(dl);
+    return fail(ZAB_E_MODULE, "%s: module ABI %d, runtime ABI %d", path.c_str(), m ? m->abi : -1, ZAB_MODULE_ABI);
+  }
+
+  zab_engine* e = new zab_engine();
+  e->dl = dl; e->mod = m; e->cfg = *cfg;
+  if (e->cfg.max_block <= 0) e->cfg.max_block = 512;
+  int rc = ZAB_OK;
+  hipError_t he;
+  if ((he = hipSetDevice(cfg->device)) != hipSuccess || (he = hipStreamCreate(&e->stream)) != hipSuccess ||
+      (he = hipEventCreate(&e->ev0)) != hipSuccess || (he = hipEventCreate(&e->ev1)) != hipSuccess) {
+    rc = fail(ZAB_E_HIP, "HIP stream/event setup failed: %s", hipGetErrorString(he));
+    zab_destroy(e);
+    return rc;
+  }
+  ZabBatch& b = e->b;
+  b.n_inst = cfg->n_instances;
+  b.n_pad = (cfg->n_instances + 63) / 64 * 64;
+  b.nvars = m->nvars;
+  b.instance_major = m->prefer_instance_major ? 1 : 0;
+  b.mem_cap = cfg->mem_cap > 0 ? cfg->mem_cap : m->default_mem_cap;
+  b.srate = cfg->srate;
+  b.first_id = cfg->first_instance_id ? cfg->first_instance_id : 1;
+  const int64_t P = b.n_pad;
+  if (b.instance_major) {
+    b.var_se = 1; b.var_si = m->nvars;
+    b.sl_se = 1; b.sl_si = 64;
+    b.mem_se = 1; b.mem_si = b.mem_cap;
+    b.mt_se = 1; b.mt_si = 624;
+  } else {
+    b.var_se = P; b.var_si = 1;
+    b.sl_se = P; b.sl_si = 1;
+    b.mem_se = P; b.mem_si = 1;
+    b.mt_se = P; b.mt_si = 1;
+  }
+  if ((rc = e->alloc(&b.vars, (size_t)P * m->nvars)) || (rc = e->alloc(&b.sliders, (size_t)P * 64)) ||
+      (rc = e->alloc(&b.spl, (size_t)P * 64)) || (rc = e->alloc(&b.mem, (size_t)P * b.mem_cap)) ||
+      (rc = e->alloc(&b.mt, (size_t)P * 624)) || (rc = e->alloc(&b.mti, (size_t)P)) ||
+      (rc = e->alloc(&b.mem_high, (size_t)P)) || (rc = e->alloc(&b.mem_need, (size_t)P)) ||
+      (rc = e->alloc(&b.err, (size_t)P)) || (rc = e->alloc(&b.flags, (size_t)P)) ||
+      (rc = e->alloc(&b.pend, (size_t)P * 3)) || (rc = e->alloc(&b.vis_mask, (size_t)P)) ||
+      (rc = e->alloc(&b.vis_init, (size_t)P))) {
+    zab_destroy(e);
+    return rc;
+  }
+  if ((he = hipStreamSynchronize(e->stream)) != hipSuccess) {
+    rc = fail(ZAB_E_HIP, "state clear failed: %s", hipGetErrorString(he));
+    zab_destroy(e);
+    return rc;
+  }
+  *out = e;
+  return ZAB_OK;
+}
+
+int zab_destroy(zab_engine* e) {
+  if (!e) return ZAB_OK;
+  if (e->stream) hipStreamSynchronize(e->stream);
+  for (void* p : e->owned) hipFree(p);
+  if (e->stage_in) hipFree(e->stage_in);
+  if (e->stage_out) hipFree(e->stage_out);
+  if (e->ev0) hipEventDestroy(e->ev0);
+  if (e->ev1) hipEventDestroy(e->ev1);
+  if (e->stream) hipStreamDestroy(e->stream);
+  // the module stays loaded: its code object is registered with the HIP runtime for the process lifetime
+  delete e;
+  return ZAB_OK;
+}
+
+int zab_get_info(zab_engine* e, zab_info* o) {
+  if (!e || !o) return fail(ZAB_E_ARG, "zab_get_info: null argument");
+  memset(o, 0, sizeof *o);
+  snprintf(o->name, sizeof o->name, "%s", e->mod->name);
+  o->nvars = e->mod->nvars; o->n_channels = e->mod->nch; o->n_inputs = e->mod->n_in; o->n_outputs = e->mod->n_out;
+  o->has_init = e->mod->has_init; o->has_slider = e->mod->has_slider; o->has_block = e->mod->has_block;
+  o->has_sample = e->mod->has_sample; o->has_fast_path = e->mod->launch_fast != nullptr;
+  o->mem_cap = e->b.mem_cap; o->n_instances = e->b.n_inst; o->layout_instance_major = e->b.instance_major;
+  return ZAB_OK;
+}
+
+int zab_var_count(zab_engine* e) { return e ? e->mod->nvars : 0; }
+const char* zab_var_name(zab_engine* e, int i) {
+  if (!e || i < 0 || i >= e->mod->nvars || !e->mod->var_names) return "";
+  return e->mod->var_names[i];
+}
+int zab_var_index(zab_engine* e, const char* name) {
+  if (!e || !name || !e->mod->var_names) return -1;
+  for (int i = 0; i < e->mod->nvars; ++i) if (!strcmp(e->mod->var_names[i], name)) return i;
+  return -1;
+}
+
+static int range_ok(zab_engine* e, int32_t first, int32_t count) {
+  return first >= 0 && count >= 0 && (int64_t)first + count <= e->b.n_inst;
+}
+
+int zab_set_sliders(zab_engine* e, int32_t first, int32_t count, const double* values) {
+  if (!e || !values) return fail(ZAB_E_ARG, "zab_set_sliders: null argument");
+  const bool bcast = (count == 0 && first == 0);
+  if (!bcast && !range_ok(e, first, count)) return fail(ZAB_E_ARG, "zab_set_sliders: range [%d,+%d) outside batch", first, count);
+  const ZabBatch& b = e->b;
+  const int lo = bcast ? 0 : first, n = bcast ? b.n_inst : count;
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  // stage as the device layout of the touched range; dirty flags only where a value actually changed
+  std::vector<double> cur((size_t)n * 64);
+  std::vector<uint32_t> flags((size_t)n);
+  HIP_TRY(hipMemcpy(flags.data(), b.flags + lo, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+  if (b.instance_major) {
+    HIP_TRY(hipMemcpy(cur.data(), b.sliders + (size_t)lo * 64, sizeof(double) * 64 * n, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) {
+      const double* src = values + (bcast ? 0 : (size_t)i * 64);
+      if (memcmp(&cur[(size_t)i * 64], src, 64 * sizeof(double))) { memcpy(&cur[(size_t)i * 64], src, 64 * sizeof(double)); flags[i] |= ZAB_FLAG_SLIDER_DIRTY; }
+    }
+    HIP_TRY(hipMemcpy(b.sliders + (size_t)lo * 64, cur.data(), sizeof(double) * 64 * n, hipMemcpyHostToDevice));
+  } else {
+    HIP_TRY(hipMemcpy2D(cur.data(), sizeof(double) * n, b.sliders + lo, sizeof(double) * b.n_pad, sizeof(double) * n, 64, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) {
+      const double* src = values + (bcast ? 0 : (size_t)i * 64);
+      bool ch = false;
+      for (int k = 0; k < 64; ++k) {
+        double& d = cur[(size_t)k * n + i];
+        if (memcmp(&d, &src[k], sizeof(double))) { d = src[k]; ch = true; }
+      }
+      if (ch) flags[i] |= ZAB_FLAG_SLIDER_DIRTY;
+    }
+    HIP_TRY(hipMemcpy2D(b.sliders + lo, sizeof(double) * b.n_pad, cur.data(), sizeof(double) * n, sizeof(double) * n, 64, hipMemcpyHostToDevice));
+  }
+  HIP_TRY(hipMemcpy(b.flags + lo, flags.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
+  e->b.epoch++;
+  return ZAB_OK;
+}
+
+static int read_strided(zab_engine* e, const double* base, int64_t se, int64_t si, int32_t first, int32_t count,
+                        int64_t e0, int64_t ne, double* dst) {
+  // dst[i][k] = base[(e0+k)*se + (first+i)*si]
+  if (ne <= 0 || count <= 0) return ZAB_OK;
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (se == 1) {
+    HIP_TRY(hipMemcpy2D(dst, sizeof(double) * ne, base + (int64_t)first * si + e0, sizeof(double) * si, sizeof(double) * ne,
+                        count, hipMemcpyDeviceToHost));
+    return ZAB_OK;
+  }
+  std::vector<double> tmp((size_t)ne * count);
+  HIP_TRY(hipMemcpy2D(tmp.data(), sizeof(double) * count, base + e0 * se + first, sizeof(double) * se, sizeof(double) * count,
+                      ne, hipMemcpyDeviceToHost));
+  for (int64_t k = 0; k < ne; ++k)
+    for (int i = 0; i < count; ++i) dst[(size_t)i * ne + k] = tmp[(size_t)k * count + i];
+  return ZAB_OK;
+}
+
+int zab_get_sliders(zab_engine* e, int32_t first, int32_t count, double* values) {
+  if (!e || !values || !range_ok(e, first, count)) return fail(ZAB_E_ARG, "zab_get_sliders: bad argument");
+  return read_strided(e, e->b.sliders, e->b.sl_se, e->b.sl_si, first, count, 0, 64, values);
+}
+
+static int check_device_errors(zab_engine* e, const char* where) {
+  const ZabBatch& b = e->b;
+  std::vector<uint32_t> err((size_t)b.n_inst);
+  HIP_TRY(hipMemcpy(err.data(), b.err, sizeof(uint32_t) * b.n_inst, hipMemcpyDeviceToHost));
+  uint32_t any = 0; int who = -1;
+  for (int i = 0; i < b.n_inst; ++i) if (err[i] & 7u) { any |= err[i]; if (who < 0) who = i; }
+  if (!any) return ZAB_OK;
+  HIP_TRY(hipMemset(b.err, 0, sizeof(uint32_t) * b.n_pad));
+  if (any & 1u) {
+    std::vector<int64_t> need((size_t)b.n_inst);
+    HIP_TRY(hipMemcpy(need.data(), b.mem_need, sizeof(int64_t) * b.n_inst, hipMemcpyDeviceToHost));
+    int64_t mx = 0;
+    for (int64_t v : need) mx = v > mx ? v : mx;
+    return fail(ZAB_E_MEM_OVERFLOW, "%s: %s stored to mem[] past the arena (instance %d first): mem_cap=%lld, needed >= %lld; "
+                "state is invalid, recreate with a larger zab_config.mem_cap", where, e->mod->name, who, (long long)b.mem_cap, (long long)mx);
+  }
+  if (any & 4u) return fail(ZAB_E_UNSUPPORTED, "%s: %s reached a host-only builtin (MIDI/file/msg) on the device (instance %d)", where, e->mod->name, who);
+  return fail(ZAB_E_LOOP_CAP, "%s: %s exceeded the loop safety cap (instance %d)", where, e->mod->name, who);
+}
+
+int zab_prepare(zab_engine* e) {
+  if (!e) return fail(ZAB_E_ARG, "zab_prepare: null engine");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  hipError_t he = e->mod->launch_prepare(&e->b, e->stream);
+  if (he != hipSuccess) return fail(ZAB_E_HIP, "prepare launch failed: %s", hipGetErrorString(he));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->prepared = true;
+  e->b.epoch++;
+  return check_device_errors(e, "zab_prepare");
+}
+
+int zab_process(zab_engine* e, const void* in, void* out, int64_t frames, int64_t frame_stride, int32_t block, int32_t placement) {
+  if (!e) return fail(ZAB_E_ARG, "zab_process: null engine");
+  if (!e->prepared) return fail(ZAB_E_STATE, "zab_process before zab_prepare");
+  const int nch = e->mod->nch;
+  if (frames < 0 || block <= 0 || frame_stride < frames) return fail(ZAB_E_ARG, "zab_process: bad frames/block/stride");
+  if (block > e->cfg.max_block) return fail(ZAB_E_ARG, "zab_process: block %d > max_block %d", block, e->cfg.max_block);
+  if (nch > 0 && e->mod->has_sample && (!in || !out)) return fail(ZAB_E_ARG, "zab_process: null audio buffer");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  ZabAudio a{};
+  a.frames = frames; a.frame_stride = frame_stride; a.block = block;
+  const int64_t bytes = (int64_t)e->b.n_inst * nch * frame_stride * (int64_t)sizeof(float);
+  if (placement == ZAB_BUF_HOST) {
+    if (bytes > e->stage_bytes) {
+      if (e->stage_in) hipFree(e->stage_in);
+      if (e->stage_out) hipFree(e->stage_out);
+      e->stage_in = e->stage_out = nullptr; e->stage_bytes = 0;
+      HIP_TRY(hipMalloc((void**)&e->stage_in, bytes));
+      HIP_TRY(hipMalloc((void**)&e->stage_out, bytes));
+      e->stage_bytes = bytes;
+    }
+    if (bytes) HIP_TRY(hipMemcpyAsync(e->stage_in, in, bytes, hipMemcpyHostToDevice, e->stream));
+    a.in = e->stage_in; a.out = e->stage_out;
+  } else if (placement == ZAB_BUF_DEVICE) {
+    a.in = (const float*)in; a.out = (float*)out;
+  } else {
+    return fail(ZAB_E_ARG, "zab_process: placement %d", placement);
+  }
+  bool fast = false;
+  if (e->cfg.path != ZAB_PATH_GENERIC && e->mod->launch_fast && e->mod->fast_applies) fast = e->mod->fast_applies(&e->b, &a) != 0;
+  if (e->cfg.path == ZAB_PATH_FAST && !fast)
+    return fail(ZAB_E_ARG, "ZAB_PATH_FAST requested but %s's hand-written kernel does not apply to this configuration", e->mod->name);
+  HIP_TRY(hipEventRecord(e->ev0, e->stream));
+  hipError_t he = fast ? e->mod->launch_fast(&e->b, &a, e->stream) : e->mod->launch_process(&e->b, &a, e->stream);
+  if (he != hipSuccess) return fail(ZAB_E_HIP, "process launch failed: %s", hipGetErrorString(he));
+  HIP_TRY(hipEventRecord(e->ev1, e->stream));
+  e->timing_valid = true; e->launches = 1; e->used_fast = fast;
+  if (placement == ZAB_BUF_HOST) {
+    if (bytes) HIP_TRY(hipMemcpyAsync(out, e->stage_out, bytes, hipMemcpyDeviceToHost, e->stream));
+    return zab_sync(e);
+  }
+  return ZAB_OK;
+}
+
+int zab_sync(zab_engine* e) {
+  if (!e) return fail(ZAB_E_ARG, "zab_sync: null engine");
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return check_device_errors(e, "zab_process");
+}
+
+int zab_read_vars(zab_engine* e, int32_t first, int32_t count, double* dst) {
+  if (!e || !dst || !range_ok(e, first, count)) return fail(ZAB_E_ARG, "zab_read_vars: bad argument");
+  return read_strided(e, e->b.vars, e->b.var_se, e->b.var_si, first, count, 0, e->mod->nvars, dst);
+}
+
+int zab_read_mem(zab_engine* e, int32_t first, int32_t count, int64_t start, int64_t n, double* dst) {
+  if (!e || !dst || !range_ok(e, first, count) || start < 0 || n < 0) return fail(ZAB_E_ARG, "zab_read_mem: bad argument");
+  const int64_t avail = start < e->b.mem_cap ? (e->b.mem_cap - start < n ? e->b.mem_cap - start : n) : 0;
+  if (avail < n) memset(dst, 0, sizeof(double) * (size_t)count * n);   // beyond the arena reads 0, like ungrown mem
+  if (avail == n) return read_strided(e, e->b.mem, e->b.mem_se, e->b.mem_si, first, count, start, n, dst);
+  if (avail > 0) {
+    std::vector<double> tmp((size_t)count * avail);
+    int rc = read_strided(e, e->b.mem, e->b.mem_se, e->b.mem_si, first, count, start, avail, tmp.data());
+    if (rc) return rc;
+    for (int i = 0; i < count; ++i) memcpy(dst + (size_t)i * n, &tmp[(size_t)i * avail], sizeof(double) * avail);
+  }
+  return ZAB_OK;
+}
+
+int zab_write_mem(zab_engine* e, int32_t first, int32_t count, int64_t start, int64_t n, const double* src) {
+  if (!e || !src || !range_ok(e, first, count) || start < 0 || n < 0) return fail(ZAB_E_ARG, "zab_write_mem: bad argument");
+  if (start + n > e->b.mem_cap) return fail(ZAB_E_MEM_OVERFLOW, "zab_write_mem: [%lld,+%lld) beyond mem_cap %lld", (long long)start, (long long)n, (long long)e->b.mem_cap);
+  if (!n || !count) return ZAB_OK;
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  const ZabBatch& b = e->b;
+  if (b.mem_se == 1) {
+    HIP_TRY(hipMemcpy2D(b.mem + (int64_t)first * b.mem_si + start, sizeof(double) * b.mem_si, src, sizeof(double) * n, sizeof(double) * n, count, hipMemcpyHostToDevice));
+  } else {
+    std::vector<double> tmp((size_t)n * count);
+    for (int64_t k = 0; k < n; ++k) for (int i = 0; i < count; ++i) tmp[(size_t)k * count + i] = src[(size_t)i * n + k];
+    HIP_TRY(hipMemcpy2D(b.mem + start * b.mem_se + first, sizeof(double) * b.mem_se, tmp.data(), sizeof(double) * count, sizeof(double) * count, n, hipMemcpyHostToDevice));
+  }
+  std::vector<int64_t> hi((size_t)count);
+  HIP_TRY(hipMemcpy(hi.data(), b.mem_high + first, sizeof(int64_t) * count, hipMemcpyDeviceToHost));
+  for (auto& h : hi) if (h < start + n) h = start + n;
+  HIP_TRY(hipMemcpy(b.mem_high + first, hi.data(), sizeof(int64_t) * count, hipMemcpyHostToDevice));
+  e->b.epoch++;
+  return ZAB_OK;
+}
+
+int zab_read_mem_high(zab_engine* e, int32_t first, int32_t count, int64_t* dst) {
+  if (!e || !dst || !range_ok(e, first, count)) return fail(ZAB_E_ARG, "zab_read_mem_high: bad argument");
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  HIP_TRY(hipMemcpy(dst, e->b.mem_high + first, sizeof(int64_t) * count, hipMemcpyDeviceToHost));
+  return ZAB_OK;
+}
+
+int zab_device_alloc(zab_engine* e, int64_t bytes, void** out) {
+  if (!e || !out || bytes < 0) return fail(ZAB_E_ARG, "zab_device_alloc: bad argument");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipMalloc(out, (size_t)(bytes ? bytes : 1)));
+  return ZAB_OK;
+}
+int zab_device_free(zab_engine* e, void* p) {
+  if (!e) return fail(ZAB_E_ARG, "zab_device_free: null engine");
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  HIP_TRY(hipFree(p));
+  return ZAB_OK;
+}
+int zab_device_upload(zab_engine* e, void* dst, const void* src, int64_t bytes) {
+  if (!e) return fail(ZAB_E_ARG, "zab_device_upload: null engine");
+  HIP_TRY(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return ZAB_OK;
+}
+int zab_device_download(zab_engine* e, void* dst, const void* src, int64_t bytes) {
+  if (!e) return fail(ZAB_E_ARG, "zab_device_download: null engine");
+  HIP_TRY(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return ZAB_OK;
+}
+int zab_device_noise(zab_engine* e, void* dst, int64_t frames, int64_t frame_stride, uint64_t id_offset) {
+  if (!e || !dst || frames < 0 || frame_stride < frames) return fail(ZAB_E_ARG, "zab_device_noise: bad argument");
+  const int n = e->b.n_inst, nch = e->mod->nch;
+  hipLaunchKernelGGL(zab_k_noise, dim3((n + 63) / 64), dim3(64), 0, e->stream, (float*)dst, n, nch, frames, frame_stride, id_offset);
+  HIP_TRY(hipGetLastError());
+  return ZAB_OK;
+}
+
+int zab_last_timing(zab_engine* e, double* kernel_ms, int32_t* launches) {
+  if (!e || !e->timing_valid) return fail(ZAB_E_STATE, "zab_last_timing: no zab_process yet");
+  HIP_TRY(hipEventSynchronize(e->ev1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+  if (kernel_ms) *kernel_ms = ms;
+  if (launches) *launches = e->launches;
+  return ZAB_OK;
+}
+void* zab_stream(zab_engine* e) { return e ? (void*)e->stream : nullptr; }
+
+int zab_used_fast_path(zab_engine* e) { return e && e->used_fast ? 1 : 0; }
+
+}  // extern "C"

@@ -23,8 +23,9 @@
 #include <stdint.h>
 
 #if defined(__HIPCC__)
-#define ZA_FN __device__ __forceinline__
-#define ZA_NOINLINE __device__ __noinline__
+#include <hip/hip_runtime.h>
+#define ZA_FN __device__ inline __attribute__((always_inline))
+#define ZA_NOINLINE __device__ __attribute__((noinline))
 #else
 #define ZA_FN static inline __attribute__((always_inline))
 #define ZA_NOINLINE static __attribute__((noinline))

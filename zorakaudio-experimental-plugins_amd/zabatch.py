@@ -1,0 +1,329 @@
+"""ctypes binding of include/zabatch.h + a host-side mirror of the reference's processor surface.
+
+`JsfxBatchProcessor` keeps the call sequence of JSFXJuceProcessor (src/JSFXJuceProcessor.cpp:3239-3342 prepareToPlay,
+:3435-3772 processBlock, :9286-9357 pushParamsToStateSliders) with the same names and argument meaning, except that
+every call acts on N instances of the leaf living on one GPU. This module never computes DSP on the CPU: if the HIP
+library or the leaf's module is missing it raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+from pathlib import Path
+from typing import Optional
+
+import numpy as np
+
+PKG = Path(__file__).resolve().parent
+LIB_DIR = PKG / "lib"
+
+ZAB_PATH_AUTO, ZAB_PATH_GENERIC, ZAB_PATH_FAST = 0, 1, 2
+ZAB_BUF_DEVICE, ZAB_BUF_HOST = 0, 1
+
+
+class ZabError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"zabatch error {code}: {msg}")
+        self.code = code
+
+
+class zab_config(C.Structure):
+    _fields_ = [("n_instances", C.c_int32), ("device", C.c_int32), ("srate", C.c_double), ("max_block", C.c_int32),
+                ("path", C.c_int32), ("mem_cap", C.c_int64), ("first_instance_id", C.c_uint64)]
+
+
+class zab_info(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("nvars", C.c_int32), ("n_channels", C.c_int32), ("n_inputs", C.c_int32),
+                ("n_outputs", C.c_int32), ("has_init", C.c_int32), ("has_slider", C.c_int32), ("has_block", C.c_int32),
+                ("has_sample", C.c_int32), ("has_fast_path", C.c_int32), ("mem_cap", C.c_int64),
+                ("n_instances", C.c_int32), ("layout_instance_major", C.c_int32)]
+
+
+# every symbol include/zabatch.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = [
+    "zab_last_error", "zab_abi_version", "zab_create", "zab_destroy", "zab_get_info", "zab_var_count", "zab_var_name",
+    "zab_var_index", "zab_set_sliders", "zab_get_sliders", "zab_prepare", "zab_process", "zab_sync", "zab_read_vars",
+    "zab_read_mem", "zab_write_mem", "zab_read_mem_high", "zab_device_alloc", "zab_device_free", "zab_device_upload",
+    "zab_device_download", "zab_device_noise", "zab_last_timing", "zab_stream", "zab_used_fast_path",
+]
+
+_lib = None
+
+
+def runtime_path() -> Path:
+    return LIB_DIR / "libzabatch.so"
+
+
+def load_runtime():
+    """Load libzabatch.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = runtime_path()
+    if not p.exists():
+        raise ZabError(-2, f"{p} not built: run __graft_entry__.build() / python -m zajit.build")
+    L = C.CDLL(str(p))
+    vp, i32, i64, d = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    L.zab_last_error.restype = C.c_char_p
+    L.zab_create.argtypes = [C.c_char_p, C.POINTER(zab_config), C.POINTER(vp)]
+    L.zab_destroy.argtypes = [vp]
+    L.zab_get_info.argtypes = [vp, C.POINTER(zab_info)]
+    L.zab_var_count.argtypes = [vp]
+    L.zab_var_name.restype = C.c_char_p; L.zab_var_name.argtypes = [vp, C.c_int]
+    L.zab_var_index.argtypes = [vp, C.c_char_p]
+    L.zab_set_sliders.argtypes = [vp, i32, i32, C.POINTER(d)]
+    L.zab_get_sliders.argtypes = [vp, i32, i32, C.POINTER(d)]
+    L.zab_prepare.argtypes = [vp]
+    L.zab_process.argtypes = [vp, vp, vp, i64, i64, i32, i32]
+    L.zab_sync.argtypes = [vp]
+    L.zab_read_vars.argtypes = [vp, i32, i32, C.POINTER(d)]
+    L.zab_read_mem.argtypes = [vp, i32, i32, i64, i64, C.POINTER(d)]
+    L.zab_write_mem.argtypes = [vp, i32, i32, i64, i64, C.POINTER(d)]
+    L.zab_read_mem_high.argtypes = [vp, i32, i32, C.POINTER(i64)]
+    L.zab_device_alloc.argtypes = [vp, i64, C.POINTER(vp)]
+    L.zab_device_free.argtypes = [vp, vp]
+    L.zab_device_upload.argtypes = [vp, vp, vp, i64]
+    L.zab_device_download.argtypes = [vp, vp, vp, i64]
+    L.zab_device_noise.argtypes = [vp, vp, i64, i64, C.c_uint64]
+    L.zab_last_timing.argtypes = [vp, C.POINTER(d), C.POINTER(i32)]
+    L.zab_stream.restype = vp; L.zab_stream.argtypes = [vp]
+    L.zab_used_fast_path.argtypes = [vp]
+    _lib = L
+    return L
+
+
+def module_path(leaf: str) -> Path:
+    return LIB_DIR / f"libzab_{leaf}.so"
+
+
+def leaf_meta(leaf: str) -> dict:
+    p = LIB_DIR / f"{leaf}.json"
+    if not p.exists():
+        raise ZabError(-2, f"{p} missing: leaf {leaf} has not been built")
+    return json.loads(p.read_text())
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Engine:
+    """Thin RAII wrapper over zab_engine*."""
+
+    def __init__(self, leaf: str, n_instances: int, srate: float = 48000.0, max_block: int = 512, device: int = 0,
+                 path: int = ZAB_PATH_AUTO, mem_cap: int = 0, first_instance_id: int = 1):
+        self.L = load_runtime()
+        mp = module_path(leaf)
+        if not mp.exists():
+            raise ZabError(-2, f"{mp} missing: leaf {leaf} has not been built (no CPU fallback exists)")
+        cfg = zab_config(int(n_instances), int(device), float(srate), int(max_block), int(path), int(mem_cap),
+                         int(first_instance_id))
+        h = C.c_void_p()
+        self.h = None
+        self._chk(self.L.zab_create(str(mp).encode(), C.byref(cfg), C.byref(h)))
+        self.h = h
+        self.leaf = leaf
+        self.n = int(n_instances)
+        self.srate = float(srate)
+        info = zab_info()
+        self._chk(self.L.zab_get_info(self.h, C.byref(info)))
+        self.info = info
+        self.nch = info.n_channels
+        self.nvars = info.nvars
+        self._owned = []
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise ZabError(rc, self.L.zab_last_error().decode(errors="replace"))
+
+    def close(self):
+        if getattr(self, "h", None):
+            for p in list(self._owned):
+                self.L.zab_device_free(self.h, p)
+            self._owned.clear()
+            self.L.zab_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- metadata
+    def var_names(self):
+        return [self.L.zab_var_name(self.h, i).decode() for i in range(self.nvars)]
+
+    def var_index(self, name: str) -> int:
+        return int(self.L.zab_var_index(self.h, name.encode()))
+
+    # -- sliders / lifecycle
+    def set_sliders(self, values, first: int = 0, count: Optional[int] = None):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        if v.ndim == 1:
+            row = np.zeros(64)
+            row[: len(v)] = v
+            self._chk(self.L.zab_set_sliders(self.h, 0, 0, _dp(row)))
+            return
+        cnt = v.shape[0] if count is None else count
+        full = np.zeros((cnt, 64))
+        full[:, : v.shape[1]] = v[:cnt]
+        self._chk(self.L.zab_set_sliders(self.h, int(first), int(cnt), _dp(full)))
+
+    def get_sliders(self, first=0, count=None):
+        cnt = self.n - first if count is None else count
+        out = np.zeros((cnt, 64))
+        self._chk(self.L.zab_get_sliders(self.h, int(first), int(cnt), _dp(out)))
+        return out
+
+    def prepare(self):
+        self._chk(self.L.zab_prepare(self.h))
+
+    # -- audio
+    def process_host(self, x: np.ndarray, block: int = 512) -> np.ndarray:
+        """x: float32 [N, nch, frames] in host memory; staged over PCIe; returns the output array."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        assert x.shape[0] == self.n and x.shape[1] == self.nch, (x.shape, self.n, self.nch)
+        frames = x.shape[2]
+        y = np.empty_like(x)
+        self._chk(self.L.zab_process(self.h, x.ctypes.data, y.ctypes.data, frames, frames, int(block), ZAB_BUF_HOST))
+        return y
+
+    def device_alloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        self._chk(self.L.zab_device_alloc(self.h, int(nbytes), C.byref(p)))
+        self._owned.append(p.value)
+        return p.value
+
+    def device_free(self, p: int):
+        self._chk(self.L.zab_device_free(self.h, p))
+        if p in self._owned:
+            self._owned.remove(p)
+
+    def upload(self, dptr: int, arr: np.ndarray):
+        a = np.ascontiguousarray(arr)
+        self._chk(self.L.zab_device_upload(self.h, dptr, a.ctypes.data, a.nbytes))
+
+    def download(self, dptr: int, shape, dtype=np.float32) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        self._chk(self.L.zab_device_download(self.h, out.ctypes.data, dptr, out.nbytes))
+        return out
+
+    def device_noise(self, dptr: int, frames: int, stride: Optional[int] = None, id_offset: int = 0):
+        self._chk(self.L.zab_device_noise(self.h, dptr, int(frames), int(stride or frames), int(id_offset)))
+
+    def process_device(self, d_in: int, d_out: int, frames: int, stride: Optional[int] = None, block: int = 512):
+        self._chk(self.L.zab_process(self.h, d_in, d_out, int(frames), int(stride or frames), int(block), ZAB_BUF_DEVICE))
+
+    def sync(self):
+        self._chk(self.L.zab_sync(self.h))
+
+    def last_timing(self):
+        ms, n = C.c_double(), C.c_int32()
+        self._chk(self.L.zab_last_timing(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def used_fast_path(self) -> bool:
+        return bool(self.L.zab_used_fast_path(self.h))
+
+    # -- state
+    def read_vars(self, first=0, count=None) -> np.ndarray:
+        cnt = self.n - first if count is None else count
+        out = np.zeros((cnt, self.nvars))
+        self._chk(self.L.zab_read_vars(self.h, int(first), int(cnt), _dp(out)))
+        return out
+
+    def read_mem(self, start: int, n: int, first=0, count=None) -> np.ndarray:
+        cnt = self.n - first if count is None else count
+        out = np.zeros((cnt, n))
+        self._chk(self.L.zab_read_mem(self.h, int(first), int(cnt), int(start), int(n), _dp(out)))
+        return out
+
+    def write_mem(self, start: int, values: np.ndarray, first=0):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        if v.ndim == 1:
+            v = v[None, :]
+        self._chk(self.L.zab_write_mem(self.h, int(first), v.shape[0], int(start), v.shape[1], _dp(v)))
+
+    def mem_high(self, first=0, count=None) -> np.ndarray:
+        cnt = self.n - first if count is None else count
+        out = np.zeros(cnt, dtype=np.int64)
+        self._chk(self.L.zab_read_mem_high(self.h, int(first), int(cnt), out.ctypes.data_as(C.POINTER(C.c_int64))))
+        return out
+
+
+class JsfxBatchProcessor:
+    """N instances of one JSFX leaf behind the reference processor's method names.
+
+    reference                                   here
+    ------------------------------------------  ---------------------------------------------------------------
+    JSFXJuceProcessor()  (parses slider decls)  JsfxBatchProcessor(leaf, n_instances)
+    host parameter values (APVTS)               set_parameter(slider_index0, host_value[, instance])
+    prepareToPlay(sampleRate, blockSize)        prepareToPlay(sampleRate, samplesPerBlockExpected)
+    processBlock(AudioBuffer&, MidiBuffer&)     processBlock(buffer[N, nch, n])  (in-place semantics: returns output)
+    """
+
+    def __init__(self, leaf: str, n_instances: int, device: int = 0, path: int = ZAB_PATH_AUTO, mem_cap: int = 0):
+        from zajit.sliders import SliderDecl
+        self.leaf, self.n, self.device, self.path, self.mem_cap = leaf, int(n_instances), device, path, mem_cap
+        self.meta = leaf_meta(leaf)
+        self.decls = {}
+        for k, sd in self.meta["sliders"].items():
+            self.decls[int(k)] = SliderDecl(index0=int(k), default=sd["default"], vmin=sd["min"], vmax=sd["max"],
+                                            step=sd["step"], var_name=sd["var"], is_choice=sd["is_choice"],
+                                            is_string=sd["is_string"], label=sd["label"])
+        self.host_params = np.zeros((self.n, 64))
+        for i, dcl in self.decls.items():
+            if dcl.is_string:
+                continue
+            host = dcl.default
+            if dcl.is_choice:
+                host = (dcl.default - dcl.vmin) / dcl.step if dcl.step > 0 else 0.0
+            self.host_params[:, i] = host
+        self.engine: Optional[Engine] = None
+
+    def set_parameter(self, slider_index0: int, host_value, instance=None):
+        if instance is None:
+            self.host_params[:, slider_index0] = host_value
+        else:
+            self.host_params[instance, slider_index0] = host_value
+
+    def _slider_rows(self) -> np.ndarray:
+        rows = np.zeros((self.n, 64))
+        for i, dcl in self.decls.items():
+            if dcl.is_string:
+                continue
+            col = self.host_params[:, i]
+            uniq = {}
+            for j, hv in enumerate(col):
+                if hv not in uniq:
+                    uniq[hv] = dcl.to_slider_value(float(hv))
+                rows[j, i] = uniq[hv]
+        return rows
+
+    def prepareToPlay(self, sampleRate: float, samplesPerBlockExpected: int):
+        if self.engine is not None:
+            self.engine.close()
+        self.engine = Engine(self.leaf, self.n, srate=sampleRate, max_block=max(1, samplesPerBlockExpected),
+                             device=self.device, path=self.path, mem_cap=self.mem_cap)
+        self.block = max(1, samplesPerBlockExpected)
+        self.engine.set_sliders(self._slider_rows())      # sliders are valid inside @init (:3297-3302)
+        self.engine.prepare()
+
+    def processBlock(self, buffer: np.ndarray) -> np.ndarray:
+        if self.engine is None:
+            raise ZabError(-7, "processBlock before prepareToPlay")
+        self.engine.set_sliders(self._slider_rows())      # pushParamsToStateSliders(); changed rows re-run @slider
+        n = buffer.shape[2]
+        return self.engine.process_host(buffer, block=max(1, min(self.block, n)) if n else self.block)
+
+    def releaseResources(self):
+        if self.engine is not None:
+            self.engine.close()
+            self.engine = None
