@@ -129,6 +129,8 @@ int zab_device_noise(zab_engine* e, void* dst, int64_t frames, int64_t frame_str
 /* Timing of the most recent zab_process: HIP events recorded on the engine's stream around the kernel launches.
  * kernel_ms = sum over launches; launches = number of kernel launches. */
 int zab_last_timing(zab_engine* e, double* kernel_ms, int32_t* launches);
+/* Device durations (ms) of the most recent zab_process launches, oldest first, at most 64 kept; returns the count. */
+int zab_timing_history(zab_engine* e, double* kernel_ms, int32_t max_entries);
 void* zab_stream(zab_engine* e);   /* hipStream_t of the engine */
 int zab_used_fast_path(zab_engine* e); /* 1 if the most recent zab_process ran the leaf's hand-written kernel */
 

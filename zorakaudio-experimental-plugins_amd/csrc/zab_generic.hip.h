@@ -187,6 +187,23 @@ extern "C" __global__ void __launch_bounds__(64) ZA_KERNEL(process)(ZabBatch b, 
   if (active) za_state_store(s, b, inst);
 }
 
+// processBlock prologue for the hand-written kernels: instances whose sliders changed run @slider first (:3545-3547).
+extern "C" __global__ void __launch_bounds__(64) ZA_KERNEL(slider)(ZabBatch b) {
+  const int inst = blockIdx.x * 64 + threadIdx.x;
+  if (inst >= b.n_inst) return;
+  if (!(b.flags[inst] & ZAB_FLAG_SLIDER_DIRTY)) return;
+  ZaS s;
+  za_state_load(s, b, inst);
+  za_alias_sync(s);
+  za_section_slider(s);
+  za_state_store(s, b, inst);
+  b.flags[inst] &= ~ZAB_FLAG_SLIDER_DIRTY;
+}
+
+static hipError_t za_launch_slider(const ZabBatch* b, hipStream_t st) {
+  hipLaunchKernelGGL(ZA_KERNEL(slider), dim3((b->n_inst + 63) / 64), dim3(64), 0, st, *b);
+  return hipGetLastError();
+}
 static hipError_t za_launch_prepare(const ZabBatch* b, hipStream_t st) {
   hipLaunchKernelGGL(ZA_KERNEL(prepare), dim3((b->n_inst + 63) / 64), dim3(64), 0, st, *b);
   return hipGetLastError();

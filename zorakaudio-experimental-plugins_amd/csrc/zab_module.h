@@ -6,7 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define ZAB_MODULE_ABI 3
+#define ZAB_MODULE_ABI 4
 
 enum { ZAB_FLAG_SLIDER_DIRTY = 1u, ZAB_FLAG_PREPARED = 2u };
 
@@ -57,6 +57,7 @@ struct ZabModule {
   // generic (translator-generated) kernels
   hipError_t (*launch_prepare)(const ZabBatch*, hipStream_t);
   hipError_t (*launch_process)(const ZabBatch*, const ZabAudio*, hipStream_t);
+  hipError_t (*launch_slider)(const ZabBatch*, hipStream_t);   // @slider on instances flagged ZAB_FLAG_SLIDER_DIRTY
   // optional hand-written leaf kernel; applies() decides from host-visible config, launch may still defer
   // per instance to the generic kernel through `fallback_mask` semantics documented by the leaf
   int32_t (*fast_applies)(const ZabBatch*, const ZabAudio*);

@@ -14,6 +14,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -70,8 +71,11 @@ struct zab_engine {
   zab_config cfg{};
   ZabBatch b{};
   hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  static const int kTimingSlots = 64;
+  hipEvent_t ev0[kTimingSlots] = {}, ev1[kTimingSlots] = {};
+  uint64_t n_process = 0;
   bool prepared = false;
+  bool sliders_dirty = false;
   bool timing_valid = false;
   int launches = 0;
   bool used_fast = false;
@@ -92,6 +96,16 @@ struct zab_engine {
     return ZAB_OK;
   }
 };
+
+static hipError_t create_events(zab_engine* e) {
+  for (int i = 0; i < zab_engine::kTimingSlots; ++i) {
+    hipError_t he = hipEventCreate(&e->ev0[i]);
+    if (he != hipSuccess) return he;
+    he = hipEventCreate(&e->ev1[i]);
+    if (he != hipSuccess) return he;
+  }
+  return hipSuccess;
+}
 
 extern "C" {
 
@@ -130,7 +144,7 @@ int zab_create(const char* module, const zab_config* cfg, zab_engine** out) {
   int rc = ZAB_OK;
   hipError_t he;
   if ((he = hipSetDevice(cfg->device)) != hipSuccess || (he = hipStreamCreate(&e->stream)) != hipSuccess ||
-      (he = hipEventCreate(&e->ev0)) != hipSuccess || (he = hipEventCreate(&e->ev1)) != hipSuccess) {
+      (he = create_events(e)) != hipSuccess) {
     rc = fail(ZAB_E_HIP, "HIP stream/event setup failed: %s", hipGetErrorString(he));
     zab_destroy(e);
     return rc;
@@ -143,6 +157,12 @@ int zab_create(const char* module, const zab_config* cfg, zab_engine** out) {
   b.mem_cap = cfg->mem_cap > 0 ? cfg->mem_cap : m->default_mem_cap;
   b.srate = cfg->srate;
   b.first_id = cfg->first_instance_id ? cfg->first_instance_id : 1;
+  {
+    // epochs are unique across engines of the process (device pointers get recycled, so modules that cache plans
+    // per batch must not be able to confuse a new engine with a destroyed one)
+    static std::atomic<uint64_t> next_engine{1};
+    b.epoch = next_engine.fetch_add(1) << 32;
+  }
   const int64_t P = b.n_pad;
   if (b.instance_major) {
     b.var_se = 1; b.var_si = m->nvars;
@@ -180,8 +200,10 @@ int zab_destroy(zab_engine* e) {
   for (void* p : e->owned) hipFree(p);
   if (e->stage_in) hipFree(e->stage_in);
   if (e->stage_out) hipFree(e->stage_out);
-  if (e->ev0) hipEventDestroy(e->ev0);
-  if (e->ev1) hipEventDestroy(e->ev1);
+  for (int i = 0; i < zab_engine::kTimingSlots; ++i) {
+    if (e->ev0[i]) hipEventDestroy(e->ev0[i]);
+    if (e->ev1[i]) hipEventDestroy(e->ev1[i]);
+  }
   if (e->stream) hipStreamDestroy(e->stream);
   // the module stays loaded: its code object is registered with the HIP runtime for the process lifetime
   delete e;
@@ -246,6 +268,7 @@ int zab_set_sliders(zab_engine* e, int32_t first, int32_t count, const double* v
     HIP_TRY(hipMemcpy2D(b.sliders + lo, sizeof(double) * b.n_pad, cur.data(), sizeof(double) * n, sizeof(double) * n, 64, hipMemcpyHostToDevice));
   }
   HIP_TRY(hipMemcpy(b.flags + lo, flags.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
+  for (uint32_t f : flags) if (f & ZAB_FLAG_SLIDER_DIRTY) e->sliders_dirty = true;
   e->b.epoch++;
   return ZAB_OK;
 }
@@ -300,6 +323,7 @@ int zab_prepare(zab_engine* e) {
   if (he != hipSuccess) return fail(ZAB_E_HIP, "prepare launch failed: %s", hipGetErrorString(he));
   HIP_TRY(hipStreamSynchronize(e->stream));
   e->prepared = true;
+  e->sliders_dirty = false;
   e->b.epoch++;
   return check_device_errors(e, "zab_prepare");
 }
@@ -331,14 +355,22 @@ int zab_process(zab_engine* e, const void* in, void* out, int64_t frames, int64_
   } else {
     return fail(ZAB_E_ARG, "zab_process: placement %d", placement);
   }
+  if (e->sliders_dirty && e->cfg.path != ZAB_PATH_GENERIC && e->mod->launch_fast) {
+    // hand-written kernels expect @slider to have run already; the generic process kernel does it itself
+    hipError_t hs = e->mod->launch_slider(&e->b, e->stream);
+    if (hs != hipSuccess) return fail(ZAB_E_HIP, "slider launch failed: %s", hipGetErrorString(hs));
+  }
+  e->sliders_dirty = false;
   bool fast = false;
   if (e->cfg.path != ZAB_PATH_GENERIC && e->mod->launch_fast && e->mod->fast_applies) fast = e->mod->fast_applies(&e->b, &a) != 0;
   if (e->cfg.path == ZAB_PATH_FAST && !fast)
     return fail(ZAB_E_ARG, "ZAB_PATH_FAST requested but %s's hand-written kernel does not apply to this configuration", e->mod->name);
-  HIP_TRY(hipEventRecord(e->ev0, e->stream));
+  const int slot = (int)(e->n_process % zab_engine::kTimingSlots);
+  HIP_TRY(hipEventRecord(e->ev0[slot], e->stream));
   hipError_t he = fast ? e->mod->launch_fast(&e->b, &a, e->stream) : e->mod->launch_process(&e->b, &a, e->stream);
   if (he != hipSuccess) return fail(ZAB_E_HIP, "process launch failed: %s", hipGetErrorString(he));
-  HIP_TRY(hipEventRecord(e->ev1, e->stream));
+  HIP_TRY(hipEventRecord(e->ev1[slot], e->stream));
+  e->n_process++;
   e->timing_valid = true; e->launches = 1; e->used_fast = fast;
   if (placement == ZAB_BUF_HOST) {
     if (bytes) HIP_TRY(hipMemcpyAsync(out, e->stage_out, bytes, hipMemcpyDeviceToHost, e->stream));
@@ -434,12 +466,28 @@ int zab_device_noise(zab_engine* e, void* dst, int64_t frames, int64_t frame_str
 
 int zab_last_timing(zab_engine* e, double* kernel_ms, int32_t* launches) {
   if (!e || !e->timing_valid) return fail(ZAB_E_STATE, "zab_last_timing: no zab_process yet");
-  HIP_TRY(hipEventSynchronize(e->ev1));
+  const int slot = (int)((e->n_process - 1) % zab_engine::kTimingSlots);
+  HIP_TRY(hipEventSynchronize(e->ev1[slot]));
   float ms = 0.f;
-  HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+  HIP_TRY(hipEventElapsedTime(&ms, e->ev0[slot], e->ev1[slot]));
   if (kernel_ms) *kernel_ms = ms;
   if (launches) *launches = e->launches;
   return ZAB_OK;
+}
+
+int zab_timing_history(zab_engine* e, double* kernel_ms, int32_t max_entries) {
+  if (!e || !kernel_ms || max_entries < 0) return fail(ZAB_E_ARG, "zab_timing_history: bad argument");
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  uint64_t have = e->n_process < (uint64_t)zab_engine::kTimingSlots ? e->n_process : (uint64_t)zab_engine::kTimingSlots;
+  if (have > (uint64_t)max_entries) have = (uint64_t)max_entries;
+  for (uint64_t k = 0; k < have; ++k) {            // oldest of the returned window first
+    const uint64_t idx = e->n_process - have + k;
+    const int slot = (int)(idx % zab_engine::kTimingSlots);
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e->ev0[slot], e->ev1[slot]));
+    kernel_ms[k] = ms;
+  }
+  return (int)have;
 }
 void* zab_stream(zab_engine* e) { return e ? (void*)e->stream : nullptr; }
 

@@ -44,7 +44,8 @@ ABI_SYMBOLS = [
     "zab_last_error", "zab_abi_version", "zab_create", "zab_destroy", "zab_get_info", "zab_var_count", "zab_var_name",
     "zab_var_index", "zab_set_sliders", "zab_get_sliders", "zab_prepare", "zab_process", "zab_sync", "zab_read_vars",
     "zab_read_mem", "zab_write_mem", "zab_read_mem_high", "zab_device_alloc", "zab_device_free", "zab_device_upload",
-    "zab_device_download", "zab_device_noise", "zab_last_timing", "zab_stream", "zab_used_fast_path",
+    "zab_device_download", "zab_device_noise", "zab_last_timing", "zab_timing_history", "zab_stream",
+    "zab_used_fast_path",
 ]
 
 _lib = None
@@ -86,6 +87,7 @@ def load_runtime():
     L.zab_device_download.argtypes = [vp, vp, vp, i64]
     L.zab_device_noise.argtypes = [vp, vp, i64, i64, C.c_uint64]
     L.zab_last_timing.argtypes = [vp, C.POINTER(d), C.POINTER(i32)]
+    L.zab_timing_history.argtypes = [vp, C.POINTER(d), i32]
     L.zab_stream.restype = vp; L.zab_stream.argtypes = [vp]
     L.zab_used_fast_path.argtypes = [vp]
     _lib = L
@@ -228,6 +230,13 @@ class Engine:
         ms, n = C.c_double(), C.c_int32()
         self._chk(self.L.zab_last_timing(self.h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def timing_history(self, max_entries: int = 64) -> np.ndarray:
+        out = np.zeros(max_entries)
+        n = self.L.zab_timing_history(self.h, _dp(out), int(max_entries))
+        if n < 0:
+            self._chk(n)
+        return out[:n]
 
     def used_fast_path(self) -> bool:
         return bool(self.L.zab_used_fast_path(self.h))
