@@ -7,14 +7,17 @@
 //     by LINEAR constant-coefficient one-poles (dirZ*, eZ*, lZ*, and the seven UI meters). So time is data-parallel:
 //     ONE WAVEFRONT PER INSTANCE, each lane owns KF=4 consecutive frames of a 256-frame chunk.
 //   * The mono delay history M[n] = 0.5*(L[n]+R[n]) (the only thing the taps read: :467-468) lives in an LDS ring of
-//     W doubles, de-interleaved by 4 (slot(n) = (n&3)*W/4 + (n>>2)) so that both the 4-frames-per-lane stores and
-//     the `frame - delay` gathers of a wave hit consecutive LDS addresses: conflict-free for every tap delay.
-//   * Tap parameters (delays, gains, early/late flag) are wave-uniform: staged once in LDS, read as broadcasts.
-//     Tap sums are accumulated in source order with separate multiply and add (no FMA contraction), so sumE*/sumL*
-//     are bit-identical to the serial reference.
-//   * The six filter recurrences y[n] = (1-a) x[n] + a y[n-1] run as: 4 serial steps inside the lane, a 64-lane
-//     Kogge-Stone scan of the lane aggregates with coefficient a^4 (wavefront shuffles), then a 4-step fix-up.
-//     Lane 0 of a full chunk reproduces the serial rounding exactly; other lanes differ by O(1e-16) relative.
+//     W doubles, de-interleaved by 4: frame n sits in plane (n&3) at position (n>>2) mod W/4. A lane's 4 stores go to
+//     4 planes at one position; a tap gather `frame - delay` of the whole wave reads 64 consecutive doubles of one
+//     plane (conflict-free for every delay), and because frame = 4*lane + uniform, plane and position offset are
+//     wave-uniform: the address math is scalar except one add and one mask per gather.
+//   * Tap parameters (delays, gains) are wave-uniform: staged once in LDS as two lists -- early taps, late taps, each
+//     in source order -- and read as broadcasts. Each list feeds its own pair of accumulators with separate multiply
+//     and add (no FMA contraction) in source order, so sumE*/sumL* are bit-identical to the serial reference.
+//   * The six filter recurrences y[n] = (1-a) x[n] + a y[n-1]: 4 serial steps inside the lane, a weighted 64-lane scan
+//     of the lane aggregates with coefficient a^4 done with DPP (row_shr 1/2/4/8, row_bcast15, row_bcast31 -- no LDS
+//     crossbar traffic, no lane masks), then a 4-step fix-up. Lane 0 of a full chunk reproduces the serial rounding
+//     exactly; other lanes differ by O(1e-16) relative.
 //   * The seven meter one-poles are only observable as state after the launch, so they are carried as per-lane
 //     weighted partial sums and reduced across the wave once, at the end.
 //   * HBM traffic per frame: 8 B in + 8 B out (float4 per lane per channel, 1 KiB per wave instruction); the f64
@@ -34,303 +37,378 @@
 #define DDT_MAXTAPS 64
 #define DDT_RING 16384                 /* BUF_LEN of the script */
 
-struct DdtTap { int32_t dL, dR; int32_t early, pad; double gL, gR; };   // 32 B, read as wave-uniform broadcasts
+struct DdtTap { int32_t dL, dR; double gL, gR; };            // 24 B, read as wave-uniform broadcasts
+struct DdtPole {
+  double a, c1;        // pole and (1 - pole)
+  double ap[4];        // a^1..a^4
+  double sp[4];        // (a^4)^(2^j), j = 0..3 : in-row scan step coefficients
+};
 
+// ---- wave-level helpers ------------------------------------------------------------------------------------------
 __device__ __forceinline__ double ddt_uniform(double v) {
   int2 t = __builtin_bit_cast(int2, v);
   t.x = __builtin_amdgcn_readfirstlane(t.x);
   t.y = __builtin_amdgcn_readfirstlane(t.y);
   return __builtin_bit_cast(double, t);
 }
-__device__ __forceinline__ double ddt_shfl_up(double v, int d) { return __shfl_up(v, d, 64); }
-__device__ __forceinline__ double ddt_lane(double v, int l) { return __shfl(v, l, 64); }
-__device__ __forceinline__ int ddt_slot(int64_t n, int wmask, int wq) {
-  const int i = (int)(n & wmask);
-  return (i & 3) * wq + (i >> 2);
+__device__ __forceinline__ double ddt_readlane(double v, int l) {
+  int2 t = __builtin_bit_cast(int2, v);
+  t.x = __builtin_amdgcn_readlane(t.x, l);
+  t.y = __builtin_amdgcn_readlane(t.y, l);
+  return __builtin_bit_cast(double, t);
 }
+// DPP move of a double; lanes without a source (or masked out by ROWS) receive 0.
+template <int CTRL, int ROWS>
+__device__ __forceinline__ double ddt_dpp(double v) {
+  int2 t = __builtin_bit_cast(int2, v);
+  t.x = __builtin_amdgcn_update_dpp(0, t.x, CTRL, ROWS, 0xF, true);
+  t.y = __builtin_amdgcn_update_dpp(0, t.y, CTRL, ROWS, 0xF, true);
+  return __builtin_bit_cast(double, t);
+}
+#define DDT_ROW_SHR(n) (0x110 | (n))
+#define DDT_WAVE_SHR1 0x138
+#define DDT_ROW_BCAST15 0x142
+#define DDT_ROW_BCAST31 0x143
+
 __device__ __forceinline__ double ddt_clamp(double x, double a, double b) { return x < a ? a : (x > b ? b : x); }
+__device__ __forceinline__ double ddt_ipow(double base, int e) {   // base^e, e >= 0, square-and-multiply
+  double r = 1.0;
+  while (e) { if (e & 1) r *= base; base *= base; e >>= 1; }
+  return r;
+}
 
-// y[n] = c1*x[n] + a*y[n-1] over the chunk, 4 frames per lane; `carry` (wave-uniform) is y before the chunk's first
-// valid frame and is returned updated to y at the chunk's last frame. first = (lane, k) of the first valid frame.
-struct DdtPole {
-  double a, c1;        // pole and (1 - pole)
-  double ap[4];        // a^1..a^4
-  double sp[6];        // (a^4)^(2^j), j = 0..5 : Kogge-Stone step coefficients
-  __device__ void init(double pole) {
-    a = pole; c1 = 1.0 - pole;
-    ap[0] = a; ap[1] = a * a; ap[2] = ap[1] * a; ap[3] = ap[1] * ap[1];
-    sp[0] = ap[3];
-#pragma unroll
-    for (int j = 1; j < 6; ++j) sp[j] = sp[j - 1] * sp[j - 1];
-  }
-};
+// Inclusive weighted scan across the wave: g[l] <- sum_{i<=l} q^(l-i) g[i], q = a^4.
+// cb1 = q^((l&15)+1), cb2 = q^(l-31) are per-lane constants of the pole.
+__device__ __forceinline__ double ddt_scan(double g, const DdtPole& p, double cb1, double cb2) {
+  g = __builtin_fma(p.sp[0], ddt_dpp<DDT_ROW_SHR(1), 0xF>(g), g);
+  g = __builtin_fma(p.sp[1], ddt_dpp<DDT_ROW_SHR(2), 0xF>(g), g);
+  g = __builtin_fma(p.sp[2], ddt_dpp<DDT_ROW_SHR(4), 0xF>(g), g);
+  g = __builtin_fma(p.sp[3], ddt_dpp<DDT_ROW_SHR(8), 0xF>(g), g);
+  g = __builtin_fma(cb1, ddt_dpp<DDT_ROW_BCAST15, 0xA>(g), g);
+  g = __builtin_fma(cb2, ddt_dpp<DDT_ROW_BCAST31, 0xC>(g), g);
+  return g;
+}
 
-template <int NP>
-__device__ __forceinline__ void ddt_poles_run(const DdtPole* P, const int (&pole_of)[2 * NP], double (&x)[2 * NP][DDT_KF],
-                                              double (&carry)[2 * NP], int lane, int first_lane, int first_k) {
-  // x[s][k] in: inputs; out: y. Signals s = 2*p + {0: left, 1: right} share pole p.
-  double g[2 * NP];
+// One recurrence over the chunk. x[k]: inputs in, outputs out. carry: wave-uniform y before the chunk's first valid
+// frame in, y at the chunk's last frame out. PARTIAL chunks (only the first of a launch) mask the leading slots.
+template <bool PARTIAL>
+__device__ __forceinline__ void ddt_pole_run(const DdtPole& p, double cb1, double cb2, double (&x)[DDT_KF], double& carry,
+                                             int lane, int first_lane, int first_k) {
+  double z = 0.0;
 #pragma unroll
-  for (int s = 0; s < 2 * NP; ++s) {
-    const DdtPole& p = P[pole_of[s]];
-    double z = 0.0;
-#pragma unroll
-    for (int k = 0; k < DDT_KF; ++k) {
-      const bool inject = (lane == first_lane) && (k == first_k);
-      const double prev = inject ? carry[s] : z;            // identical op order to the script: (1-a)*x + a*prev
-      z = p.c1 * x[s][k] + p.a * prev;
+  for (int k = 0; k < DDT_KF; ++k) {
+    double prev = z;
+    if (PARTIAL) {
+      if (lane == first_lane && k == first_k) prev = carry;
+    } else {
+      if (k == 0 && lane == 0) prev = carry;
+    }
+    z = p.c1 * x[k] + p.a * prev;                        // same op order as the script: (1-a)*x + a*prev
+    if (PARTIAL) {
       const bool valid = (lane > first_lane) || (lane == first_lane && k >= first_k);
       z = valid ? z : 0.0;
-      x[s][k] = z;
     }
-    g[s] = z;
+    x[k] = z;
   }
+  const double g = ddt_scan(z, p, cb1, cb2);
+  const double cin = ddt_dpp<DDT_WAVE_SHR1, 0xF>(g);      // y at the end of the previous lane (0 for lane 0)
 #pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    const int d = 1 << j;
-    double t[2 * NP];
+  for (int k = 0; k < DDT_KF; ++k) x[k] = __builtin_fma(p.ap[k], cin, x[k]);
+  carry = ddt_readlane(g, 63);
+}
+
+struct DdtCtx {
+  // wave-uniform launch constants
+  const float *in0, *in1;
+  float *out0, *out1;
+  double* Mem;
+  double* ring;
+  const DdtTap* taps;
+  const DdtPole* P;
+  int64_t frames, wofs0, rL, rR;
+  int bufmask, wq, wqmask, nE, nT, mon;
+  double col, one_m_col, directGain, wetp, dryp, out_gain;
+  bool vec_ok;
+};
+
+struct DdtLast {   // @sample temporaries of the launch's final frame (lane 63, k = 3)
+  double mono, srcL, srcR, dInL, dInR, sEL, sER, sLL, sLR, yL, yR, oL, oR, sdir, sear, slat, stot, dL, dR, c, spl0, spl1;
+};
+
+// gather M[frame - d] for the lane's 4 frames. cbase = (wofs0 + f0) - d is wave-uniform; frame = 4*lane + k + ...
+__device__ __forceinline__ void ddt_gather(const double* ring, int lane, int cbase, int wq, int wqmask, double (&x)[DDT_KF]) {
 #pragma unroll
-    for (int s = 0; s < 2 * NP; ++s) t[s] = ddt_shfl_up(g[s], d);
-#pragma unroll
-    for (int s = 0; s < 2 * NP; ++s)
-      if (lane >= d) g[s] = __builtin_fma(P[pole_of[s]].sp[j], t[s], g[s]);
-  }
-#pragma unroll
-  for (int s = 0; s < 2 * NP; ++s) {
-    double cin = ddt_shfl_up(g[s], 1);
-    if (lane == 0) cin = 0.0;
-    const DdtPole& p = P[pole_of[s]];
-#pragma unroll
-    for (int k = 0; k < DDT_KF; ++k) x[s][k] = __builtin_fma(p.ap[k], cin, x[s][k]);
-    carry[s] = ddt_lane(g[s], 63);
+  for (int k = 0; k < DDT_KF; ++k) {
+    const int c = cbase + k;                             // scalar
+    const int plane = c & 3, q = c >> 2;                 // scalar (arithmetic shift: c may be negative)
+    x[k] = ring[plane * wq + ((lane + q) & wqmask)];
   }
 }
 
-extern "C" __global__ void __launch_bounds__(64, 4) zab_ddt_fast(ZabBatch b, ZabAudio a, int W) {
+template <bool PARTIAL>
+__device__ __forceinline__ void ddt_chunk(const DdtCtx& C, int lane, int64_t f0, double (&carry)[6], const double (&cb1)[3],
+                                          const double (&cb2)[3], double (&accM)[6], double& accC, double dM, double dC,
+                                          double wM, double wC, const double (&cwM)[DDT_KF], const double (&cwC)[DDT_KF],
+                                          bool want_last, DdtLast& last) {
+  const int64_t t0 = f0 + DDT_KF * lane;
+  int first_lane = 0, first_k = 0;
+  if (PARTIAL) {
+    const int firstv = (int)(-f0);
+    first_lane = firstv / DDT_KF;
+    first_k = firstv % DDT_KF;
+  }
+  double x0[DDT_KF], x1[DDT_KF], M[DDT_KF];
+  if (C.vec_ok && (!PARTIAL || t0 >= 0)) {
+    const float4 v0 = *reinterpret_cast<const float4*>(C.in0 + t0);
+    const float4 v1 = *reinterpret_cast<const float4*>(C.in1 + t0);
+    x0[0] = v0.x; x0[1] = v0.y; x0[2] = v0.z; x0[3] = v0.w;
+    x1[0] = v1.x; x1[1] = v1.y; x1[2] = v1.z; x1[3] = v1.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < DDT_KF; ++k) {
+      const bool ok = t0 + k >= 0;
+      x0[k] = ok ? (double)C.in0[t0 + k] : 0.0;
+      x1[k] = ok ? (double)C.in1[t0 + k] : 0.0;
+    }
+  }
+  // ring stores: frame n = wofs0 + t0 + k -> plane (n & 3), position ((n >> 2) & wqmask); n = 4*lane + uniform
+  const int nb = (int)((C.wofs0 + f0) & 0x3fffffff);      // uniform; W divides 2^30 so low bits suffice
+  __syncthreads();                                        // previous chunk's gathers have been consumed
+#pragma unroll
+  for (int k = 0; k < DDT_KF; ++k) {
+    M[k] = 0.5 * (x0[k] + x1[k]);                         // mono (:445) == ring value 0.5*(L+R) (:467)
+    const int c = nb + k;
+    const int plane = c & 3, q = c >> 2;
+    if (!PARTIAL || t0 + k >= 0) C.ring[plane * C.wq + ((lane + q) & C.wqmask)] = M[k];
+  }
+  if (f0 + DDT_CHUNK > C.frames - DDT_RING) {             // :441-442, only slots that survive the launch
+#pragma unroll
+    for (int k = 0; k < DDT_KF; ++k) {
+      const int64_t t = t0 + k;
+      if (t >= 0 && t >= C.frames - DDT_RING) {
+        const int64_t ri = (C.wofs0 + t) & C.bufmask;
+        C.Mem[C.rL + ri] = x0[k];
+        C.Mem[C.rR + ri] = x1[k];
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- tap loops (:459-484): each accumulator sees its taps in source order, multiply then add -------------------
+  double y[6][DDT_KF];
+#pragma unroll
+  for (int k = 0; k < DDT_KF; ++k) y[2][k] = y[3][k] = y[4][k] = y[5][k] = 0.0;
+  for (int i = 0; i < C.nE; ++i) {
+    const DdtTap tp = C.taps[i];
+    const int dLu = __builtin_amdgcn_readfirstlane(tp.dL), dRu = __builtin_amdgcn_readfirstlane(tp.dR);
+    const double gL = ddt_uniform(tp.gL), gR = ddt_uniform(tp.gR);
+    double xl[DDT_KF], xr[DDT_KF];
+    ddt_gather(C.ring, lane, nb - dLu, C.wq, C.wqmask, xl);
+    ddt_gather(C.ring, lane, nb - dRu, C.wq, C.wqmask, xr);
+#pragma unroll
+    for (int k = 0; k < DDT_KF; ++k) { y[2][k] = y[2][k] + gL * xl[k]; y[3][k] = y[3][k] + gR * xr[k]; }
+  }
+  for (int i = C.nE; i < C.nT; ++i) {
+    const DdtTap tp = C.taps[i];
+    const int dLu = __builtin_amdgcn_readfirstlane(tp.dL), dRu = __builtin_amdgcn_readfirstlane(tp.dR);
+    const double gL = ddt_uniform(tp.gL), gR = ddt_uniform(tp.gR);
+    double xl[DDT_KF], xr[DDT_KF];
+    ddt_gather(C.ring, lane, nb - dLu, C.wq, C.wqmask, xl);
+    ddt_gather(C.ring, lane, nb - dRu, C.wq, C.wqmask, xr);
+#pragma unroll
+    for (int k = 0; k < DDT_KF; ++k) { y[4][k] = y[4][k] + gL * xl[k]; y[5][k] = y[5][k] + gR * xr[k]; }
+  }
+
+  // ---- one-poles (:450-454, 486-490) ---------------------------------------------------------------------------------
+#pragma unroll
+  for (int k = 0; k < DDT_KF; ++k) {
+    const double srcL = x0[k] * C.one_m_col + M[k] * C.col;
+    const double srcR = x1[k] * C.one_m_col + M[k] * C.col;
+    y[0][k] = C.directGain * srcL;
+    y[1][k] = C.directGain * srcR;
+  }
+  if (want_last) {
+    const int q = DDT_KF - 1;
+    last.mono = M[q];
+    last.srcL = x0[q] * C.one_m_col + M[q] * C.col; last.srcR = x1[q] * C.one_m_col + M[q] * C.col;
+    last.dInL = y[0][q]; last.dInR = y[1][q];
+    last.sEL = y[2][q]; last.sER = y[3][q]; last.sLL = y[4][q]; last.sLR = y[5][q];
+  }
+  ddt_pole_run<PARTIAL>(C.P[0], cb1[0], cb2[0], y[0], carry[0], lane, first_lane, first_k);
+  ddt_pole_run<PARTIAL>(C.P[0], cb1[0], cb2[0], y[1], carry[1], lane, first_lane, first_k);
+  ddt_pole_run<PARTIAL>(C.P[1], cb1[1], cb2[1], y[2], carry[2], lane, first_lane, first_k);
+  ddt_pole_run<PARTIAL>(C.P[1], cb1[1], cb2[1], y[3], carry[3], lane, first_lane, first_k);
+  ddt_pole_run<PARTIAL>(C.P[2], cb1[2], cb2[2], y[4], carry[4], lane, first_lane, first_k);
+  ddt_pole_run<PARTIAL>(C.P[2], cb1[2], cb2[2], y[5], carry[5], lane, first_lane, first_k);
+
+  // ---- output mix (:492-505) and meters (:510-536) -----------------------------------------------------------------
+  float o0[DDT_KF], o1[DDT_KF];
+  double zM[6] = {0, 0, 0, 0, 0, 0}, zC = 0.0;
+#pragma unroll
+  for (int k = 0; k < DDT_KF; ++k) {
+    const double dirZL = y[0][k], dirZR = y[1][k], eZL = y[2][k], eZR = y[3][k], lZL = y[4][k], lZR = y[5][k];
+    const double yL = dirZL + eZL + lZL, yR = dirZR + eZR + lZR;
+    const double dL = eZL + lZL, dR = eZR + lZR;
+    double oL, oR;
+    if (C.mon == 3) { oL = x0[k]; oR = x1[k]; }
+    else if (C.mon == 1) { oL = dirZL; oR = dirZR; }
+    else if (C.mon == 2) { oL = dL; oR = dR; }
+    else { oL = yL; oR = yR; }
+    double s0 = (C.dryp * x0[k] + C.wetp * oL) * C.out_gain;
+    double s1 = (C.dryp * x1[k] + C.wetp * oR) * C.out_gain;
+    s0 = s0 > 8.0 ? 8.0 : (s0 < -8.0 ? -8.0 : s0);
+    s1 = s1 > 8.0 ? 8.0 : (s1 < -8.0 ? -8.0 : s1);
+    o0[k] = (float)s0; o1[k] = (float)s1;
+    const double s_dir = 0.5 * (fabs(dirZL) + fabs(dirZR));
+    const double s_ear = 0.5 * (fabs(eZL) + fabs(eZR));
+    const double s_lat = 0.5 * (fabs(lZL) + fabs(lZR));
+    const double s_tot = s_dir + s_ear + s_lat;
+    const double adL = fabs(dL), adR = fabs(dR);
+    const double cc = (dL * dR) / za_max(0.0000001, adL * adR + 0.0000001);
+    // lane-local one-pole with zero start == sum_k val_k * (1-a) a^(3-k): linear, so accumulate with weights
+    zM[0] = __builtin_fma(cwM[k], s_dir, zM[0]);
+    zM[1] = __builtin_fma(cwM[k], s_ear, zM[1]);
+    zM[2] = __builtin_fma(cwM[k], s_lat, zM[2]);
+    zM[3] = __builtin_fma(cwM[k], s_tot, zM[3]);
+    zM[4] = __builtin_fma(cwM[k], adL, zM[4]);
+    zM[5] = __builtin_fma(cwM[k], adR, zM[5]);
+    zC = __builtin_fma(cwC[k], ddt_clamp(cc, -1.0, 1.0), zC);
+    if (want_last && k == DDT_KF - 1) {
+      last.yL = yL; last.yR = yR; last.oL = oL; last.oR = oR; last.sdir = s_dir; last.sear = s_ear; last.slat = s_lat;
+      last.stot = s_tot; last.dL = dL; last.dR = dR; last.c = cc; last.spl0 = s0; last.spl1 = s1;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 6; ++q) accM[q] = __builtin_fma(accM[q], dM, wM * zM[q]);
+  accC = __builtin_fma(accC, dC, wC * zC);
+
+  if (C.vec_ok && (!PARTIAL || t0 >= 0)) {
+    *reinterpret_cast<float4*>(C.out0 + t0) = make_float4(o0[0], o0[1], o0[2], o0[3]);
+    *reinterpret_cast<float4*>(C.out1 + t0) = make_float4(o1[0], o1[1], o1[2], o1[3]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < DDT_KF; ++k)
+      if (t0 + k >= 0) { C.out0[t0 + k] = o0[k]; C.out1[t0 + k] = o1[k]; }
+  }
+}
+
+extern "C" __global__ void __launch_bounds__(64, 2) zab_ddt_fast(ZabBatch b, ZabAudio a, int W) {
   extern __shared__ double ddt_lds[];
-  double* ring = ddt_lds;                                  // [W]
-  DdtTap* taps = (DdtTap*)(ddt_lds + W);                   // [DDT_MAXTAPS]
-  DdtPole* P = (DdtPole*)(taps + DDT_MAXTAPS);             // [3] pole tables, read as broadcasts
+  double* ring = ddt_lds;                                  // [4 planes][W/4]
+  DdtTap* taps = (DdtTap*)(ddt_lds + W);                   // [DDT_MAXTAPS] early taps first, then late taps
+  DdtPole* P = (DdtPole*)(taps + DDT_MAXTAPS);             // [3]
+  int* scratch = (int*)(P + 3);                            // [4]
   const int lane = threadIdx.x;
   const int inst = blockIdx.x;
-  const int wmask = W - 1, wq = W >> 2;
 
   double* V = b.vars + (int64_t)inst * b.var_si;           // instance-major (checked by za_fast_applies)
   double* Mem = b.mem + (int64_t)inst * b.mem_si;
   const double* SL = b.sliders + (int64_t)inst * b.sl_si;
-  const float* in0 = a.in + (int64_t)inst * 2 * a.frame_stride;
-  const float* in1 = in0 + a.frame_stride;
-  float* out0 = a.out + (int64_t)inst * 2 * a.frame_stride;
-  float* out1 = out0 + a.frame_stride;
   const int64_t frames = a.frames;
   if (frames <= 0) return;
 
-  // ---- per-launch scalars (wave-uniform) -------------------------------------------------------------------
+  DdtCtx C;
+  C.in0 = a.in + (int64_t)inst * 2 * a.frame_stride;
+  C.in1 = C.in0 + a.frame_stride;
+  C.out0 = a.out + (int64_t)inst * 2 * a.frame_stride;
+  C.out1 = C.out0 + a.frame_stride;
+  C.Mem = Mem; C.ring = ring; C.taps = taps; C.P = P; C.frames = frames;
+  C.wq = W >> 2; C.wqmask = (W >> 2) - 1;
+
+  // ---- per-launch scalars (wave-uniform) ---------------------------------------------------------------------------
   const double mbase = V[ZA_VAR_m];
-  const int64_t rL = za_addr(mbase, V[ZA_VAR_bL]), rR = za_addr(mbase, V[ZA_VAR_bR]);
+  C.rL = za_addr(mbase, V[ZA_VAR_bL]); C.rR = za_addr(mbase, V[ZA_VAR_bR]);
   const int64_t tDL = za_addr(mbase, V[ZA_VAR_bDL]), tDR = za_addr(mbase, V[ZA_VAR_bDR]);
   const int64_t tGL = za_addr(mbase, V[ZA_VAR_bGL]), tGR = za_addr(mbase, V[ZA_VAR_bGR]), tD0 = za_addr(mbase, V[ZA_VAR_bD0]);
-  const int bufmask = za_i32(V[ZA_VAR_BUF_MASK]);
-  const int tapN = (int)za_loopcount(V[ZA_VAR_tapN]) > DDT_MAXTAPS ? DDT_MAXTAPS : (int)za_loopcount(V[ZA_VAR_tapN]);
+  C.bufmask = za_i32(V[ZA_VAR_BUF_MASK]);
+  int tapN = (int)za_loopcount(V[ZA_VAR_tapN]);
+  if (tapN > DDT_MAXTAPS) tapN = DDT_MAXTAPS;
   const double splitSamp = V[ZA_VAR_splitSamp];
-  const double directGain = V[ZA_VAR_directGain];
-  const double wetp = V[ZA_VAR_wetp], dryp = V[ZA_VAR_dryp], out_gain = V[ZA_VAR_out_gain];
+  C.directGain = V[ZA_VAR_directGain];
+  C.wetp = V[ZA_VAR_wetp]; C.dryp = V[ZA_VAR_dryp]; C.out_gain = V[ZA_VAR_out_gain];
   const double slider1 = SL[0], slider8 = SL[7];
-  const int64_t wofs0 = za_f2i64(V[ZA_VAR_wofs]);
+  C.wofs0 = za_f2i64(V[ZA_VAR_wofs]);
 
   // distN = smooth01(slider1/100); col = distN^0.8   (:444-446; clamp/smooth01 :62-64)
   double tt = ddt_clamp(slider1 / 100.0, 0.0, 1.0);
   const double distN = (tt * tt) * (3.0 - 2.0 * tt);
-  const double col = pow(distN, 0.8);
-  const double one_m_col = 1.0 - col;
-  const int mon = za_i32(slider8);
+  C.col = pow(distN, 0.8);
+  C.one_m_col = 1.0 - C.col;
+  C.mon = za_i32(slider8);
 
   if (lane < 3) {
     DdtPole pl;
-    pl.init(lane == 0 ? V[ZA_VAR_a_dir] : (lane == 1 ? V[ZA_VAR_a_early] : V[ZA_VAR_a_late]));
+    const double pole = lane == 0 ? V[ZA_VAR_a_dir] : (lane == 1 ? V[ZA_VAR_a_early] : V[ZA_VAR_a_late]);
+    pl.a = pole; pl.c1 = 1.0 - pole;
+    pl.ap[0] = pole; pl.ap[1] = pole * pole; pl.ap[2] = pl.ap[1] * pole; pl.ap[3] = pl.ap[1] * pl.ap[1];
+    pl.sp[0] = pl.ap[3];
+    for (int j = 1; j < 4; ++j) pl.sp[j] = pl.sp[j - 1] * pl.sp[j - 1];
     P[lane] = pl;
   }
-  const int pole_of[6] = {0, 0, 1, 1, 2, 2};
   double carry[6] = {V[ZA_VAR_dirZL], V[ZA_VAR_dirZR], V[ZA_VAR_eZL], V[ZA_VAR_eZR], V[ZA_VAR_lZL], V[ZA_VAR_lZR]};
+  // per-lane scan constants q^((l&15)+1), q^(l-31), q = a^4
+  double cb1[3], cb2[3];
+  {
+    const double poles[3] = {V[ZA_VAR_a_dir], V[ZA_VAR_a_early], V[ZA_VAR_a_late]};
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      const double q = (poles[p] * poles[p]) * (poles[p] * poles[p]);
+      cb1[p] = ddt_ipow(q, (lane & 15) + 1);
+      cb2[p] = ddt_ipow(q, lane >= 32 ? lane - 31 : 0);
+    }
+  }
 
   // meters: m = (1-aM)*val + aM*m  (:128-131,518-536); six with aM, the correlation one with 0.9990
   const double aM = 0.9985, aC = 0.9990;
   const double cM = 1.0 - aM, cC = 1.0 - aC;
-  // per-lane weight aM^(4*(63-lane)) and chunk decay aM^256, by square-and-multiply (once per launch)
-  double wM = 1.0, wC = 1.0;
-  {
-    double bm = (aM * aM) * (aM * aM), bc = (aC * aC) * (aC * aC);
-    int e = 63 - lane;
-    while (e) { if (e & 1) { wM *= bm; wC *= bc; } bm *= bm; bc *= bc; e >>= 1; }
-  }
-  double dM = aM, dC = aC;
+  const double wM = ddt_ipow((aM * aM) * (aM * aM), 63 - lane), wC = ddt_ipow((aC * aC) * (aC * aC), 63 - lane);
+  const double dM = ddt_ipow(aM, DDT_CHUNK), dC = ddt_ipow(aC, DDT_CHUNK);
+  double cwM[DDT_KF], cwC[DDT_KF];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { dM *= dM; dC *= dC; }      // a^256
+  for (int k = 0; k < DDT_KF; ++k) { cwM[k] = cM * ddt_ipow(aM, DDT_KF - 1 - k); cwC[k] = cC * ddt_ipow(aC, DDT_KF - 1 - k); }
   double accM[6] = {0, 0, 0, 0, 0, 0}, accC = 0.0;
 
-  // ---- stage tap table and delay history ---------------------------------------------------------------------
+  // ---- stage tap lists: early taps (baseD < splitSamp) then late taps, each in source order ---------------------
+  bool early = false;
+  DdtTap mine = {0, 0, 0.0, 0.0};
   if (lane < tapN) {
-    DdtTap t;
-    t.dL = za_i32(Mem[tDL + lane]);
-    t.dR = za_i32(Mem[tDR + lane]);
-    t.gL = Mem[tGL + lane];
-    t.gR = Mem[tGR + lane];
-    const double baseD = (double)za_i32(Mem[tD0 + lane]);
-    t.early = baseD < splitSamp ? 1 : 0;
-    t.pad = 0;
-    taps[lane] = t;
+    mine.dL = za_i32(Mem[tDL + lane]);
+    mine.dR = za_i32(Mem[tDR + lane]);
+    mine.gL = Mem[tGL + lane];
+    mine.gR = Mem[tGR + lane];
+    early = (double)za_i32(Mem[tD0 + lane]) < splitSamp;
   }
-  const int H = W - DDT_CHUNK;                             // history frames kept (>= max tap delay)
+  const unsigned long long emask = __ballot(lane < tapN && early);
+  const unsigned long long lmask = __ballot(lane < tapN && !early);
+  const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  C.nE = __popcll(emask);
+  C.nT = tapN;
+  if (lane < tapN) taps[early ? __popcll(emask & below) : C.nE + __popcll(lmask & below)] = mine;
+  if (lane == tapN - 1) { scratch[0] = mine.dL; scratch[1] = mine.dR; }   // source-order last tap (state temporaries)
+
+  const int H = W - DDT_CHUNK;                             // history frames kept (> max tap delay)
   for (int j = lane; j < H; j += 64) {
-    const int64_t n = wofs0 - H + j;
-    const int64_t ri = n & bufmask;
-    ring[ddt_slot(n, wmask, wq)] = 0.5 * (Mem[rL + ri] + Mem[rR + ri]);
+    const int64_t n = C.wofs0 - H + j;
+    const int64_t ri = n & C.bufmask;
+    const int c = (int)(n & 0x3fffffff);
+    ring[(c & 3) * C.wq + ((c >> 2) & C.wqmask)] = 0.5 * (Mem[C.rL + ri] + Mem[C.rR + ri]);
   }
+
+  C.vec_ok = ((frames & 3) == 0) && ((a.frame_stride & 3) == 0) && ((((uintptr_t)C.in0) | ((uintptr_t)C.out0)) & 15) == 0;
 
   const int64_t nchunks = (frames + DDT_CHUNK - 1) / DDT_CHUNK;
-  const bool vec_ok = ((frames & 3) == 0) && ((a.frame_stride & 3) == 0) &&
-                      ((((uintptr_t)in0) | ((uintptr_t)out0)) & 15) == 0;
-  for (int64_t c = 0; c < nchunks; ++c) {
-    const int64_t f0 = frames - DDT_CHUNK * (nchunks - c);           // chunk is end-aligned; f0 < 0 only for c == 0
-    const int64_t t0 = f0 + DDT_KF * lane;                           // first frame of this lane
-    const int64_t firstv = f0 < 0 ? -f0 : 0;                         // first valid slot in the chunk
-    const int first_lane = (int)(firstv / DDT_KF), first_k = (int)(firstv % DDT_KF);
-
-    double x0[DDT_KF], x1[DDT_KF], M[DDT_KF];
-    if (vec_ok && t0 >= 0) {
-      const float4 v0 = *reinterpret_cast<const float4*>(in0 + t0);
-      const float4 v1 = *reinterpret_cast<const float4*>(in1 + t0);
-      x0[0] = v0.x; x0[1] = v0.y; x0[2] = v0.z; x0[3] = v0.w;
-      x1[0] = v1.x; x1[1] = v1.y; x1[2] = v1.z; x1[3] = v1.w;
-    } else {
-#pragma unroll
-      for (int k = 0; k < DDT_KF; ++k) {
-        const bool ok = t0 + k >= 0;
-        x0[k] = ok ? (double)in0[t0 + k] : 0.0;
-        x1[k] = ok ? (double)in1[t0 + k] : 0.0;
-      }
-    }
-    __syncthreads();                                                  // previous chunk's gathers are done
-#pragma unroll
-    for (int k = 0; k < DDT_KF; ++k) {
-      M[k] = 0.5 * (x0[k] + x1[k]);                                   // mono (:445) == ring value 0.5*(L+R) (:467)
-      const int64_t t = t0 + k;
-      if (t >= 0) {
-        const int64_t n = wofs0 + t;
-        ring[ddt_slot(n, wmask, wq)] = M[k];
-        if (t >= frames - DDT_RING) {                                 // :441-442, only slots that survive the launch
-          const int64_t ri = n & bufmask;
-          Mem[rL + ri] = x0[k];
-          Mem[rR + ri] = x1[k];
-        }
-      }
-    }
-    __syncthreads();
-
-    // ---- tap loop (:459-484): sums in source order, mul then add ------------------------------------------
-    double sEL[DDT_KF], sER[DDT_KF], sLL[DDT_KF], sLR[DDT_KF];
-#pragma unroll
-    for (int k = 0; k < DDT_KF; ++k) sEL[k] = sER[k] = sLL[k] = sLR[k] = 0.0;
-    const int64_t nbase = wofs0 + t0;
-    double xL_last = 0.0, xR_last = 0.0;
-    for (int i = 0; i < tapN; ++i) {
-      const DdtTap tp = taps[i];
-      const int dLu = __builtin_amdgcn_readfirstlane(tp.dL), dRu = __builtin_amdgcn_readfirstlane(tp.dR);
-      const double gL = ddt_uniform(tp.gL), gR = ddt_uniform(tp.gR);
-      double xl[DDT_KF], xr[DDT_KF];
-#pragma unroll
-      for (int k = 0; k < DDT_KF; ++k) {
-        xl[k] = ring[ddt_slot(nbase + k - dLu, wmask, wq)];
-        xr[k] = ring[ddt_slot(nbase + k - dRu, wmask, wq)];
-      }
-      if (__builtin_amdgcn_readfirstlane(tp.early)) {
-#pragma unroll
-        for (int k = 0; k < DDT_KF; ++k) { sEL[k] = sEL[k] + gL * xl[k]; sER[k] = sER[k] + gR * xr[k]; }
-      } else {
-#pragma unroll
-        for (int k = 0; k < DDT_KF; ++k) { sLL[k] = sLL[k] + gL * xl[k]; sLR[k] = sLR[k] + gR * xr[k]; }
-      }
-      xL_last = xl[DDT_KF - 1]; xR_last = xr[DDT_KF - 1];
-    }
-
-    // ---- one-poles (:450-454, 486-490) ------------------------------------------------------------------------
-    double y[6][DDT_KF];
-#pragma unroll
-    for (int k = 0; k < DDT_KF; ++k) {
-      const double srcL = x0[k] * one_m_col + M[k] * col;
-      const double srcR = x1[k] * one_m_col + M[k] * col;
-      y[0][k] = directGain * srcL; y[1][k] = directGain * srcR;
-      y[2][k] = sEL[k]; y[3][k] = sER[k]; y[4][k] = sLL[k]; y[5][k] = sLR[k];
-    }
-    double dInL_last = y[0][DDT_KF - 1], dInR_last = y[1][DDT_KF - 1];
-    ddt_poles_run<3>(P, pole_of, y, carry, lane, first_lane, first_k);
-
-    // ---- output mix (:492-505) and meters (:510-536) ---------------------------------------------------------
-    float o0[DDT_KF], o1[DDT_KF];
-    double zM[6] = {0, 0, 0, 0, 0, 0}, zC = 0.0;
-    double l_oL = 0, l_oR = 0, l_yL = 0, l_yR = 0, l_dL = 0, l_dR = 0, l_c = 0, l_sdir = 0, l_sear = 0, l_slat = 0, l_stot = 0;
-    double l_spl0 = 0, l_spl1 = 0;
-#pragma unroll
-    for (int k = 0; k < DDT_KF; ++k) {
-      const double dirZL = y[0][k], dirZR = y[1][k], eZL = y[2][k], eZR = y[3][k], lZL = y[4][k], lZR = y[5][k];
-      const double yL = dirZL + eZL + lZL, yR = dirZR + eZR + lZR;
-      double oL, oR;
-      if (mon == 3) { oL = x0[k]; oR = x1[k]; }
-      else if (mon == 1) { oL = dirZL; oR = dirZR; }
-      else if (mon == 2) { oL = eZL + lZL; oR = eZR + lZR; }
-      else { oL = yL; oR = yR; }
-      double s0 = (dryp * x0[k] + wetp * oL) * out_gain;
-      double s1 = (dryp * x1[k] + wetp * oR) * out_gain;
-      s0 = s0 > 8.0 ? 8.0 : (s0 < -8.0 ? -8.0 : s0);
-      s1 = s1 > 8.0 ? 8.0 : (s1 < -8.0 ? -8.0 : s1);
-      o0[k] = (float)s0; o1[k] = (float)s1;
-      const double s_dir = 0.5 * (fabs(dirZL) + fabs(dirZR));
-      const double s_ear = 0.5 * (fabs(eZL) + fabs(eZR));
-      const double s_lat = 0.5 * (fabs(lZL) + fabs(lZR));
-      const double s_tot = s_dir + s_ear + s_lat;
-      const double dL = eZL + lZL, dR = eZR + lZR;
-      const double cc = (dL * dR) / za_max(0.0000001, fabs(dL) * fabs(dR) + 0.0000001);
-      zM[0] = cM * s_dir + aM * zM[0];
-      zM[1] = cM * s_ear + aM * zM[1];
-      zM[2] = cM * s_lat + aM * zM[2];
-      zM[3] = cM * s_tot + aM * zM[3];
-      zM[4] = cM * fabs(dL) + aM * zM[4];
-      zM[5] = cM * fabs(dR) + aM * zM[5];
-      zC = cC * ddt_clamp(cc, -1.0, 1.0) + aC * zC;
-      if (k == DDT_KF - 1) {
-        l_oL = oL; l_oR = oR; l_yL = yL; l_yR = yR; l_dL = dL; l_dR = dR; l_c = cc;
-        l_sdir = s_dir; l_sear = s_ear; l_slat = s_lat; l_stot = s_tot; l_spl0 = s0; l_spl1 = s1;
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < 6; ++q) accM[q] = accM[q] * dM + wM * zM[q];
-    accC = accC * dC + wC * zC;
-
-    if (vec_ok && t0 >= 0) {
-      *reinterpret_cast<float4*>(out0 + t0) = make_float4(o0[0], o0[1], o0[2], o0[3]);
-      *reinterpret_cast<float4*>(out1 + t0) = make_float4(o1[0], o1[1], o1[2], o1[3]);
-    } else {
-#pragma unroll
-      for (int k = 0; k < DDT_KF; ++k)
-        if (t0 + k >= 0) { out0[t0 + k] = o0[k]; out1[t0 + k] = o1[k]; }
-    }
-
-    if (c == nchunks - 1 && lane == 63) {   // lane 63 holds the launch's last frame: its temporaries are state
-      const int q = DDT_KF - 1;
-      V[ZA_VAR_distN] = distN; V[ZA_VAR_col] = col; V[ZA_VAR_mono] = M[q];
-      V[ZA_VAR_srcL] = x0[q] * one_m_col + M[q] * col; V[ZA_VAR_srcR] = x1[q] * one_m_col + M[q] * col;
-      V[ZA_VAR_dInL] = dInL_last; V[ZA_VAR_dInR] = dInR_last;
-      V[ZA_VAR_sumEL] = sEL[q]; V[ZA_VAR_sumER] = sER[q]; V[ZA_VAR_sumLL] = sLL[q]; V[ZA_VAR_sumLR] = sLR[q];
-      V[ZA_VAR_xL] = xL_last; V[ZA_VAR_xR] = xR_last;
-      V[ZA_VAR_yL] = l_yL; V[ZA_VAR_yR] = l_yR; V[ZA_VAR_oL] = l_oL; V[ZA_VAR_oR] = l_oR;
-      V[ZA_VAR_s_dir] = l_sdir; V[ZA_VAR_s_ear] = l_sear; V[ZA_VAR_s_lat] = l_slat; V[ZA_VAR_s_tot] = l_stot;
-      V[ZA_VAR_dL] = l_dL; V[ZA_VAR_dR] = l_dR; V[ZA_VAR_c] = l_c;
-      double* SPL = b.spl + (int64_t)inst * b.sl_si;
-      SPL[0] = l_spl0; SPL[1] = l_spl1;
-    }
+  DdtLast last = {};
+  int64_t c = 0;
+  const int64_t f_first = frames - DDT_CHUNK * nchunks;    // <= 0; chunks are end-aligned
+  if (f_first < 0) {
+    ddt_chunk<true>(C, lane, f_first, carry, cb1, cb2, accM, accC, dM, dC, wM, wC, cwM, cwC, nchunks == 1, last);
+    c = 1;
   }
+  for (; c < nchunks; ++c)
+    ddt_chunk<false>(C, lane, f_first + DDT_CHUNK * c, carry, cb1, cb2, accM, accC, dM, dC, wM, wC, cwM, cwC,
+                     c == nchunks - 1, last);
 
-  // ---- meters: m_final = a^frames * m_start + sum over lanes of the weighted partials --------------------------
+  // ---- meters: m_final = a^frames * m_start + sum over lanes of the weighted partials ---------------------------------
   double red[7];
 #pragma unroll
   for (int q = 0; q < 6; ++q) red[q] = accM[q];
@@ -340,7 +418,8 @@ extern "C" __global__ void __launch_bounds__(64, 4) zab_ddt_fast(ZabBatch b, Zab
 #pragma unroll
     for (int q = 0; q < 7; ++q) red[q] += __shfl_xor(red[q], d, 64);
 
-  // ---- state write-back (one lane) ---------------------------------------------------------------------------------
+  __syncthreads();
+  // ---- state write-back (lane 63 owns the launch's last frame) --------------------------------------------------------
   if (lane == 63) {
     const double pM = pow(aM, (double)frames), pC = pow(aC, (double)frames);
     V[ZA_VAR_m_dirE] = pM * V[ZA_VAR_m_dirE] + red[0];
@@ -354,19 +433,30 @@ extern "C" __global__ void __launch_bounds__(64, 4) zab_ddt_fast(ZabBatch b, Zab
     V[ZA_VAR_eZL] = carry[2]; V[ZA_VAR_eZR] = carry[3];
     V[ZA_VAR_lZL] = carry[4]; V[ZA_VAR_lZR] = carry[5];
     V[ZA_VAR_wofs] = V[ZA_VAR_wofs] + (double)frames;
-    // remaining temporaries of the last frame, exactly as the script leaves them
-    const int64_t nlast = wofs0 + frames - 1;
+    // @sample temporaries of the last frame, exactly as the script leaves them
+    const int64_t nlast = C.wofs0 + frames - 1;
+    V[ZA_VAR_distN] = distN; V[ZA_VAR_col] = C.col; V[ZA_VAR_mono] = last.mono;
+    V[ZA_VAR_srcL] = last.srcL; V[ZA_VAR_srcR] = last.srcR; V[ZA_VAR_dInL] = last.dInL; V[ZA_VAR_dInR] = last.dInR;
+    V[ZA_VAR_sumEL] = last.sEL; V[ZA_VAR_sumER] = last.sER; V[ZA_VAR_sumLL] = last.sLL; V[ZA_VAR_sumLR] = last.sLR;
     V[ZA_VAR_i] = (double)tapN;
     if (tapN > 0) {
-      const DdtTap tp = taps[tapN - 1];
-      V[ZA_VAR_idxL] = (double)(int32_t)((nlast - tp.dL) & bufmask);
-      V[ZA_VAR_idxR] = (double)(int32_t)((nlast - tp.dR) & bufmask);
-      V[ZA_VAR_gL] = tp.gL; V[ZA_VAR_gR] = tp.gR;
+      const int dLl = scratch[0], dRl = scratch[1];
+      const int cl = (int)((nlast - dLl) & 0x3fffffff), cr = (int)((nlast - dRl) & 0x3fffffff);
+      V[ZA_VAR_idxL] = (double)(int32_t)((nlast - dLl) & C.bufmask);
+      V[ZA_VAR_idxR] = (double)(int32_t)((nlast - dRl) & C.bufmask);
+      V[ZA_VAR_xL] = ring[(cl & 3) * C.wq + ((cl >> 2) & C.wqmask)];   // the LDS ring still holds frame - delay
+      V[ZA_VAR_xR] = ring[(cr & 3) * C.wq + ((cr >> 2) & C.wqmask)];
+      V[ZA_VAR_gL] = Mem[tGL + tapN - 1]; V[ZA_VAR_gR] = Mem[tGR + tapN - 1];
       V[ZA_VAR_baseD] = (double)za_i32(Mem[tD0 + tapN - 1]);
     }
-    V[ZA_VAR_mon] = (double)mon;
+    V[ZA_VAR_yL] = last.yL; V[ZA_VAR_yR] = last.yR; V[ZA_VAR_mon] = (double)C.mon;
+    V[ZA_VAR_oL] = last.oL; V[ZA_VAR_oR] = last.oR;
+    V[ZA_VAR_s_dir] = last.sdir; V[ZA_VAR_s_ear] = last.sear; V[ZA_VAR_s_lat] = last.slat; V[ZA_VAR_s_tot] = last.stot;
     V[ZA_VAR_aM] = aM;
-    const int64_t hi = (rL > rR ? rL : rR) + DDT_RING;
+    V[ZA_VAR_dL] = last.dL; V[ZA_VAR_dR] = last.dR; V[ZA_VAR_c] = last.c;
+    double* SPL = b.spl + (int64_t)inst * b.sl_si;
+    SPL[0] = last.spl0; SPL[1] = last.spl1;
+    const int64_t hi = (C.rL > C.rR ? C.rL : C.rR) + DDT_RING;
     if (b.mem_high[inst] < hi) b.mem_high[inst] = hi;
   }
 }
@@ -413,7 +503,7 @@ static int ddt_ring_len(const ZabBatch* b) {
   if (!res[1]) {
     W = 1024;
     while (W < res[0] + DDT_CHUNK + 1) W <<= 1;
-    if (W > 16384) W = 0;                                  // 128 KiB + taps still fits the 160 KiB LDS; beyond: generic
+    if (W > 16384) W = 0;                                  // 128 KiB + tables still fit the 160 KiB LDS; beyond: generic
   }
   ddt_plans[b->vars] = DdtPlan{b->epoch, W};
   return W;
@@ -428,9 +518,11 @@ static int32_t za_fast_applies(const ZabBatch* b, const ZabAudio* a) {
 static hipError_t za_launch_fast(const ZabBatch* b, const ZabAudio* a, hipStream_t st) {
   const int W = ddt_ring_len(b);
   if (W <= 0) return hipErrorInvalidValue;
-  const size_t lds = (size_t)W * sizeof(double) + DDT_MAXTAPS * sizeof(DdtTap) + 3 * sizeof(DdtPole);
+  const size_t lds = (size_t)W * sizeof(double) + DDT_MAXTAPS * sizeof(DdtTap) + 3 * sizeof(DdtPole) + 16;
   static std::once_flag once;
-  std::call_once(once, [] { hipFuncSetAttribute((const void*)zab_ddt_fast, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); });
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute((const void*)zab_ddt_fast, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+  });
   hipLaunchKernelGGL(zab_ddt_fast, dim3(b->n_inst), dim3(64), lds, st, *b, *a, W);
   return hipGetLastError();
 }
