@@ -37,7 +37,7 @@
 #define DDT_MAXTAPS 64
 #define DDT_RING 16384                 /* BUF_LEN of the script */
 
-struct DdtTap { int32_t dL, dR; double gL, gR; };            // 24 B, read as wave-uniform broadcasts
+struct DdtTap { int32_t dL8, dR8; double gL, gR; };          // 8*delay (bytes) and gains; read as wave-uniform broadcasts
 struct DdtPole {
   double a, c1;        // pole and (1 - pole)
   double ap[4];        // a^1..a^4
@@ -126,7 +126,8 @@ struct DdtCtx {
   const DdtTap* taps;
   const DdtPole* P;
   int64_t frames, wofs0, rL, rR;
-  int bufmask, wq, wqmask, nE, nT, mon;
+  double* T;           // [4][DDT_CHUNK] transpose area: tap sums go strided -> blocked through here
+  int bufmask, W, m8, nE, nT, mon;
   double col, one_m_col, directGain, wetp, dryp, out_gain;
   bool vec_ok;
 };
@@ -135,16 +136,10 @@ struct DdtLast {   // @sample temporaries of the launch's final frame (lane 63, 
   double mono, srcL, srcR, dInL, dInR, sEL, sER, sLL, sLR, yL, yR, oL, oR, sdir, sear, slat, stot, dL, dR, c, spl0, spl1;
 };
 
-// gather M[frame - d] for the lane's 4 frames. cbase = (wofs0 + f0) - d is wave-uniform; frame = 4*lane + k + ...
-__device__ __forceinline__ void ddt_gather(const double* ring, int lane, int cbase, int wq, int wqmask, double (&x)[DDT_KF]) {
-#pragma unroll
-  for (int k = 0; k < DDT_KF; ++k) {
-    const int c = cbase + k;                             // scalar
-    const int plane = c & 3, q = c >> 2;                 // scalar (arithmetic shift: c may be negative)
-    x[k] = ring[plane * wq + ((lane + q) & wqmask)];
-  }
-}
-
+// Tap phase mapping: lane l handles frames {l, 64+l, 128+l, 192+l} of the chunk ("strided"), so a gather of
+// frame - delay reads 64 consecutive ring slots per k and the four k differ by a constant 512 bytes: one masked
+// address per (tap, channel), the rest are ds_read_b64 immediates. The ring keeps a 256-slot mirror of its head
+// behind its tail so those +512k offsets never need a wrap.
 template <bool PARTIAL>
 __device__ __forceinline__ void ddt_chunk(const DdtCtx& C, int lane, int64_t f0, double (&carry)[6], const double (&cb1)[3],
                                           const double (&cb2)[3], double (&accM)[6], double& accC, double dM, double dC,
@@ -171,15 +166,17 @@ __device__ __forceinline__ void ddt_chunk(const DdtCtx& C, int lane, int64_t f0,
       x1[k] = ok ? (double)C.in1[t0 + k] : 0.0;
     }
   }
-  // ring stores: frame n = wofs0 + t0 + k -> plane (n & 3), position ((n >> 2) & wqmask); n = 4*lane + uniform
+  // ring stores (plain circular layout + mirror of the first 256 slots behind slot W)
   const int nb = (int)((C.wofs0 + f0) & 0x3fffffff);      // uniform; W divides 2^30 so low bits suffice
-  __syncthreads();                                        // previous chunk's gathers have been consumed
+  __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int k = 0; k < DDT_KF; ++k) {
     M[k] = 0.5 * (x0[k] + x1[k]);                         // mono (:445) == ring value 0.5*(L+R) (:467)
-    const int c = nb + k;
-    const int plane = c & 3, q = c >> 2;
-    if (!PARTIAL || t0 + k >= 0) C.ring[plane * C.wq + ((lane + q) & C.wqmask)] = M[k];
+    if (!PARTIAL || t0 + k >= 0) {
+      const int slot = (nb + DDT_KF * lane + k) & (C.W - 1);
+      C.ring[slot] = M[k];
+      if (slot < DDT_CHUNK) C.ring[C.W + slot] = M[k];
+    }
   }
   if (f0 + DDT_CHUNK > C.frames - DDT_RING) {             // :441-442, only slots that survive the launch
 #pragma unroll
@@ -192,31 +189,44 @@ __device__ __forceinline__ void ddt_chunk(const DdtCtx& C, int lane, int64_t f0,
       }
     }
   }
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();
 
-  // ---- tap loops (:459-484): each accumulator sees its taps in source order, multiply then add -------------------
+  // ---- tap loops (:459-484), strided lanes: each accumulator sees its taps in source order, multiply then add ----
   double y[6][DDT_KF];
+  {
+    const char* ringb = reinterpret_cast<const char*>(C.ring);
+    const int lane8nb = (8 * lane + 8 * nb) & C.m8;       // byte address of frame (nb + lane) in the ring
+    double sE[2][DDT_KF], sL[2][DDT_KF];
 #pragma unroll
-  for (int k = 0; k < DDT_KF; ++k) y[2][k] = y[3][k] = y[4][k] = y[5][k] = 0.0;
-  for (int i = 0; i < C.nE; ++i) {
-    const DdtTap tp = C.taps[i];
-    const int dLu = __builtin_amdgcn_readfirstlane(tp.dL), dRu = __builtin_amdgcn_readfirstlane(tp.dR);
-    const double gL = ddt_uniform(tp.gL), gR = ddt_uniform(tp.gR);
-    double xl[DDT_KF], xr[DDT_KF];
-    ddt_gather(C.ring, lane, nb - dLu, C.wq, C.wqmask, xl);
-    ddt_gather(C.ring, lane, nb - dRu, C.wq, C.wqmask, xr);
+    for (int k = 0; k < DDT_KF; ++k) sE[0][k] = sE[1][k] = sL[0][k] = sL[1][k] = 0.0;
+#define DDT_TAP(acc)                                                                                   \
+    {                                                                                                  \
+      const DdtTap tp = C.taps[i];                                                                     \
+      const char* pl = ringb + ((lane8nb - tp.dL8) & C.m8);                                            \
+      const char* pr = ringb + ((lane8nb - tp.dR8) & C.m8);                                            \
+      _Pragma("unroll") for (int k = 0; k < DDT_KF; ++k) {                                             \
+        acc[0][k] = acc[0][k] + tp.gL * *reinterpret_cast<const double*>(pl + 512 * k);                \
+        acc[1][k] = acc[1][k] + tp.gR * *reinterpret_cast<const double*>(pr + 512 * k);                \
+      }                                                                                                \
+    }
+    for (int i = 0; i < C.nE; ++i) DDT_TAP(sE)
+    for (int i = C.nE; i < C.nT; ++i) DDT_TAP(sL)
+#undef DDT_TAP
+    // strided -> blocked: lane l wrote frames 64k+l, reads back frames 4l..4l+3
 #pragma unroll
-    for (int k = 0; k < DDT_KF; ++k) { y[2][k] = y[2][k] + gL * xl[k]; y[3][k] = y[3][k] + gR * xr[k]; }
-  }
-  for (int i = C.nE; i < C.nT; ++i) {
-    const DdtTap tp = C.taps[i];
-    const int dLu = __builtin_amdgcn_readfirstlane(tp.dL), dRu = __builtin_amdgcn_readfirstlane(tp.dR);
-    const double gL = ddt_uniform(tp.gL), gR = ddt_uniform(tp.gR);
-    double xl[DDT_KF], xr[DDT_KF];
-    ddt_gather(C.ring, lane, nb - dLu, C.wq, C.wqmask, xl);
-    ddt_gather(C.ring, lane, nb - dRu, C.wq, C.wqmask, xr);
+    for (int k = 0; k < DDT_KF; ++k) {
+      C.T[0 * DDT_CHUNK + 64 * k + lane] = sE[0][k];
+      C.T[1 * DDT_CHUNK + 64 * k + lane] = sE[1][k];
+      C.T[2 * DDT_CHUNK + 64 * k + lane] = sL[0][k];
+      C.T[3 * DDT_CHUNK + 64 * k + lane] = sL[1][k];
+    }
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int k = 0; k < DDT_KF; ++k) { y[4][k] = y[4][k] + gL * xl[k]; y[5][k] = y[5][k] + gR * xr[k]; }
+    for (int sgn = 0; sgn < 4; ++sgn) {
+      const double2 lo = *reinterpret_cast<const double2*>(C.T + sgn * DDT_CHUNK + DDT_KF * lane);
+      const double2 hi = *reinterpret_cast<const double2*>(C.T + sgn * DDT_CHUNK + DDT_KF * lane + 2);
+      y[2 + sgn][0] = lo.x; y[2 + sgn][1] = lo.y; y[2 + sgn][2] = hi.x; y[2 + sgn][3] = hi.y;
+    }
   }
 
   // ---- one-poles (:450-454, 486-490) ---------------------------------------------------------------------------------
@@ -294,8 +304,9 @@ __device__ __forceinline__ void ddt_chunk(const DdtCtx& C, int lane, int64_t f0,
 
 extern "C" __global__ void __launch_bounds__(64, 2) zab_ddt_fast(ZabBatch b, ZabAudio a, int W) {
   extern __shared__ double ddt_lds[];
-  double* ring = ddt_lds;                                  // [4 planes][W/4]
-  DdtTap* taps = (DdtTap*)(ddt_lds + W);                   // [DDT_MAXTAPS] early taps first, then late taps
+  double* ring = ddt_lds;                                  // [W + 256]: circular history + mirror of its first 256 slots
+  double* T = ddt_lds + W + DDT_CHUNK;                     // [4][256] transpose area
+  DdtTap* taps = (DdtTap*)(T + 4 * DDT_CHUNK);             // [DDT_MAXTAPS] early taps first, then late taps
   DdtPole* P = (DdtPole*)(taps + DDT_MAXTAPS);             // [3]
   int* scratch = (int*)(P + 3);                            // [4]
   const int lane = threadIdx.x;
@@ -312,8 +323,8 @@ extern "C" __global__ void __launch_bounds__(64, 2) zab_ddt_fast(ZabBatch b, Zab
   C.in1 = C.in0 + a.frame_stride;
   C.out0 = a.out + (int64_t)inst * 2 * a.frame_stride;
   C.out1 = C.out0 + a.frame_stride;
-  C.Mem = Mem; C.ring = ring; C.taps = taps; C.P = P; C.frames = frames;
-  C.wq = W >> 2; C.wqmask = (W >> 2) - 1;
+  C.Mem = Mem; C.ring = ring; C.T = T; C.taps = taps; C.P = P; C.frames = frames;
+  C.W = W; C.m8 = 8 * (W - 1);
 
   // ---- per-launch scalars (wave-uniform) ---------------------------------------------------------------------------
   const double mbase = V[ZA_VAR_m];
@@ -372,8 +383,8 @@ extern "C" __global__ void __launch_bounds__(64, 2) zab_ddt_fast(ZabBatch b, Zab
   bool early = false;
   DdtTap mine = {0, 0, 0.0, 0.0};
   if (lane < tapN) {
-    mine.dL = za_i32(Mem[tDL + lane]);
-    mine.dR = za_i32(Mem[tDR + lane]);
+    mine.dL8 = 8 * za_i32(Mem[tDL + lane]);
+    mine.dR8 = 8 * za_i32(Mem[tDR + lane]);
     mine.gL = Mem[tGL + lane];
     mine.gR = Mem[tGR + lane];
     early = (double)za_i32(Mem[tD0 + lane]) < splitSamp;
@@ -384,14 +395,16 @@ extern "C" __global__ void __launch_bounds__(64, 2) zab_ddt_fast(ZabBatch b, Zab
   C.nE = __popcll(emask);
   C.nT = tapN;
   if (lane < tapN) taps[early ? __popcll(emask & below) : C.nE + __popcll(lmask & below)] = mine;
-  if (lane == tapN - 1) { scratch[0] = mine.dL; scratch[1] = mine.dR; }   // source-order last tap (state temporaries)
+  if (lane == tapN - 1) { scratch[0] = mine.dL8 >> 3; scratch[1] = mine.dR8 >> 3; }   // source-order last tap (state temporaries)
 
   const int H = W - DDT_CHUNK;                             // history frames kept (> max tap delay)
   for (int j = lane; j < H; j += 64) {
     const int64_t n = C.wofs0 - H + j;
     const int64_t ri = n & C.bufmask;
-    const int c = (int)(n & 0x3fffffff);
-    ring[(c & 3) * C.wq + ((c >> 2) & C.wqmask)] = 0.5 * (Mem[C.rL + ri] + Mem[C.rR + ri]);
+    const int slot = (int)(n & (W - 1));
+    const double mv = 0.5 * (Mem[C.rL + ri] + Mem[C.rR + ri]);
+    ring[slot] = mv;
+    if (slot < DDT_CHUNK) ring[W + slot] = mv;
   }
 
   C.vec_ok = ((frames & 3) == 0) && ((a.frame_stride & 3) == 0) && ((((uintptr_t)C.in0) | ((uintptr_t)C.out0)) & 15) == 0;
@@ -441,11 +454,11 @@ extern "C" __global__ void __launch_bounds__(64, 2) zab_ddt_fast(ZabBatch b, Zab
     V[ZA_VAR_i] = (double)tapN;
     if (tapN > 0) {
       const int dLl = scratch[0], dRl = scratch[1];
-      const int cl = (int)((nlast - dLl) & 0x3fffffff), cr = (int)((nlast - dRl) & 0x3fffffff);
+      const int cl = (int)((nlast - dLl) & (W - 1)), cr = (int)((nlast - dRl) & (W - 1));
       V[ZA_VAR_idxL] = (double)(int32_t)((nlast - dLl) & C.bufmask);
       V[ZA_VAR_idxR] = (double)(int32_t)((nlast - dRl) & C.bufmask);
-      V[ZA_VAR_xL] = ring[(cl & 3) * C.wq + ((cl >> 2) & C.wqmask)];   // the LDS ring still holds frame - delay
-      V[ZA_VAR_xR] = ring[(cr & 3) * C.wq + ((cr >> 2) & C.wqmask)];
+      V[ZA_VAR_xL] = ring[cl];                                        // the LDS ring still holds frame - delay
+      V[ZA_VAR_xR] = ring[cr];
       V[ZA_VAR_gL] = Mem[tGL + tapN - 1]; V[ZA_VAR_gR] = Mem[tGR + tapN - 1];
       V[ZA_VAR_baseD] = (double)za_i32(Mem[tD0 + tapN - 1]);
     }
@@ -518,7 +531,7 @@ static int32_t za_fast_applies(const ZabBatch* b, const ZabAudio* a) {
 static hipError_t za_launch_fast(const ZabBatch* b, const ZabAudio* a, hipStream_t st) {
   const int W = ddt_ring_len(b);
   if (W <= 0) return hipErrorInvalidValue;
-  const size_t lds = (size_t)W * sizeof(double) + DDT_MAXTAPS * sizeof(DdtTap) + 3 * sizeof(DdtPole) + 16;
+  const size_t lds = (size_t)(W + 5 * DDT_CHUNK) * sizeof(double) + DDT_MAXTAPS * sizeof(DdtTap) + 3 * sizeof(DdtPole) + 16;
   static std::once_flag once;
   std::call_once(once, [] {
     (void)hipFuncSetAttribute((const void*)zab_ddt_fast, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
