@@ -103,7 +103,7 @@ __device__ __forceinline__ void ddt_pole_run(const DdtPole& p, double cb1, doubl
     } else {
       if (k == 0 && lane == 0) prev = carry;
     }
-    z = p.c1 * x[k] + p.a * prev;                        // same op order as the script: (1-a)*x + a*prev
+    z = __builtin_fma(p.a, prev, p.c1 * x[k]);           // (1-a)*x + a*prev, one rounding fewer than the script
     if (PARTIAL) {
       const bool valid = (lane > first_lane) || (lane == first_lane && k >= first_k);
       z = valid ? z : 0.0;
@@ -205,8 +205,8 @@ __device__ __forceinline__ void ddt_chunk(const DdtCtx& C, int lane, int64_t f0,
       const char* pl = ringb + ((lane8nb - tp.dL8) & C.m8);                                            \
       const char* pr = ringb + ((lane8nb - tp.dR8) & C.m8);                                            \
       _Pragma("unroll") for (int k = 0; k < DDT_KF; ++k) {                                             \
-        acc[0][k] = acc[0][k] + tp.gL * *reinterpret_cast<const double*>(pl + 512 * k);                \
-        acc[1][k] = acc[1][k] + tp.gR * *reinterpret_cast<const double*>(pr + 512 * k);                \
+        acc[0][k] = __builtin_fma(tp.gL, *reinterpret_cast<const double*>(pl + 512 * k), acc[0][k]);   \
+        acc[1][k] = __builtin_fma(tp.gR, *reinterpret_cast<const double*>(pr + 512 * k), acc[1][k]);   \
       }                                                                                                \
     }
     for (int i = 0; i < C.nE; ++i) DDT_TAP(sE)
@@ -232,8 +232,9 @@ __device__ __forceinline__ void ddt_chunk(const DdtCtx& C, int lane, int64_t f0,
   // ---- one-poles (:450-454, 486-490) ---------------------------------------------------------------------------------
 #pragma unroll
   for (int k = 0; k < DDT_KF; ++k) {
-    const double srcL = x0[k] * C.one_m_col + M[k] * C.col;
-    const double srcR = x1[k] * C.one_m_col + M[k] * C.col;
+    const double mc = M[k] * C.col;
+    const double srcL = __builtin_fma(x0[k], C.one_m_col, mc);
+    const double srcR = __builtin_fma(x1[k], C.one_m_col, mc);
     y[0][k] = C.directGain * srcL;
     y[1][k] = C.directGain * srcR;
   }
@@ -264,8 +265,8 @@ __device__ __forceinline__ void ddt_chunk(const DdtCtx& C, int lane, int64_t f0,
     else if (C.mon == 1) { oL = dirZL; oR = dirZR; }
     else if (C.mon == 2) { oL = dL; oR = dR; }
     else { oL = yL; oR = yR; }
-    double s0 = (C.dryp * x0[k] + C.wetp * oL) * C.out_gain;
-    double s1 = (C.dryp * x1[k] + C.wetp * oR) * C.out_gain;
+    double s0 = __builtin_fma(C.dryp, x0[k], C.wetp * oL) * C.out_gain;
+    double s1 = __builtin_fma(C.dryp, x1[k], C.wetp * oR) * C.out_gain;
     s0 = s0 > 8.0 ? 8.0 : (s0 < -8.0 ? -8.0 : s0);
     s1 = s1 > 8.0 ? 8.0 : (s1 < -8.0 ? -8.0 : s1);
     o0[k] = (float)s0; o1[k] = (float)s1;
@@ -274,7 +275,13 @@ __device__ __forceinline__ void ddt_chunk(const DdtCtx& C, int lane, int64_t f0,
     const double s_lat = 0.5 * (fabs(lZL) + fabs(lZR));
     const double s_tot = s_dir + s_ear + s_lat;
     const double adL = fabs(dL), adR = fabs(dR);
-    const double cc = (dL * dR) / za_max(0.0000001, adL * adR + 0.0000001);
+    // c = dL*dR / max(1e-7, |dL||dR| + 1e-7) (:534): the divisor is within [1e-7, ~1e2], so a hardware reciprocal
+    // refined by one Newton step (~1e-15 relative) replaces the full IEEE division sequence; c only feeds a meter.
+    const double den = __builtin_fmax(0.0000001, __builtin_fma(adL, adR, 0.0000001));
+    double rc = __builtin_amdgcn_rcp(den);
+    rc = __builtin_fma(__builtin_fma(-den, rc, 1.0), rc, rc);
+    rc = __builtin_fma(__builtin_fma(-den, rc, 1.0), rc, rc);
+    const double cc = (dL * dR) * rc;
     // lane-local one-pole with zero start == sum_k val_k * (1-a) a^(3-k): linear, so accumulate with weights
     zM[0] = __builtin_fma(cwM[k], s_dir, zM[0]);
     zM[1] = __builtin_fma(cwM[k], s_ear, zM[1]);
@@ -282,7 +289,7 @@ __device__ __forceinline__ void ddt_chunk(const DdtCtx& C, int lane, int64_t f0,
     zM[3] = __builtin_fma(cwM[k], s_tot, zM[3]);
     zM[4] = __builtin_fma(cwM[k], adL, zM[4]);
     zM[5] = __builtin_fma(cwM[k], adR, zM[5]);
-    zC = __builtin_fma(cwC[k], ddt_clamp(cc, -1.0, 1.0), zC);
+    zC = __builtin_fma(cwC[k], __builtin_fmin(__builtin_fmax(cc, -1.0), 1.0), zC);
     if (want_last && k == DDT_KF - 1) {
       last.yL = yL; last.yR = yR; last.oL = oL; last.oR = oR; last.sdir = s_dir; last.sear = s_ear; last.slat = s_lat;
       last.stot = s_tot; last.dL = dL; last.dR = dR; last.c = cc; last.spl0 = s0; last.spl1 = s1;
