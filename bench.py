@@ -144,10 +144,10 @@ def main() -> int:
     # device duration of each launch of the timed region: HIP event pairs recorded on the engine's own stream
     kernel_ms = eng.timing_history(min(args.steps, 64))
     used_fast = eng.used_fast_path()
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    import sharding
+    job = sharding.reduce_stats(sharding.RunStats(elapsed_s=elapsed, units=float(n_inst) * NCH * frames * args.steps),
+                                dist, device="cuda" if dist is not None else None)
+    elapsed = job.elapsed_s            # MAX over ranks
 
     # state-dependent constants for the algorithmic byte count
     names = eng.var_names()
@@ -162,7 +162,7 @@ def main() -> int:
     alg = algorithmic_bytes_per_launch(n_inst, frames, {"H": W - 256, "tapN": tapN, "nvars": len(names)})
 
     if rank == 0:
-        total_samples = float(world) * n_inst * NCH * frames * args.steps
+        total_samples = job.units      # SUM over ranks
         k_ms = float(np.mean(kernel_ms))
         achieved = alg / (k_ms * 1e-3) / 1e9
         traffic = None

@@ -1,0 +1,121 @@
+"""zajit front end vs pins captured from the reference's own front end (tests/golden/frontend.json), plus parser
+behaviours the reference's compile-smoke tests exercise (scripts/run_dsp-jsfx_*tests.py)."""
+import hashlib
+import json
+from pathlib import Path
+
+import pytest
+
+from conftest import GOLDEN
+
+REF_PLUGINS = Path("/root/reference/plugins")
+PINS = json.loads((GOLDEN / "frontend.json").read_text())
+
+
+def _leaf_sources():
+    return {p.parent.parent.name: p for p in sorted(REF_PLUGINS.glob("*/*/src/*.jsfx"))}
+
+
+@pytest.mark.skipif(not REF_PLUGINS.exists(), reason="leaf sources live in the reference tree (dev container only)")
+@pytest.mark.parametrize("leaf", sorted(PINS))
+def test_front_end_matches_reference(leaf):
+    from zajit import program
+    src = _leaf_sources()[leaf]
+    prog = program.analyse_file(src)
+    pin = PINS[leaf]
+    assert len(prog.vars) == pin["nvars"]
+    sha = hashlib.sha1(json.dumps(sorted(prog.vars.items())).encode()).hexdigest()
+    assert sha == pin["vars_sha1"], "vars[] name->index table differs from the reference's DSPJSFX_VARS"
+    assert len(prog.fns) == pin["nfns"]
+    assert hashlib.sha1(json.dumps(sorted(prog.fns.keys())).encode()).hexdigest() == pin["fns_sha1"]
+    for k in ("inputs", "outputs", "process", "max_read", "max_write"):
+        assert prog.io[k] == pin["io"][k], k
+    assert prog.memtop == pin["memtop"]
+    assert {k: prog.has(k) for k in ("init", "slider", "block", "sample")} == pin["sections"]
+
+
+def test_built_modules_carry_the_pinned_var_tables():
+    """The metadata that travels with the built modules must still agree with the reference pins."""
+    import zabatch
+    for leaf in ("DDT", "DPT", "ADS"):
+        if not zabatch.module_path(leaf).exists():
+            pytest.skip("modules not built")
+        meta = zabatch.leaf_meta(leaf)
+        assert meta["vars_sha1"] == PINS[leaf]["vars_sha1"]
+        assert meta["nvars"] == max(1, PINS[leaf]["nvars"])
+
+
+def _parse(code):
+    from zajit import syntax
+    return syntax.parse_section(code)
+
+
+def test_parser_precedence_and_forms():
+    from zajit import syntax as S
+    (n,) = _parse("a = b + c * d ^ e;")
+    assert isinstance(n, S.Assign) and n.value.op == "+" and n.value.r.op == "*" and n.value.r.r.op == "^"
+    (n,) = _parse("x = c ? 1;")                      # implicit else 0
+    assert isinstance(n.value, S.Cond) and n.value.els.value == 0.0
+    (n,) = _parse("a | b || c & d == e")             # '|' binds like '||', '&' like '=='
+    assert n.op == "||" and n.l.op == "|" and n.r.op == "=="
+    (n,) = _parse("loop(4, a += 1; b += a;)")
+    assert isinstance(n, S.Loop) and isinstance(n.body, S.Seq) and len(n.body.items) == 2
+    (n,) = _parse("wrapped\n  || other\n")           # newline-led infix continuation
+    assert isinstance(n, S.Binary) and n.op == "||"
+    two = _parse("x = a\n+ b;")                      # '+' on a new line starts a new statement (unary)
+    assert len(two) == 2
+    (n,) = _parse("m[3] = u.next.bank;")
+    assert isinstance(n.target, S.Index) and n.value.name == "u.next.bank"
+    (f,) = _parse("function f(a b) local(t, u) instance(s) ( t = a; t*b );")
+    assert f.params == ["a", "b"] and f.locals == ["t", "u"] and f.instances == ["s"]
+    (n,) = _parse("slider(3) = 5;")
+    assert isinstance(n.target, S.Call) and n.target.fn == "slider"
+    with pytest.raises(SyntaxError):
+        _parse("a + b = 3;")
+    with pytest.raises(SyntaxError):
+        _parse("x = 'unterminated")
+
+
+def test_function_lowering_names_and_locals():
+    from zajit import program
+    text = """desc:t
+@init
+function lp(x) instance(s) local(tmp) ( tmp = x; s += 0.5*(tmp - s); s );
+function two(x) ( this.a.lp(x) + this.b.lp(x) );
+@sample
+spl0 = f1.two(spl0);
+spl1 = lp(spl1);
+"""
+    p = program.analyse(text)
+    assert "__fn__sample__two__ns__f1" in p.fns
+    assert "__fn__sample__lp__ns__f1_x2E_a" in p.fns and "__fn__sample__lp__ns__f1_x2E_b" in p.fns
+    assert "__fn__sample__lp__ns__lp" in p.fns            # bare call of an instance() function: namespace = its name
+    for v in ("f1.a.s", "f1.b.s", "lp.s", "__fnlocal__sample__lp__tmp"):
+        assert v in p.vars, v
+    assert p.io["inputs"] == 2 and p.io["outputs"] == 2
+
+
+def test_slider_declarations_and_quantiser():
+    from zajit import sliders
+    text = "slider1:30<0,100,1:sqr>Distance\nslider5:2<0,4,1{Eco,Moderate,High}>Quality\nslider7:0<-12,12,0.1:log>Out\nslider3:thr=-40<-80,0,0.1>-Hidden\n"
+    d = sliders.parse_slider_decls(text)
+    assert d[0].vmax == 100.0 and d[0].shape == "sqr" and d[4].is_choice and d[4].choices[2] == "High"
+    assert d[2].var_name == "thr" and d[2].hidden
+    row = sliders.default_slider_values(d)
+    assert row[0] == 30.0 and row[4] == 2.0
+    # float32 step 0.1 => -12 + 120 * 0.100000001490116 (what the reference host pushes for "0")
+    assert abs(row[6] - 1.7881393432617188e-07) < 1e-20
+    assert d[0].to_slider_value(250.0) == 100.0 and d[0].to_slider_value(33.4) == 33.0
+
+
+def test_leaf_discovery_contract(tmp_path):
+    """plugins/<Category>/<Key>/plugin.json, exactly two levels deep, entry -> source (scripts/pluginlib.py:105-240)."""
+    from zajit import build
+    leaf = tmp_path / "Dynamics" / "Foo"
+    (leaf / "src").mkdir(parents=True)
+    (leaf / "plugin.json").write_text(json.dumps({"name": "Foo", "pluginType": "jsfx", "entry": "src/Foo.jsfx"}))
+    (leaf / "src" / "Foo.jsfx").write_text("desc:x\n@sample\nspl0*=0.5;\n")
+    (tmp_path / "Dynamics" / "Deep" / "Er").mkdir(parents=True)
+    (tmp_path / "Dynamics" / "Deep" / "Er" / "plugin.json").write_text("{}")
+    found = build.discover(tmp_path)
+    assert list(found) == ["Foo"] and found["Foo"]["entry"].name == "Foo.jsfx" and found["Foo"]["category"] == "Dynamics"
