@@ -18,6 +18,7 @@ struct ZaPort {
   ZaState<ZA_NV> s;
   std::vector<double> mem;
   std::vector<uint32_t> mt;
+  std::vector<double> fft;
   int alias[64];
 };
 
@@ -35,6 +36,13 @@ ZaPort* port_create(double srate, int64_t mem_cap) {
   p->s.mt_stride = 1;
   p->s.srate = srate;
   p->s.instance_id = 1;
+#ifdef ZA_FFT_MAX
+  za_fft_table_init();
+  p->fft.assign(2 * ZA_FFT_MAX, 0.0);
+  p->s.fft = p->fft.data();
+  p->s.fft_stride = 1;
+  p->s.fft_cap = 2 * ZA_FFT_MAX;
+#endif
   for (int i = 0; i < 64; ++i) p->alias[i] = -1;
   return p;
 }
@@ -86,6 +94,12 @@ int64_t port_mem_read(ZaPort* p, int64_t start, int64_t n, double* dst) {
   int64_t k = 0;
   for (; k < n && start + k < p->s.mem_cap; ++k) dst[k] = p->mem[(size_t)(start + k)];
   for (int64_t j = k; j < n; ++j) dst[j] = 0.0;
+  return k;
+}
+int64_t port_mem_write(ZaPort* p, int64_t start, int64_t n, const double* src) {
+  int64_t k = 0;
+  for (; k < n && start + k < p->s.mem_cap; ++k) p->mem[(size_t)(start + k)] = src[k];
+  if (start + k > p->s.mem_high) p->s.mem_high = start + k;
   return k;
 }
 int64_t port_mem_high(ZaPort* p) { return p->s.mem_high; }

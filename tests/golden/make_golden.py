@@ -45,10 +45,13 @@ CASES = [
     ("ERBTilt", "default", {}, 2048, 512),
     ("SpectralStabilizer", "default", {}, 2048, 512),
     ("TSEQ", "default", {}, 2048, 512),
+    ("fx_stft", "default", {0: 0.4}, 4096, 512),      # repo-authored fixture leaf (tests/fixtures/stft.jsfx)
 ]
 
 
 def leaf_path(leaf: str) -> Path:
+    if leaf.startswith("fx_"):
+        return ROOT / "tests" / "fixtures" / (leaf[3:] + ".jsfx")
     hits = list((REF / "plugins").glob(f"*/{leaf}/src/*.jsfx"))
     assert hits, leaf
     return hits[0]

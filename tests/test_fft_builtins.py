@@ -1,0 +1,155 @@
+"""FFT builtins against known answers produced by the reference's own WDL build
+(tests/golden/wdl_fft.npz: WDL_fft / WDL_real_fft / WDL_fft_permute at REALSIZE=8).
+
+CPU: through the port of tests/fixtures/fftkat.jsfx (zart_fft.h compiled by g++).
+GPU: the same fixture leaf through the C ABI (zart_fft.h as __device__ code), plus the STFT fixture leaf against the
+reference VM's golden run.
+"""
+import numpy as np
+import pytest
+
+from conftest import AUDIO_EPS, GOLDEN, SCALAR_EPS, assert_state_close, golden_input, load_golden
+
+KAT = np.load(GOLDEN / "wdl_fft.npz")
+SIZES = (16, 64, 256, 1024, 4096)
+OPS = {"fft": 1, "ifft": 2, "fft_real": 3, "ifft_real": 4, "fft_permute": 5, "fft_ipermute": 6, "convolve_c": 7}
+
+
+def _cases(n):
+    """(op, input doubles, expected doubles)"""
+    perm = KAT[f"perm{n}"]
+    cin, cf, ci = KAT[f"c{n}_in"], KAT[f"c{n}_fwd"], KAT[f"c{n}_inv"]
+    z = cin[0::2] + 1j * cin[1::2]
+    nat = np.empty(2 * n); nat[0::2] = z[perm].real; nat[1::2] = z[perm].imag          # natural[k] = buf[perm[k]]
+    wdl = np.empty_like(z); wdl[perm] = z
+    ip = np.empty(2 * n); ip[0::2] = wdl.real; ip[1::2] = wdl.imag                      # buf[perm[k]] = natural[k]
+    yield "fft", cin, cf
+    yield "ifft", cin, ci
+    yield "fft_permute", cin, nat
+    yield "fft_ipermute", cin, ip
+    yield "fft_real", KAT[f"r{n}_in"], KAT[f"r{n}_fwd"]
+    yield "ifft_real", KAT[f"r{n}_in"], KAT[f"r{n}_inv"]
+
+
+def _tol(n, want):
+    return 64 * n * np.finfo(np.float64).eps * max(1.0, np.abs(want).max())
+
+
+def test_permutation_recursion_matches_wdl_table():
+    """za_fft_freq restated in numpy == WDL_fft_permute for every size in the fixture."""
+    def freq(i, n):
+        mul, add, mask = 1, 0, n - 1
+        while n > 2:
+            m = n >> 1
+            if i < m:
+                mul <<= 1; n = m; continue
+            i -= m; m >>= 1
+            if i < m:
+                add += mul; mul <<= 2; n = m; continue
+            i -= m
+            add -= mul; mul <<= 2; n = m
+        return (i * mul + add) & mask
+    for n in (16, 32, 128, 2048, 4096):
+        perm = np.zeros(n, dtype=np.int64)
+        for i in range(n):
+            perm[(n - freq(i, n)) & (n - 1)] = i
+        assert np.array_equal(perm, KAT[f"perm{n}"]), n
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_port_fft_known_answers(n):
+    from oracle import port
+    if not port.port_path("fx_fftkat").exists():
+        pytest.skip("fixture port not built")
+    for op, x, want in _cases(n):
+        p = port.Port("fx_fftkat", 48000.0, mem_cap=1 << 17)
+        p.set_sliders([0, n, 0, 0]); p.prepare()
+        p.mem_write(0, x)
+        p.set_sliders([OPS[op], n, 0, 0]); p.run_slider()
+        got = p.mem(0, len(want))
+        assert p.err == 0
+        assert np.abs(got - want).max() <= _tol(n, want), (op, n, np.abs(got - want).max())
+
+
+def test_port_fft_argument_rules():
+    """Page-crossing regions and bad sizes are silent no-ops (src/JSFXJuceProcessor.cpp:1126-1195); convolve_c; memcpy."""
+    from oracle import port
+    if not port.port_path("fx_fftkat").exists():
+        pytest.skip("fixture port not built")
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(64)
+    for n, base in ((24, 0), (8, 0), (65536, 0), (32, 65536 - 32)):      # not pow2, too small, too big, crosses a page
+        p = port.Port("fx_fftkat", 48000.0, mem_cap=1 << 18)
+        p.set_sliders([0, n, base, 0]); p.prepare()
+        p.mem_write(base, x)
+        p.set_sliders([1, n, base, 0]); p.run_slider()
+        assert np.array_equal(p.mem(base, 64), x), (n, base)
+    # convolve_c: dest *= src, 16 pairs, disjoint and overlapping (src read before dest is written)
+    a, b = rng.standard_normal(32), rng.standard_normal(32)
+    za, zb = a[0::2] + 1j * a[1::2], b[0::2] + 1j * b[1::2]
+    p = port.Port("fx_fftkat", 48000.0, mem_cap=1 << 17)
+    p.set_sliders([0, 16, 0, 100]); p.prepare()
+    p.mem_write(0, a); p.mem_write(100, b)
+    p.set_sliders([7, 16, 0, 100]); p.run_slider()
+    got = p.mem(0, 32)
+    assert np.allclose(got[0::2] + 1j * got[1::2], za * zb, rtol=0, atol=1e-14)
+    p = port.Port("fx_fftkat", 48000.0, mem_cap=1 << 17)
+    both = rng.standard_normal(40)
+    p.set_sliders([0, 16, 8, 0]); p.prepare()
+    p.mem_write(0, both)
+    p.set_sliders([7, 16, 8, 0]); p.run_slider()                           # dest = [8,40), src = [0,32): overlap
+    got = p.mem(8, 32)
+    zd, zs = both[8:40][0::2] + 1j * both[8:40][1::2], both[0:32][0::2] + 1j * both[0:32][1::2]
+    assert np.allclose(got[0::2] + 1j * got[1::2], zd * zs, rtol=0, atol=1e-14)
+
+
+def test_port_stft_fixture_matches_reference_vm():
+    from oracle import port
+    if not port.port_path("fx_stft").exists():
+        pytest.skip("fixture port not built")
+    g = load_golden("fx_stft_default")
+    p = port.Port("fx_stft", float(g["srate"]), mem_cap=1 << 16)
+    p.set_sliders(g["sliders"]); p.prepare()
+    y = p.process(golden_input(g), int(g["block"]))
+    assert np.abs(y.astype(np.float64) - g["out"]).max() <= AUDIO_EPS
+    names = [str(s) for s in g["var_names"]]
+    assert_state_close(names, p.vars(), g["vars"], what="stft vars")
+    want = np.zeros(int(g["mem_high"])); want[g["mem_idx"]] = g["mem_val"]
+    assert np.abs(p.mem(0, len(want)) - want).max() <= SCALAR_EPS
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", SIZES)
+def test_gpu_fft_known_answers(n):
+    """Every op on 70 instances at once (two waves), each instance with its own scaled copy of the input."""
+    import zabatch
+    inst = 70
+    scale = 1.0 + np.arange(inst)[:, None] * 0.125
+    for op, x, want in _cases(n):
+        with zabatch.Engine("fx_fftkat", inst, mem_cap=1 << 14) as e:
+            e.set_sliders([0, n, 0, 0]); e.prepare()
+            e.write_mem(0, scale * x[None, :])
+            e.set_sliders([OPS[op], n, 0, 0])
+            e.process_host(np.zeros((inst, 2, 8), np.float32), block=8)
+            got = e.read_mem(0, len(want))
+        ref = scale * want[None, :]
+        assert np.abs(got - ref).max() <= _tol(n, ref), (op, n, np.abs(got - ref).max())
+
+
+@pytest.mark.gpu
+def test_gpu_stft_fixture_matches_reference_vm():
+    import zabatch
+    g = load_golden("fx_stft_default")
+    n = 66
+    x = np.repeat(golden_input(g)[None], n, axis=0)
+    with zabatch.Engine("fx_stft", n, srate=float(g["srate"])) as e:
+        e.set_sliders(g["sliders"]); e.prepare()
+        y = e.process_host(x, block=int(g["block"]))
+        v = e.read_vars()
+        mem = e.read_mem(0, int(g["mem_high"]))
+        names = e.var_names()
+    assert np.abs(y.astype(np.float64) - g["out"].astype(np.float64)[None]).max() <= AUDIO_EPS
+    want = np.zeros(int(g["mem_high"])); want[g["mem_idx"]] = g["mem_val"]
+    for i in (0, 63, 65):
+        assert_state_close(names, v[i], g["vars"], what=f"stft vars[{i}]")
+    assert np.abs(mem - want[None]).max() <= SCALAR_EPS

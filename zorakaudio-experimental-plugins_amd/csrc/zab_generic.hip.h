@@ -15,6 +15,8 @@
 
 #include "zab_module.h"
 
+#include <mutex>
+
 #ifndef ZA_NCH
 #error "generated defines missing"
 #endif
@@ -58,6 +60,9 @@ __device__ __forceinline__ void za_state_bind(ZaS& s, const ZabBatch& b, int ins
   s.instance_id = b.first_id + (uint64_t)inst;
   s.sink = 0.0;
   s.memtop = ZA_MEMTOP;
+  s.fft = b.fft ? b.fft + (int64_t)inst * b.fft_si : nullptr;
+  s.fft_stride = b.fft_se;
+  s.fft_cap = b.fft ? b.fft_cap : 0;
 }
 
 __device__ __forceinline__ void za_state_load(ZaS& s, const ZabBatch& b, int inst) {
@@ -205,6 +210,10 @@ static hipError_t za_launch_slider(const ZabBatch* b, hipStream_t st) {
   return hipGetLastError();
 }
 static hipError_t za_launch_prepare(const ZabBatch* b, hipStream_t st) {
+#if ZA_USES_FFT
+  static std::once_flag za_fft_once;
+  std::call_once(za_fft_once, [st] { hipLaunchKernelGGL(za_fft_table_kernel, dim3(ZA_FFT_MAX / 2 / 256), dim3(256), 0, st); });
+#endif
   hipLaunchKernelGGL(ZA_KERNEL(prepare), dim3((b->n_inst + 63) / 64), dim3(64), 0, st, *b);
   return hipGetLastError();
 }

@@ -6,7 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define ZAB_MODULE_ABI 4
+#define ZAB_MODULE_ABI 5
 
 enum { ZAB_FLAG_SLIDER_DIRTY = 1u, ZAB_FLAG_PREPARED = 2u };
 
@@ -35,6 +35,7 @@ struct ZabBatch {
   uint64_t first_id;
   const void* gmem;                            // ZaGmemView* (device) or null
   const void* pool;                            // ZaPoolView* (device) or null
+  double* fft;    int64_t fft_se, fft_si, fft_cap;   // FFT builtin scratch (null / 0 when unused)
   uint64_t epoch;                              // bumped by the runtime whenever host calls may have changed state
 };
 
@@ -54,6 +55,7 @@ struct ZabModule {
   int32_t prefer_instance_major;
   int64_t default_mem_cap;
   const char* const* var_names;      // [nvars], index order
+  int64_t fft_scratch_doubles;       // per-instance scratch the runtime must provide (0: leaf has no FFT builtins)
   // generic (translator-generated) kernels
   hipError_t (*launch_prepare)(const ZabBatch*, hipStream_t);
   hipError_t (*launch_process)(const ZabBatch*, const ZabAudio*, hipStream_t);

@@ -169,19 +169,23 @@ int zab_create(const char* module, const zab_config* cfg, zab_engine** out) {
     b.sl_se = 1; b.sl_si = 64;
     b.mem_se = 1; b.mem_si = b.mem_cap;
     b.mt_se = 1; b.mt_si = 624;
+    b.fft_se = 1; b.fft_si = m->fft_scratch_doubles;
   } else {
     b.var_se = P; b.var_si = 1;
     b.sl_se = P; b.sl_si = 1;
     b.mem_se = P; b.mem_si = 1;
     b.mt_se = P; b.mt_si = 1;
+    b.fft_se = P; b.fft_si = 1;
   }
+  b.fft_cap = m->fft_scratch_doubles;
   if ((rc = e->alloc(&b.vars, (size_t)P * m->nvars)) || (rc = e->alloc(&b.sliders, (size_t)P * 64)) ||
       (rc = e->alloc(&b.spl, (size_t)P * 64)) || (rc = e->alloc(&b.mem, (size_t)P * b.mem_cap)) ||
       (rc = e->alloc(&b.mt, (size_t)P * 624)) || (rc = e->alloc(&b.mti, (size_t)P)) ||
       (rc = e->alloc(&b.mem_high, (size_t)P)) || (rc = e->alloc(&b.mem_need, (size_t)P)) ||
       (rc = e->alloc(&b.err, (size_t)P)) || (rc = e->alloc(&b.flags, (size_t)P)) ||
       (rc = e->alloc(&b.pend, (size_t)P * 3)) || (rc = e->alloc(&b.vis_mask, (size_t)P)) ||
-      (rc = e->alloc(&b.vis_init, (size_t)P))) {
+      (rc = e->alloc(&b.vis_init, (size_t)P)) ||
+      (m->fft_scratch_doubles > 0 && (rc = e->alloc(&b.fft, (size_t)P * m->fft_scratch_doubles)))) {
     zab_destroy(e);
     return rc;
   }

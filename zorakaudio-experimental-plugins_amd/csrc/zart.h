@@ -71,6 +71,9 @@ struct ZaState {
   uint64_t instance_id;
   double sink;
   double memtop;
+  double* fft;           // FFT builtin scratch (natural-order work area), element a at fft[a * fft_stride]
+  int64_t fft_stride;
+  int64_t fft_cap;       // doubles available (0 when the leaf has no FFT builtins)
 };
 
 // ---------------------------------------------------------------------------------------------

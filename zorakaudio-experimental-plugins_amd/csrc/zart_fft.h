@@ -1,0 +1,284 @@
+// zart_fft.h -- JSFX FFT builtins for generated section code: fft / ifft / fft_real / ifft_real / fft_permute /
+// fft_ipermute / convolve_c over mem[], with the reference's conventions (not its code):
+//   * argument handling, size limits 16..32768, "region must not cross a 65536-double page, else silently do nothing",
+//     overlap-safe convolve_c ................................. src/JSFXJuceProcessor.cpp:1076-1447
+//   * WDL_fft(buf, N, 0): unscaled forward DFT (e^-i), result stored in WDL_fft_permute order; WDL_fft(buf, N, 1):
+//     input in that order, unscaled inverse (e^+i), natural-order output ............. src/WDL/fft.h:55-57
+//   * permutation: position i holds natural bin (N - f(i)) mod N with f the DJBFFT split-radix frequency recursion
+//     (src/WDL/fft.c:990-1019); fft_permute gathers natural[k] = buf[perm[k]] (JSFXJuceProcessor.cpp:1230-1264)
+//   * WDL_real_fft: N reals -> N/2 packed bins in permute order of N/2, bins scaled by 2, DC in [0].re and Nyquist in
+//     [0].im; inverse is the exact reverse, unscaled (so fft_real -> ifft_real multiplies by 2N) ... src/WDL/fft.h:59-63,
+//     fft.c:1086-1176 (the "two for one" real transform)
+// Known answers: tests/golden/wdl_fft.npz (produced by the reference WDL build).
+//
+// The transform itself is this repo's own: an iterative radix-2 decimation-in-time FFT in a per-instance scratch buffer
+// (natural order), then a scatter into the WDL order. One lane executes one instance's transform (generic kernels);
+// a wave-cooperative / MFMA batched variant for large STFT workloads is a later-round kernel.
+#pragma once
+
+#include "zart.h"
+
+#define ZA_FFT_MIN 16
+#define ZA_FFT_MAX 32768
+#define ZA_FFT_PAGE 65536
+
+// cos/sin(2*pi*j/ZA_FFT_MAX), j < ZA_FFT_MAX/2; filled once per process by za_fft_table_init (host) / init kernel (device)
+#if defined(__HIPCC__)
+__device__ double za_fft_cos[ZA_FFT_MAX / 2];
+__device__ double za_fft_sin[ZA_FFT_MAX / 2];
+extern "C" __global__ void za_fft_table_kernel() {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < ZA_FFT_MAX / 2) {
+    double sn, cs;
+    sincos(6.283185307179586476925286766559 * (double)j / (double)ZA_FFT_MAX, &sn, &cs);
+    za_fft_cos[j] = cs;
+    za_fft_sin[j] = sn;
+  }
+}
+#else
+static double za_fft_cos[ZA_FFT_MAX / 2];
+static double za_fft_sin[ZA_FFT_MAX / 2];
+static void za_fft_table_init(void) {
+  static int done;
+  if (done) return;
+  for (int j = 0; j < ZA_FFT_MAX / 2; ++j) {
+    za_fft_cos[j] = cos(6.283185307179586476925286766559 * (double)j / (double)ZA_FFT_MAX);
+    za_fft_sin[j] = sin(6.283185307179586476925286766559 * (double)j / (double)ZA_FFT_MAX);
+  }
+  done = 1;
+}
+#endif
+
+// DJBFFT frequency of buffer position i in an n-point transform (iterative form of the split-radix recursion).
+ZA_FN uint32_t za_fft_freq(uint32_t i, uint32_t n) {
+  uint32_t mul = 1, add = 0;           // result = ((f(i', n') * mul) + add), accumulated from the outside in
+  // f(i,n): n<=2 -> i;  i<n/2 -> 2 f(i, n/2);  i-n/2 < n/4 -> 4 f(., n/4) + 1;  else 4 f(., n/4) - 1   (mod n)
+  const uint32_t mask = n - 1;
+  while (n > 2) {
+    uint32_t m = n >> 1;
+    if (i < m) { mul <<= 1; n = m; continue; }
+    i -= m; m >>= 1;
+    if (i < m) { add += mul; mul <<= 2; n = m; continue; }
+    i -= m;
+    add -= mul; mul <<= 2; n = m;
+  }
+  return (i * mul + add) & mask;
+}
+ZA_FN uint32_t za_fft_bin_of_pos(uint32_t i, uint32_t n) { return (n - za_fft_freq(i, n)) & (n - 1); }
+ZA_FN uint32_t za_bitrev(uint32_t v, int bits) {
+  v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+  v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+  v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
+  v = ((v >> 8) & 0x00FF00FFu) | ((v & 0x00FF00FFu) << 8);
+  v = (v >> 16) | (v << 16);
+  return v >> (32 - bits);
+}
+ZA_FN int za_log2(uint32_t n) { int b = 0; while ((1u << b) < n) ++b; return b; }
+
+ZA_FN bool za_fft_pow2(int64_t n) { return n >= ZA_FFT_MIN && n <= ZA_FFT_MAX && (n & (n - 1)) == 0; }
+ZA_FN bool za_fft_in_page(int64_t base, int64_t span) {
+  if (base < 0 || span <= 0) return false;
+  return (base / ZA_FFT_PAGE) == ((base + span - 1) / ZA_FFT_PAGE);
+}
+
+// Validate a region of `span` doubles at base; the reference grows mem here, a fixed arena reports overflow.
+template <class S>
+ZA_FN bool za_fft_region(S& s, double baseD, int64_t span, int64_t& base, int64_t scratch_need) {
+  int64_t b = za_round_idx(baseD);
+  if (b < 0) b = 0;
+  if (!za_fft_in_page(b, span)) return false;
+  if (b + span > s.mem_cap) {
+    s.err |= ZA_ERR_MEM_OVERFLOW;
+    if (b + span > s.mem_need) s.mem_need = b + span;
+    return false;
+  }
+  if (s.fft_cap < scratch_need) { s.err |= ZA_ERR_UNSUPPORTED; return false; }   // scratch not provisioned for this size
+  if (b + span > s.mem_high) s.mem_high = b + span;
+  base = b;
+  return true;
+}
+
+#define ZA_M(a) s.mem[(a) * s.mem_stride]
+#define ZA_F(a) s.fft[(a) * s.fft_stride]
+
+// natural-order in-scratch DIT butterflies on n complex values (already stored bit-reversed); sign = -1 forward, +1 inverse
+template <class S>
+ZA_FN void za_fft_butterflies(S& s, int n, int sign) {
+  for (int len = 2; len <= n; len <<= 1) {
+    const int half = len >> 1, step = ZA_FFT_MAX / len;
+    for (int j = 0; j < half; ++j) {
+      const double wr = za_fft_cos[j * step], wi = (sign < 0 ? -za_fft_sin[j * step] : za_fft_sin[j * step]);
+      for (int i = j; i < n; i += len) {
+        const int a = 2 * i, b = 2 * (i + half);
+        const double br = ZA_F(b), bi = ZA_F(b + 1);
+        const double tr = br * wr - bi * wi, ti = br * wi + bi * wr;
+        const double ar = ZA_F(a), ai = ZA_F(a + 1);
+        ZA_F(a) = ar + tr; ZA_F(a + 1) = ai + ti;
+        ZA_F(b) = ar - tr; ZA_F(b + 1) = ai - ti;
+      }
+    }
+  }
+}
+
+// forward complex transform of mem[base .. base+2n): natural in, WDL order out
+template <class S>
+ZA_FN void za_fft_fwd_core(S& s, int64_t base, int n) {
+  const int bits = za_log2((uint32_t)n);
+  for (int i = 0; i < n; ++i) {
+    const uint32_t r = za_bitrev((uint32_t)i, bits);
+    ZA_F(2 * r) = ZA_M(base + 2 * i);
+    ZA_F(2 * r + 1) = ZA_M(base + 2 * i + 1);
+  }
+  za_fft_butterflies(s, n, -1);
+  for (int i = 0; i < n; ++i) {
+    const uint32_t k = za_fft_bin_of_pos((uint32_t)i, (uint32_t)n);
+    ZA_M(base + 2 * i) = ZA_F(2 * k);
+    ZA_M(base + 2 * i + 1) = ZA_F(2 * k + 1);
+  }
+}
+// inverse complex transform: WDL order in, natural out, unscaled
+template <class S>
+ZA_FN void za_fft_inv_core(S& s, int64_t base, int n) {
+  const int bits = za_log2((uint32_t)n);
+  for (int i = 0; i < n; ++i) {
+    const uint32_t k = za_fft_bin_of_pos((uint32_t)i, (uint32_t)n);
+    const uint32_t r = za_bitrev(k, bits);
+    ZA_F(2 * r) = ZA_M(base + 2 * i);
+    ZA_F(2 * r + 1) = ZA_M(base + 2 * i + 1);
+  }
+  za_fft_butterflies(s, n, +1);
+  for (int i = 0; i < 2 * n; ++i) ZA_M(base + i) = ZA_F(i);
+}
+
+template <class S> ZA_NOINLINE double za_fft(S& s, double baseD, double sizeD) {
+  const int64_t n = za_round_idx(sizeD);
+  int64_t base;
+  if (!za_fft_pow2(n) || !za_fft_region(s, baseD, 2 * n, base, 2 * n)) return 0.0;
+  za_fft_fwd_core(s, base, (int)n);
+  return 0.0;
+}
+template <class S> ZA_NOINLINE double za_ifft(S& s, double baseD, double sizeD) {
+  const int64_t n = za_round_idx(sizeD);
+  int64_t base;
+  if (!za_fft_pow2(n) || !za_fft_region(s, baseD, 2 * n, base, 2 * n)) return 0.0;
+  za_fft_inv_core(s, base, (int)n);
+  return 0.0;
+}
+template <class S> ZA_NOINLINE double za_fft_permute(S& s, double baseD, double sizeD) {   // WDL order -> natural
+  const int64_t n = za_round_idx(sizeD);
+  int64_t base;
+  if (!za_fft_pow2(n) || !za_fft_region(s, baseD, 2 * n, base, 2 * n)) return 0.0;
+  for (int i = 0; i < (int)n; ++i) {
+    const uint32_t k = za_fft_bin_of_pos((uint32_t)i, (uint32_t)n);
+    ZA_F(2 * k) = ZA_M(base + 2 * i);
+    ZA_F(2 * k + 1) = ZA_M(base + 2 * i + 1);
+  }
+  for (int i = 0; i < 2 * (int)n; ++i) ZA_M(base + i) = ZA_F(i);
+  return 0.0;
+}
+template <class S> ZA_NOINLINE double za_fft_ipermute(S& s, double baseD, double sizeD) {  // natural -> WDL order
+  const int64_t n = za_round_idx(sizeD);
+  int64_t base;
+  if (!za_fft_pow2(n) || !za_fft_region(s, baseD, 2 * n, base, 2 * n)) return 0.0;
+  for (int i = 0; i < 2 * (int)n; ++i) ZA_F(i) = ZA_M(base + i);
+  for (int i = 0; i < (int)n; ++i) {
+    const uint32_t k = za_fft_bin_of_pos((uint32_t)i, (uint32_t)n);
+    ZA_M(base + 2 * i) = ZA_F(2 * k);
+    ZA_M(base + 2 * i + 1) = ZA_F(2 * k + 1);
+  }
+  return 0.0;
+}
+
+// Real transforms ("two for one"): N reals are treated as N/2 complex z[t] = x[2t] + i x[2t+1].
+//   forward:  Z = FFT_{N/2}(z) (natural bins), X[k] = 0.5*(Z[k] + conj Z[h-k]) - 0.5i e^{-2 pi i k/N} (Z[k] - conj Z[h-k]),
+//             stored 2*X[k] at position perm_h(k); position 0 holds (2*X[0], 2*X[N/2]).
+//   inverse:  the exact reverse, then an unscaled inverse FFT_{N/2}.
+template <class S> ZA_NOINLINE double za_fft_real(S& s, double baseD, double sizeD) {
+  const int64_t n = za_round_idx(sizeD);
+  int64_t base;
+  if (!za_fft_pow2(n) || !za_fft_region(s, baseD, n, base, 2 * n)) return 0.0;
+  const int h = (int)(n >> 1), bits = za_log2((uint32_t)h);
+  for (int i = 0; i < h; ++i) {
+    const uint32_t r = za_bitrev((uint32_t)i, bits);
+    ZA_F(2 * r) = ZA_M(base + 2 * i);
+    ZA_F(2 * r + 1) = ZA_M(base + 2 * i + 1);
+  }
+  za_fft_butterflies(s, h, -1);                                   // scratch = Z[0..h) natural
+  const int step = ZA_FFT_MAX / (int)n;
+  for (int i = 0; i < h; ++i) {
+    const int k = (int)za_fft_bin_of_pos((uint32_t)i, (uint32_t)h);
+    double re, im;
+    if (k == 0) {
+      re = 2.0 * (ZA_F(0) + ZA_F(1));                              // 2*X[0]
+      im = 2.0 * (ZA_F(0) - ZA_F(1));                              // 2*X[N/2]
+    } else {
+      const int m = h - k;
+      const double zr = ZA_F(2 * k), zi = ZA_F(2 * k + 1), yr = ZA_F(2 * m), yi = -ZA_F(2 * m + 1);   // y = conj Z[h-k]
+      const double er = zr + yr, ei = zi + yi, dr = zr - yr, di = zi - yi;
+      const double c = za_fft_cos[k * step], sn = za_fft_sin[k * step];   // e^{-i t}: (c, -sn); -i*e^{-it} = (-sn, -c)
+      // 2X = (er,ei) + (-sn,-c)*(dr,di)
+      re = er + (-sn * dr + c * di);
+      im = ei + (-sn * di - c * dr);
+    }
+    ZA_M(base + 2 * i) = re;
+    ZA_M(base + 2 * i + 1) = im;
+  }
+  return 0.0;
+}
+template <class S> ZA_NOINLINE double za_ifft_real(S& s, double baseD, double sizeD) {
+  const int64_t n = za_round_idx(sizeD);
+  int64_t base;
+  if (!za_fft_pow2(n) || !za_fft_region(s, baseD, n, base, 2 * n)) return 0.0;
+  const int h = (int)(n >> 1), bits = za_log2((uint32_t)h);
+  // gather the packed spectrum into natural order at the start of scratch's upper half, then build Z bit-reversed
+  // in the lower half. scratch capacity >= 2*(2h) doubles is guaranteed by fft_cap >= n (complex count) * 2.
+  const int64_t up = 2 * (int64_t)h;
+  for (int i = 0; i < h; ++i) {
+    const uint32_t k = za_fft_bin_of_pos((uint32_t)i, (uint32_t)h);
+    ZA_F(up + 2 * k) = ZA_M(base + 2 * i);
+    ZA_F(up + 2 * k + 1) = ZA_M(base + 2 * i + 1);
+  }
+  const int step = ZA_FFT_MAX / (int)n;
+  for (int k = 0; k < h; ++k) {
+    double zr, zi;
+    if (k == 0) {
+      const double x0 = ZA_F(up), xn = ZA_F(up + 1);               // X[0], X[N/2] (both real)
+      zr = x0 + xn; zi = x0 - xn;                                  // Z[0] = (X0 + Xn) + i (X0 - Xn)
+    } else {
+      const int m = h - k;
+      const double ar = ZA_F(up + 2 * k), ai = ZA_F(up + 2 * k + 1);          // X[k]
+      const double br = ZA_F(up + 2 * m), bi = -ZA_F(up + 2 * m + 1);         // conj X[h-k]
+      const double er = ar + br, ei = ai + bi, dr = ar - br, di = ai - bi;
+      const double c = za_fft_cos[k * step], sn = za_fft_sin[k * step];       // i*e^{+it} = (-sn, c)
+      zr = er + (-sn * dr - c * di);
+      zi = ei + (-sn * di + c * dr);
+    }
+    const uint32_t r = za_bitrev((uint32_t)k, bits);
+    ZA_F(2 * r) = zr;
+    ZA_F(2 * r + 1) = zi;
+  }
+  za_fft_butterflies(s, h, +1);
+  for (int i = 0; i < (int)n; ++i) ZA_M(base + i) = ZA_F(i);
+  return 0.0;
+}
+
+// convolve_c(dest, src, size): dest[i] *= src[i] for `size` complex pairs, src read before dest is written on overlap.
+template <class S> ZA_NOINLINE double za_convolve_c(S& s, double destD, double srcD, double sizeD) {
+  const int64_t cnt = za_round_idx(sizeD);
+  if (cnt <= 0 || cnt > ZA_FFT_PAGE / 2) return 0.0;
+  int64_t d, r;
+  if (!za_fft_region(s, destD, 2 * cnt, d, 2 * cnt)) return 0.0;
+  if (!za_fft_region(s, srcD, 2 * cnt, r, 2 * cnt)) return 0.0;
+  const bool overlap = (d < r + 2 * cnt) && (r < d + 2 * cnt) && d != r;
+  if (overlap) for (int64_t i = 0; i < 2 * cnt; ++i) ZA_F(i) = ZA_M(r + i);
+  for (int64_t i = 0; i < cnt; ++i) {
+    const double ar = ZA_M(d + 2 * i), ai = ZA_M(d + 2 * i + 1);
+    const double br = overlap ? ZA_F(2 * i) : ZA_M(r + 2 * i), bi = overlap ? ZA_F(2 * i + 1) : ZA_M(r + 2 * i + 1);
+    ZA_M(d + 2 * i) = ar * br - ai * bi;
+    ZA_M(d + 2 * i + 1) = ar * bi + ai * br;
+  }
+  return 0.0;
+}
+
+#undef ZA_M
+#undef ZA_F
