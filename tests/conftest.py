@@ -56,3 +56,9 @@ def assert_state_close(names, got, want, eps=SCALAR_EPS, what="vars", skip=()):
 def have_gpu():
     import torch
     return torch.cuda.is_available()
+
+
+def leaf_of(case: str) -> str:
+    """'DDT_far_extreme' -> 'DDT', 'fx_stft_default' -> 'fx_stft' (fixture leaves carry the fx_ prefix)."""
+    parts = case.split("_")
+    return "_".join(parts[:2]) if parts[0] == "fx" else parts[0]

@@ -7,7 +7,7 @@ write high-water mark exactly. Instances are replicated so that several lanes of
 import numpy as np
 import pytest
 
-from conftest import AUDIO_EPS, GOLDEN, SCALAR_EPS, assert_state_close, dbfs, golden_input, load_golden
+from conftest import AUDIO_EPS, GOLDEN, SCALAR_EPS, assert_state_close, dbfs, golden_input, leaf_of, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -17,7 +17,7 @@ CASES = sorted(p.stem for p in GOLDEN.glob("*_default.npz") if not p.stem.starts
 @pytest.mark.parametrize("case", CASES)
 def test_leaf_matches_reference_vm(case):
     import zabatch
-    leaf = case.split("_")[0]
+    leaf = leaf_of(case)
     if not zabatch.module_path(leaf).exists():
         pytest.skip(f"module for {leaf} not built")
     g = load_golden(case)

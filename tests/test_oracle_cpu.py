@@ -11,7 +11,7 @@ from pathlib import Path
 import numpy as np
 import pytest
 
-from conftest import AUDIO_EPS, GOLDEN, ROOT, SCALAR_EPS, assert_state_close, golden_input, load_golden
+from conftest import AUDIO_EPS, GOLDEN, ROOT, SCALAR_EPS, assert_state_close, golden_input, leaf_of, load_golden
 
 CASES = sorted(p.stem for p in GOLDEN.glob("*_*.npz") if p.stem != "wdl_fft")
 REF_PLUGINS = Path("/root/reference/plugins")
@@ -25,7 +25,7 @@ def _port_available(leaf):
 @pytest.mark.parametrize("case", CASES)
 def test_port_matches_reference_vm_fixture(case):
     from oracle import port
-    leaf = case.split("_")[0]
+    leaf = leaf_of(case)
     if not _port_available(leaf):
         pytest.skip(f"port for {leaf} not built")
     g = load_golden(case)
@@ -55,7 +55,7 @@ def test_reference_vm_reproduces_its_fixture(case):
     from zajit import program
     if not eel_oracle.available():
         pytest.skip("oracle/_ref not built")
-    leaf = case.split("_")[0]
+    leaf = leaf_of(case)
     src = next(REF_PLUGINS.glob(f"*/{leaf}/src/*.jsfx"))
     text = program.expand_imports(src)
     prog = program.analyse(text, leaf)
