@@ -375,7 +375,10 @@ void eelo_get_sliders(eelo* e, double* v, int count) {
 
 // prepareToPlay analogue: sliders must have been set already (valid inside @init).
 void eelo_prepare(eelo* e, double srate, int64_t mem_hint) {
-  e->ensure_ram(std::max<int64_t>(65536, mem_hint));
+  // The reference sizes the shadow VM's RAM to max(65536, memN of the compiled side) at every block start
+  // (src/JSFXCorrectnessCheck.h:259), i.e. to whatever the compiled code has grown its heap to. A standalone oracle has
+  // no compiled side to follow, so without a hint it keeps EEL2's own default ceiling (8 Mi items, ns-eel.h:230).
+  e->ensure_ram(mem_hint > 0 ? std::max<int64_t>(65536, mem_hint) : (int64_t)NSEEL_RAM_BLOCKS * NSEEL_RAM_ITEMSPERBLOCK);
   e->sync_alias();
   if (e->p_srate) *e->p_srate = srate;
   if (e->p_samplesblock) *e->p_samplesblock = 0.0;
@@ -422,11 +425,12 @@ double eelo_get_spl(eelo* e, int ch) { return (ch >= 0 && ch < 64 && e->splp[ch]
 int64_t eelo_mem_read(eelo* e, int64_t start, int64_t count, double* dst) {
   int64_t done = 0;
   while (done < count) {
+    const int64_t off = start + done;
+    const int64_t in_block = NSEEL_RAM_ITEMSPERBLOCK - (off % NSEEL_RAM_ITEMSPERBLOCK);
+    const int64_t n = std::min<int64_t>(in_block, count - done);
     int valid = 0;
-    EEL_F* p = NSEEL_VM_getramptr(e->m_vm, (unsigned)(start + done), &valid);
-    if (valid <= 0) break;
-    int64_t n = std::min<int64_t>(valid, count - done);
-    if (p) std::memcpy(dst + done, p, (size_t)n * sizeof(double));
+    EEL_F* p = NSEEL_VM_getramptr_noalloc(e->m_vm, (unsigned)off, &valid);   // never-touched blocks read as zeros
+    if (p && valid >= n) std::memcpy(dst + done, p, (size_t)n * sizeof(double));
     else std::memset(dst + done, 0, (size_t)n * sizeof(double));
     done += n;
   }

@@ -46,6 +46,13 @@ CASES = [
     ("SpectralStabilizer", "default", {}, 2048, 512),
     ("TSEQ", "default", {}, 2048, 512),
     ("fx_stft", "default", {0: 0.4}, 4096, 512),      # repo-authored fixture leaf (tests/fixtures/stft.jsfx)
+    # DOT is deliberately absent: its `topo == 1 ? K=4 : (...)` chain (DOT.jsfx:372) parses differently in EEL2
+    # (unparenthesised assignment inside ?: -> K stays 0) and in the reference's AOT parser (K = 2), so the reference's
+    # own shadow VM disagrees with its compiled path on this leaf; DOT is checked device-vs-port instead.
+    ("Alias", "default", {}, 2048, 512),
+    ("SOMA", "default", {}, 2048, 512),                # rand(): EEL2's MT19937 is process-global -> one process per case
+    ("BedRock", "default", {}, 2048, 512),
+    ("NeuroCV", "default", {}, 1024, 256),             # 18 channels, rand, sliderchange, memcpy
 ]
 
 
@@ -135,10 +142,14 @@ def fft_vectors():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) == 3 and sys.argv[1] == "--one":           # child: exactly one case in a fresh VM process
+        make_case(*CASES[int(sys.argv[2])])
+        sys.exit(0)
     only = set(sys.argv[1:])
-    for c in CASES:
+    import subprocess
+    for i, c in enumerate(CASES):
         if not only or c[0] in only:
-            make_case(*c)
+            subprocess.run([sys.executable, __file__, "--one", str(i)], check=True)
     if not only or "frontend" in only:
         frontend_pins()
     if not only or "fft" in only:

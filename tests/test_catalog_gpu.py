@@ -77,3 +77,32 @@ def test_processor_mirror_parameter_push():
         r2 = p.process(x[i, :, frames:], 256)
         assert np.abs(y1[i].astype(np.float64) - r1).max() <= AUDIO_EPS
         assert np.abs(y2[i].astype(np.float64) - r2).max() <= AUDIO_EPS
+
+
+def test_dot_device_vs_port():
+    """Spatialization/DOT (fft/fft_permute/ifft in @slider building a min-phase kernel). The reference's own EEL2 VM
+    parses DOT.jsfx:372 differently from its AOT compiler (see tests/golden/make_golden.py), so this leaf is checked
+    against the CPU port of the AOT lowering instead of a VM fixture: same translator text, g++ vs hipcc + device libm."""
+    import zabatch
+    from oracle import port
+    from zajit import noise
+    if not zabatch.module_path("DOT").exists() or not port.port_path("DOT").exists():
+        pytest.skip("DOT not built")
+    meta = zabatch.leaf_meta("DOT")
+    n, frames = 66, 1536
+    x = noise.white_noise(range(n), frames)
+    rows = np.tile(np.array(meta["default_sliders"]), (n, 1))
+    rows[1::3, 0] = 1; rows[2::3, 0] = 2; rows[5::7, 0] = 3        # all four topologies
+    rows[:, 2] = np.linspace(5, 95, n)                             # brightness sweep -> different kernel lengths
+    with zabatch.Engine("DOT", n, mem_cap=1 << 16) as e:
+        e.set_sliders(rows); e.prepare()
+        y = e.process_host(x, block=512)
+        v = e.read_vars(); names = e.var_names()
+        mem = e.read_mem(0, 57344)
+    for i in (0, 1, 2, 5, 33, 65):
+        p = port.Port("DOT", 48000.0, mem_cap=1 << 16)
+        p.set_sliders(rows[i]); p.prepare()
+        ref = p.process(x[i], 512)
+        assert np.abs(y[i].astype(np.float64) - ref).max() <= AUDIO_EPS, i
+        assert_state_close(names, v[i], p.vars(), what=f"DOT vars[{i}]")
+        assert np.abs(mem[i] - p.mem(0, 57344)).max() <= SCALAR_EPS, i
