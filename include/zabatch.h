@@ -117,6 +117,13 @@ int zab_read_mem(zab_engine* e, int32_t first, int32_t count, int64_t start, int
 int zab_write_mem(zab_engine* e, int32_t first, int32_t count, int64_t start, int64_t n, const double* src);
 int zab_read_mem_high(zab_engine* e, int32_t first, int32_t count, int64_t* dst); /* write high-water marks */
 
+/* gmem[] segment of the engine (leaves that use gmem; reference: DspJsfxGmemAttachment, src/DspJsfxGmem.cpp).
+ * One segment of 1 Mi cells per engine, shared by all its instances. read/write move raw doubles; seq returns the
+ * write-sequence counter of a 1024-cell page, or the global one for page < 0. */
+int zab_gmem_read(zab_engine* e, int64_t start, int64_t n, double* dst);
+int zab_gmem_write(zab_engine* e, int64_t start, int64_t n, const double* src);
+int zab_gmem_seq(zab_engine* e, int64_t page, uint64_t* out);
+
 /* Device buffer helpers so hosts without a HIP binding (ctypes, cgo, JNI) can keep audio HBM-resident. */
 int zab_device_alloc(zab_engine* e, int64_t bytes, void** out);
 int zab_device_free(zab_engine* e, void* p);

@@ -19,6 +19,11 @@ struct ZaPort {
   std::vector<double> mem;
   std::vector<uint32_t> mt;
   std::vector<double> fft;
+#ifdef ZA_GMEM_PAGE_CELLS
+  std::vector<unsigned long long> gcells, gpseq, gpwr;
+  unsigned long long gseq = 0;
+  ZaGmemView gview;
+#endif
   int alias[64];
 };
 
@@ -42,6 +47,15 @@ ZaPort* port_create(double srate, int64_t mem_cap) {
   p->s.fft = p->fft.data();
   p->s.fft_stride = 1;
   p->s.fft_cap = 2 * ZA_FFT_MAX;
+#endif
+#ifdef ZA_GMEM_PAGE_CELLS
+  p->gcells.assign(ZA_GMEM_DEFAULT_CELLS, 0ull);
+  p->gpseq.assign(ZA_GMEM_DEFAULT_CELLS / ZA_GMEM_PAGE_CELLS, 0ull);
+  p->gpwr.assign(ZA_GMEM_DEFAULT_CELLS / ZA_GMEM_PAGE_CELLS, 0ull);
+  p->gview = ZaGmemView{p->gcells.data(), p->gpseq.data(), p->gpwr.data(), &p->gseq, ZA_GMEM_DEFAULT_CELLS,
+                        ZA_GMEM_DEFAULT_CELLS / ZA_GMEM_PAGE_CELLS};
+  p->s.gmem = &p->gview;
+  p->s.gmem_attached = ZA_GMEM_AUTOATTACH;
 #endif
   for (int i = 0; i < 64; ++i) p->alias[i] = -1;
   return p;
@@ -102,6 +116,11 @@ int64_t port_mem_write(ZaPort* p, int64_t start, int64_t n, const double* src) {
   if (start + k > p->s.mem_high) p->s.mem_high = start + k;
   return k;
 }
+#ifdef ZA_GMEM_PAGE_CELLS
+void port_gmem_read(ZaPort* p, int64_t start, int64_t n, double* dst) { memcpy(dst, p->gcells.data() + start, sizeof(double) * (size_t)n); }
+void port_gmem_write(ZaPort* p, int64_t start, int64_t n, const double* src) { memcpy(p->gcells.data() + start, src, sizeof(double) * (size_t)n); }
+uint64_t port_gmem_seq(ZaPort* p, int64_t page) { return page < 0 ? p->gseq : p->gpseq[(size_t)page]; }
+#endif
 int64_t port_mem_high(ZaPort* p) { return p->s.mem_high; }
 int64_t port_mem_need(ZaPort* p) { return p->s.mem_need; }
 uint32_t port_err(ZaPort* p) { return p->s.err; }

@@ -63,6 +63,7 @@ __device__ __forceinline__ void za_state_bind(ZaS& s, const ZabBatch& b, int ins
   s.fft = b.fft ? b.fft + (int64_t)inst * b.fft_si : nullptr;
   s.fft_stride = b.fft_se;
   s.fft_cap = b.fft ? b.fft_cap : 0;
+  s.gmem_attached = b.gmem_att ? b.gmem_att[inst] : 0;
 }
 
 __device__ __forceinline__ void za_state_load(ZaS& s, const ZabBatch& b, int inst) {
@@ -95,6 +96,7 @@ __device__ __forceinline__ void za_state_store(const ZaS& s, const ZabBatch& b, 
   b.pend[2 * b.n_pad + inst] = s.pend_automate_end;
   b.vis_mask[inst] = s.vis_mask;
   b.vis_init[inst] = s.vis_init;
+  if (b.gmem_att) b.gmem_att[inst] = s.gmem_attached;
 }
 
 // sliderN:var=... aliases: the host keeps the named var equal to the slider (src/JSFXJuceProcessor.cpp:9349-9353)
@@ -123,6 +125,7 @@ extern "C" __global__ void __launch_bounds__(64) ZA_KERNEL(prepare)(ZabBatch b) 
   s.pend_change = s.pend_automate = s.pend_automate_end = 0;
   s.vis_mask = 0;
   s.vis_init = 0;
+  s.gmem_attached = ZA_GMEM_AUTOATTACH;
   za_alias_sync(s);
   za_section_init(s);
   za_alias_sync(s);

@@ -6,7 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define ZAB_MODULE_ABI 5
+#define ZAB_MODULE_ABI 6
 
 enum { ZAB_FLAG_SLIDER_DIRTY = 1u, ZAB_FLAG_PREPARED = 2u };
 
@@ -36,6 +36,7 @@ struct ZabBatch {
   const void* gmem;                            // ZaGmemView* (device) or null
   const void* pool;                            // ZaPoolView* (device) or null
   double* fft;    int64_t fft_se, fft_si, fft_cap;   // FFT builtin scratch (null / 0 when unused)
+  uint32_t* gmem_att;                          // per-instance "gmem attached" flag [n_pad] (null when unused)
   uint64_t epoch;                              // bumped by the runtime whenever host calls may have changed state
 };
 
@@ -56,6 +57,7 @@ struct ZabModule {
   int64_t default_mem_cap;
   const char* const* var_names;      // [nvars], index order
   int64_t fft_scratch_doubles;       // per-instance scratch the runtime must provide (0: leaf has no FFT builtins)
+  int32_t uses_gmem;                 // runtime must provide a gmem segment; 2 = instances start attached (options:gmem=)
   // generic (translator-generated) kernels
   hipError_t (*launch_prepare)(const ZabBatch*, hipStream_t);
   hipError_t (*launch_process)(const ZabBatch*, const ZabAudio*, hipStream_t);

@@ -80,6 +80,8 @@ struct zab_engine {
   int launches = 0;
   bool used_fast = false;
   std::vector<void*> owned;
+  unsigned long long *gmem_cells = nullptr, *gmem_page_seq = nullptr, *gmem_global_seq = nullptr;
+  uint64_t gmem_cell_count = 0;
   float* stage_in = nullptr;
   float* stage_out = nullptr;
   int64_t stage_bytes = 0;
@@ -96,6 +98,24 @@ struct zab_engine {
     return ZAB_OK;
   }
 };
+
+// gmem segment of the engine (default size of the reference: 1 Mi cells, pages of 1024; src/DspJsfxGmem.h:17-18)
+struct ZabGmemView { unsigned long long *cells, *page_seq, *page_writer, *global_seq; uint64_t cell_count, page_count; };
+static int setup_gmem(zab_engine* e) {
+  const uint64_t cells = 1024ull * 1024ull, pages = cells / 1024ull;
+  ZabGmemView v{};
+  int rc;
+  if ((rc = e->alloc(&v.cells, cells)) || (rc = e->alloc(&v.page_seq, pages)) || (rc = e->alloc(&v.page_writer, pages)) ||
+      (rc = e->alloc(&v.global_seq, 1)) || (rc = e->alloc(&e->b.gmem_att, (size_t)e->b.n_pad)))
+    return rc;
+  v.cell_count = cells; v.page_count = pages;
+  ZabGmemView* dv = nullptr;
+  if ((rc = e->alloc(&dv, 1))) return rc;
+  if (hipMemcpyAsync(dv, &v, sizeof v, hipMemcpyHostToDevice, e->stream) != hipSuccess) return fail(ZAB_E_HIP, "gmem view upload failed");
+  e->b.gmem = dv;
+  e->gmem_cells = v.cells; e->gmem_page_seq = v.page_seq; e->gmem_global_seq = v.global_seq; e->gmem_cell_count = cells;
+  return ZAB_OK;
+}
 
 static hipError_t create_events(zab_engine* e) {
   for (int i = 0; i < zab_engine::kTimingSlots; ++i) {
@@ -185,7 +205,8 @@ int zab_create(const char* module, const zab_config* cfg, zab_engine** out) {
       (rc = e->alloc(&b.err, (size_t)P)) || (rc = e->alloc(&b.flags, (size_t)P)) ||
       (rc = e->alloc(&b.pend, (size_t)P * 3)) || (rc = e->alloc(&b.vis_mask, (size_t)P)) ||
       (rc = e->alloc(&b.vis_init, (size_t)P)) ||
-      (m->fft_scratch_doubles > 0 && (rc = e->alloc(&b.fft, (size_t)P * m->fft_scratch_doubles)))) {
+      (m->fft_scratch_doubles > 0 && (rc = e->alloc(&b.fft, (size_t)P * m->fft_scratch_doubles))) ||
+      (m->uses_gmem && (rc = setup_gmem(e)))) {
     zab_destroy(e);
     return rc;
   }
@@ -433,6 +454,34 @@ int zab_read_mem_high(zab_engine* e, int32_t first, int32_t count, int64_t* dst)
   if (!e || !dst || !range_ok(e, first, count)) return fail(ZAB_E_ARG, "zab_read_mem_high: bad argument");
   HIP_TRY(hipStreamSynchronize(e->stream));
   HIP_TRY(hipMemcpy(dst, e->b.mem_high + first, sizeof(int64_t) * count, hipMemcpyDeviceToHost));
+  return ZAB_OK;
+}
+
+int zab_gmem_read(zab_engine* e, int64_t start, int64_t n, double* dst) {
+  if (!e || !dst || start < 0 || n < 0) return fail(ZAB_E_ARG, "zab_gmem_read: bad argument");
+  if (!e->gmem_cells) return fail(ZAB_E_STATE, "zab_gmem_read: leaf %s has no gmem", e->mod->name);
+  if ((uint64_t)(start + n) > e->gmem_cell_count) return fail(ZAB_E_ARG, "zab_gmem_read: range beyond %llu cells", (unsigned long long)e->gmem_cell_count);
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  HIP_TRY(hipMemcpy(dst, e->gmem_cells + start, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+  return ZAB_OK;
+}
+int zab_gmem_write(zab_engine* e, int64_t start, int64_t n, const double* src) {
+  if (!e || !src || start < 0 || n < 0) return fail(ZAB_E_ARG, "zab_gmem_write: bad argument");
+  if (!e->gmem_cells) return fail(ZAB_E_STATE, "zab_gmem_write: leaf %s has no gmem", e->mod->name);
+  if ((uint64_t)(start + n) > e->gmem_cell_count) return fail(ZAB_E_ARG, "zab_gmem_write: range beyond %llu cells", (unsigned long long)e->gmem_cell_count);
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  HIP_TRY(hipMemcpy(e->gmem_cells + start, src, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+  return ZAB_OK;
+}
+int zab_gmem_seq(zab_engine* e, int64_t page, uint64_t* out) {
+  if (!e || !out) return fail(ZAB_E_ARG, "zab_gmem_seq: bad argument");
+  if (!e->gmem_cells) return fail(ZAB_E_STATE, "zab_gmem_seq: leaf %s has no gmem", e->mod->name);
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  const unsigned long long* src = page < 0 ? e->gmem_global_seq : e->gmem_page_seq + page;
+  if (page >= (int64_t)(e->gmem_cell_count / 1024)) return fail(ZAB_E_ARG, "zab_gmem_seq: page out of range");
+  unsigned long long v = 0;
+  HIP_TRY(hipMemcpy(&v, src, sizeof v, hipMemcpyDeviceToHost));
+  *out = v;
   return ZAB_OK;
 }
 

@@ -71,6 +71,7 @@ struct ZaState {
   uint64_t instance_id;
   double sink;
   double memtop;
+  uint32_t gmem_attached; // this instance has called gmem_attach() (or the leaf declares options:gmem=)
   double* fft;           // FFT builtin scratch (natural-order work area), element a at fft[a * fft_stride]
   int64_t fft_stride;
   int64_t fft_cap;       // doubles available (0 when the leaf has no FFT builtins)

@@ -45,7 +45,7 @@ ABI_SYMBOLS = [
     "zab_var_index", "zab_set_sliders", "zab_get_sliders", "zab_prepare", "zab_process", "zab_sync", "zab_read_vars",
     "zab_read_mem", "zab_write_mem", "zab_read_mem_high", "zab_device_alloc", "zab_device_free", "zab_device_upload",
     "zab_device_download", "zab_device_noise", "zab_last_timing", "zab_timing_history", "zab_stream",
-    "zab_used_fast_path",
+    "zab_used_fast_path", "zab_gmem_read", "zab_gmem_write", "zab_gmem_seq",
 ]
 
 _lib = None
@@ -90,6 +90,9 @@ def load_runtime():
     L.zab_timing_history.argtypes = [vp, C.POINTER(d), i32]
     L.zab_stream.restype = vp; L.zab_stream.argtypes = [vp]
     L.zab_used_fast_path.argtypes = [vp]
+    L.zab_gmem_read.argtypes = [vp, i64, i64, C.POINTER(d)]
+    L.zab_gmem_write.argtypes = [vp, i64, i64, C.POINTER(d)]
+    L.zab_gmem_seq.argtypes = [vp, i64, C.POINTER(C.c_uint64)]
     _lib = L
     return L
 
@@ -259,6 +262,20 @@ class Engine:
         if v.ndim == 1:
             v = v[None, :]
         self._chk(self.L.zab_write_mem(self.h, int(first), v.shape[0], int(start), v.shape[1], _dp(v)))
+
+    def gmem_read(self, start: int, n: int) -> np.ndarray:
+        out = np.zeros(n)
+        self._chk(self.L.zab_gmem_read(self.h, int(start), int(n), _dp(out)))
+        return out
+
+    def gmem_write(self, start: int, values):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        self._chk(self.L.zab_gmem_write(self.h, int(start), len(v), _dp(v)))
+
+    def gmem_seq(self, page: int = -1) -> int:
+        out = C.c_uint64(0)
+        self._chk(self.L.zab_gmem_seq(self.h, int(page), C.byref(out)))
+        return int(out.value)
 
     def mem_high(self, first=0, count=None) -> np.ndarray:
         cnt = self.n - first if count is None else count
