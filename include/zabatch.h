@@ -124,6 +124,16 @@ int zab_gmem_read(zab_engine* e, int64_t start, int64_t n, double* dst);
 int zab_gmem_write(zab_engine* e, int64_t start, int64_t n, const double* src);
 int zab_gmem_seq(zab_engine* e, int64_t page, uint64_t* out);
 
+/* Sample pool (leaves that call sample_read* / sample_export_mem): one immutable generation per upload, entries are
+ * 1-based sample ids in array order (DspJsfxSamplePoolEntry / Generation, src/DspJsfxSamplePool.h:55-79). audio is the
+ * packed float32 arena, each entry interleaved by channel starting at offset_items. Decode/resample is host work. */
+typedef struct zab_pool_entry {
+  int64_t offset_items;
+  int32_t frames, sample_rate, channels;
+  float peak, rms;
+} zab_pool_entry;
+int zab_pool_upload(zab_engine* e, int32_t n_entries, const zab_pool_entry* entries, const float* audio, int64_t audio_items);
+
 /* Device buffer helpers so hosts without a HIP binding (ctypes, cgo, JNI) can keep audio HBM-resident. */
 int zab_device_alloc(zab_engine* e, int64_t bytes, void** out);
 int zab_device_free(zab_engine* e, void* p);

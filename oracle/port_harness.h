@@ -24,6 +24,11 @@ struct ZaPort {
   unsigned long long gseq = 0;
   ZaGmemView gview;
 #endif
+#ifdef ZA_POOL_H_INCLUDED
+  std::vector<float> paudio;
+  std::vector<ZaPoolEntry> pent;
+  ZaPoolView pview;
+#endif
   int alias[64];
 };
 
@@ -120,6 +125,18 @@ int64_t port_mem_write(ZaPort* p, int64_t start, int64_t n, const double* src) {
 void port_gmem_read(ZaPort* p, int64_t start, int64_t n, double* dst) { memcpy(dst, p->gcells.data() + start, sizeof(double) * (size_t)n); }
 void port_gmem_write(ZaPort* p, int64_t start, int64_t n, const double* src) { memcpy(p->gcells.data() + start, src, sizeof(double) * (size_t)n); }
 uint64_t port_gmem_seq(ZaPort* p, int64_t page) { return page < 0 ? p->gseq : p->gpseq[(size_t)page]; }
+#endif
+#ifdef ZA_POOL_H_INCLUDED
+// entries: n x {offset_items, frames, sample_rate, channels} as int64, peaks/rms as float pairs
+void port_pool_upload(ZaPort* p, int n, const int64_t* ent4, const float* peak_rms, const float* audio, int64_t items) {
+  p->paudio.assign(audio, audio + items);
+  p->pent.resize((size_t)n);
+  for (int i = 0; i < n; ++i)
+    p->pent[(size_t)i] = ZaPoolEntry{(uint64_t)ent4[4 * i], (uint32_t)ent4[4 * i + 1], (uint32_t)ent4[4 * i + 2], (uint32_t)ent4[4 * i + 3],
+                                     peak_rms[2 * i], peak_rms[2 * i + 1], 0};
+  p->pview = ZaPoolView{p->paudio.data(), (uint64_t)items, p->pent.data(), (uint32_t)n, 1};
+  p->s.pool = &p->pview;
+}
 #endif
 int64_t port_mem_high(ZaPort* p) { return p->s.mem_high; }
 int64_t port_mem_need(ZaPort* p) { return p->s.mem_need; }

@@ -6,7 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define ZAB_MODULE_ABI 6
+#define ZAB_MODULE_ABI 7
 
 enum { ZAB_FLAG_SLIDER_DIRTY = 1u, ZAB_FLAG_PREPARED = 2u };
 
@@ -58,6 +58,7 @@ struct ZabModule {
   const char* const* var_names;      // [nvars], index order
   int64_t fft_scratch_doubles;       // per-instance scratch the runtime must provide (0: leaf has no FFT builtins)
   int32_t uses_gmem;                 // runtime must provide a gmem segment; 2 = instances start attached (options:gmem=)
+  int32_t uses_pool;                 // leaf reads the sample pool (zab_pool_upload provides it)
   // generic (translator-generated) kernels
   hipError_t (*launch_prepare)(const ZabBatch*, hipStream_t);
   hipError_t (*launch_process)(const ZabBatch*, const ZabAudio*, hipStream_t);

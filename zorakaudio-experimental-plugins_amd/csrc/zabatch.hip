@@ -82,6 +82,7 @@ struct zab_engine {
   std::vector<void*> owned;
   unsigned long long *gmem_cells = nullptr, *gmem_page_seq = nullptr, *gmem_global_seq = nullptr;
   uint64_t gmem_cell_count = 0;
+  uint32_t pool_generation = 0;
   float* stage_in = nullptr;
   float* stage_out = nullptr;
   int64_t stage_bytes = 0;
@@ -482,6 +483,36 @@ int zab_gmem_seq(zab_engine* e, int64_t page, uint64_t* out) {
   unsigned long long v = 0;
   HIP_TRY(hipMemcpy(&v, src, sizeof v, hipMemcpyDeviceToHost));
   *out = v;
+  return ZAB_OK;
+}
+
+// sample pool: entries + packed float32 arena, uploaded once, read-only on the device (src/DspJsfxSamplePool.h:55-79)
+struct ZabPoolEntryDev { uint64_t offset_items; uint32_t frames, sample_rate, channels; float peak, rms; uint32_t pad; };
+struct ZabPoolViewDev { const float* audio; uint64_t audio_items; const ZabPoolEntryDev* entries; uint32_t n_entries, generation; };
+int zab_pool_upload(zab_engine* e, int32_t n_entries, const zab_pool_entry* entries, const float* audio, int64_t audio_items) {
+  if (!e || n_entries < 0 || audio_items < 0 || (n_entries && !entries) || (audio_items && !audio))
+    return fail(ZAB_E_ARG, "zab_pool_upload: bad argument");
+  if (!e->mod->uses_pool) return fail(ZAB_E_STATE, "zab_pool_upload: leaf %s does not read the sample pool", e->mod->name);
+  std::vector<ZabPoolEntryDev> dev((size_t)n_entries);
+  for (int i = 0; i < n_entries; ++i) {
+    const zab_pool_entry& s = entries[i];
+    if (s.channels <= 0 || s.frames < 0 || s.offset_items < 0 || s.offset_items + (int64_t)s.frames * s.channels > audio_items)
+      return fail(ZAB_E_ARG, "zab_pool_upload: entry %d lies outside the arena", i);
+    dev[(size_t)i] = ZabPoolEntryDev{(uint64_t)s.offset_items, (uint32_t)s.frames, (uint32_t)s.sample_rate, (uint32_t)s.channels, s.peak, s.rms, 0};
+  }
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  float* d_audio = nullptr; ZabPoolEntryDev* d_ent = nullptr; ZabPoolViewDev* d_view = nullptr;
+  int rc;
+  if ((rc = e->alloc(&d_audio, (size_t)(audio_items ? audio_items : 1))) || (rc = e->alloc(&d_ent, (size_t)(n_entries ? n_entries : 1))) ||
+      (rc = e->alloc(&d_view, 1)))
+    return rc;
+  if (audio_items) HIP_TRY(hipMemcpyAsync(d_audio, audio, sizeof(float) * (size_t)audio_items, hipMemcpyHostToDevice, e->stream));
+  if (n_entries) HIP_TRY(hipMemcpyAsync(d_ent, dev.data(), sizeof(ZabPoolEntryDev) * dev.size(), hipMemcpyHostToDevice, e->stream));
+  ZabPoolViewDev v{d_audio, (uint64_t)audio_items, d_ent, (uint32_t)n_entries, ++e->pool_generation};
+  HIP_TRY(hipMemcpyAsync(d_view, &v, sizeof v, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->b.pool = d_view;          // earlier generations stay allocated until zab_destroy (readers may still hold them)
+  e->b.epoch++;
   return ZAB_OK;
 }
 

@@ -32,6 +32,11 @@ class zab_config(C.Structure):
                 ("path", C.c_int32), ("mem_cap", C.c_int64), ("first_instance_id", C.c_uint64)]
 
 
+class zab_pool_entry(C.Structure):
+    _fields_ = [("offset_items", C.c_int64), ("frames", C.c_int32), ("sample_rate", C.c_int32), ("channels", C.c_int32),
+                ("peak", C.c_float), ("rms", C.c_float)]
+
+
 class zab_info(C.Structure):
     _fields_ = [("name", C.c_char * 64), ("nvars", C.c_int32), ("n_channels", C.c_int32), ("n_inputs", C.c_int32),
                 ("n_outputs", C.c_int32), ("has_init", C.c_int32), ("has_slider", C.c_int32), ("has_block", C.c_int32),
@@ -45,7 +50,7 @@ ABI_SYMBOLS = [
     "zab_var_index", "zab_set_sliders", "zab_get_sliders", "zab_prepare", "zab_process", "zab_sync", "zab_read_vars",
     "zab_read_mem", "zab_write_mem", "zab_read_mem_high", "zab_device_alloc", "zab_device_free", "zab_device_upload",
     "zab_device_download", "zab_device_noise", "zab_last_timing", "zab_timing_history", "zab_stream",
-    "zab_used_fast_path", "zab_gmem_read", "zab_gmem_write", "zab_gmem_seq",
+    "zab_used_fast_path", "zab_gmem_read", "zab_gmem_write", "zab_gmem_seq", "zab_pool_upload",
 ]
 
 _lib = None
@@ -93,6 +98,7 @@ def load_runtime():
     L.zab_gmem_read.argtypes = [vp, i64, i64, C.POINTER(d)]
     L.zab_gmem_write.argtypes = [vp, i64, i64, C.POINTER(d)]
     L.zab_gmem_seq.argtypes = [vp, i64, C.POINTER(C.c_uint64)]
+    L.zab_pool_upload.argtypes = [vp, i32, C.POINTER(zab_pool_entry), C.POINTER(C.c_float), i64]
     _lib = L
     return L
 
@@ -276,6 +282,23 @@ class Engine:
         out = C.c_uint64(0)
         self._chk(self.L.zab_gmem_seq(self.h, int(page), C.byref(out)))
         return int(out.value)
+
+    def pool_upload(self, samples, sample_rates=None):
+        """samples: list of float32 arrays [frames, channels] (or [frames]); packs them like a pool generation."""
+        ents, chunks, off = [], [], 0
+        for k, a in enumerate(samples):
+            a = np.asarray(a, dtype=np.float32)
+            if a.ndim == 1:
+                a = a[:, None]
+            sr = int(sample_rates[k]) if sample_rates is not None else int(self.srate)
+            peak = float(np.abs(a).max()) if a.size else 0.0
+            rms = float(np.sqrt(np.mean(a.astype(np.float64) ** 2))) if a.size else 0.0
+            ents.append(zab_pool_entry(off, a.shape[0], sr, a.shape[1], peak, rms))
+            chunks.append(np.ascontiguousarray(a).reshape(-1))
+            off += a.size
+        audio = np.concatenate(chunks) if chunks else np.zeros(0, np.float32)
+        arr = (zab_pool_entry * max(1, len(ents)))(*ents)
+        self._chk(self.L.zab_pool_upload(self.h, len(ents), arr, audio.ctypes.data_as(C.POINTER(C.c_float)), audio.size))
 
     def mem_high(self, first=0, count=None) -> np.ndarray:
         cnt = self.n - first if count is None else count

@@ -33,11 +33,11 @@ HOST_ONLY = {"instance_uid", "instance_set_name", "instance_get_name", "track_na
              "msg_peer_caps", "msg_peer_alive", "midirecv", "midirecv_buf", "midirecv_str", "midisend",
              "midisend_buf", "midisend_str", "midisyx", "file_open", "file_open_multi", "file_close", "file_rewind",
              "file_seek", "file_avail", "file_text", "file_mem", "file_multi_count", "file_multi_select", "file_var",
-             "file_riff", "sample_pool_from_slot", "sample_pool_set_mode", "sample_pool_set_budget_mb",
-             "sample_pool_commit", "sample_name", "sample_preview_read", "sample_preview_bins"}
+             "file_riff", "sample_name", "sample_preview_read", "sample_preview_bins"}
 GMEM_CALLS = {"gmem_attach", "gmem_attach_size", "gmem_size", "gmem_get", "gmem_put", "gmem_fill", "gmem_zero",
               "gmem_copy", "gmem_seq", "gmem_page"}
-POOL_READ_CALLS = {"sample_pool_state", "sample_pool_selected", "sample_pool_loaded", "sample_pool_failed",
+POOL_READ_CALLS = {"sample_pool_from_slot", "sample_pool_set_mode", "sample_pool_set_budget_mb", "sample_pool_commit",
+                   "sample_pool_state", "sample_pool_selected", "sample_pool_loaded", "sample_pool_failed",
                    "sample_pool_ram_mb", "sample_pool_generation", "sample_get", "sample_len", "sample_channels",
                    "sample_srate", "sample_peak", "sample_rms", "sample_read", "sample_read_interp", "sample_read2",
                    "sample_read2_interp", "sample_export_mem", "sample_export_mem2"}
