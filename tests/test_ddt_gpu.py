@@ -11,6 +11,23 @@ from conftest import AUDIO_EPS, SCALAR_EPS, assert_state_close, dbfs, golden_inp
 pytestmark = pytest.mark.gpu
 
 DDT_CASES = ["DDT_default", "DDT_far_extreme", "DDT_near_eco_direct", "DDT_diffuse_ragged"]
+# the fast kernel runs NW wavefronts per instance (picked from the batch size); ZAB_DDT_NW pins it so every variant is covered
+FAST_VARIANTS = ["fast1", "fast2", "fast4", "fast8"]
+
+
+@pytest.fixture(autouse=True)
+def _unpin_nw(monkeypatch):
+    monkeypatch.delenv("ZAB_DDT_NW", raising=False)
+
+
+def _paths(zabatch, monkeypatch):
+    """(name, path) pairs; selecting one pins the wave count through the environment."""
+    def select(name):
+        if name.startswith("fast"):
+            monkeypatch.setenv("ZAB_DDT_NW", name[4:])
+            return zabatch.ZAB_PATH_FAST
+        return zabatch.ZAB_PATH_GENERIC
+    return select
 
 
 def _run(zabatch, path, g, n=3):
@@ -26,13 +43,13 @@ def _run(zabatch, path, g, n=3):
 
 
 @pytest.mark.parametrize("case", DDT_CASES)
-@pytest.mark.parametrize("path_name", ["generic", "fast"])
-def test_ddt_matches_reference_vm(case, path_name):
+@pytest.mark.parametrize("path_name", ["generic"] + FAST_VARIANTS)
+def test_ddt_matches_reference_vm(case, path_name, monkeypatch):
     import zabatch
     g = load_golden(case)
-    path = zabatch.ZAB_PATH_GENERIC if path_name == "generic" else zabatch.ZAB_PATH_FAST
+    path = _paths(zabatch, monkeypatch)(path_name)
     y, prepared, vars_, mem, high, names, fast = _run(zabatch, path, g)
-    assert fast == (path_name == "fast")
+    assert fast == path_name.startswith("fast")
     assert names == [str(s) for s in g["var_names"]]
     # state after prepareToPlay (@init + @slider on the device)
     for i in range(y.shape[0]):
@@ -52,13 +69,14 @@ def test_ddt_matches_reference_vm(case, path_name):
     assert (high >= int(g["mem_high"])).all()
 
 
-def test_fast_equals_generic_on_distinct_instances():
-    """Distinct noise + distinct slider sets per instance; ragged frame count; both device paths vs the CPU port."""
+@pytest.mark.parametrize("frames", [1237, 100, 257, 2048])
+def test_fast_equals_generic_on_distinct_instances(frames, monkeypatch):
+    """Distinct noise + distinct slider sets per instance; ragged / tiny / aligned frame counts; every device path vs the CPU port."""
     import zabatch
     from oracle import port
     from zajit import noise
     meta = zabatch.leaf_meta("DDT")
-    n, frames, block = 6, 1237, 300
+    n, block = 6, 300
     x = noise.white_noise(range(100, 100 + n), frames)
     rows = np.tile(np.array(meta["default_sliders"]), (n, 1))
     rows[:, 0] = [0, 15, 45, 70, 100, 30]
@@ -66,7 +84,8 @@ def test_fast_equals_generic_on_distinct_instances():
     rows[:, 7] = [0, 1, 2, 3, 0, 0]
     rows[:, 8] = [5, 25, 50, 75, 100, 50]
     res = {}
-    for name, path in (("generic", zabatch.ZAB_PATH_GENERIC), ("fast", zabatch.ZAB_PATH_FAST)):
+    for name in ["generic"] + FAST_VARIANTS:
+        path = _paths(zabatch, monkeypatch)(name)
         with zabatch.Engine("DDT", n, path=path) as e:
             e.set_sliders(rows)
             e.prepare()
@@ -86,7 +105,7 @@ def test_fast_equals_generic_on_distinct_instances():
     assert np.array_equal(res["generic"][0], res["generic"][0])
 
 
-def test_multi_call_continuity_and_slider_change():
+def test_multi_call_continuity_and_slider_change(monkeypatch):
     """Three zab_process calls with a slider move in between == one reference run with the same schedule."""
     import zabatch
     from oracle import port
@@ -95,7 +114,8 @@ def test_multi_call_continuity_and_slider_change():
     n = 2
     x = noise.white_noise([7, 8], 3 * 700)
     row2 = np.array(meta["default_sliders"]); row2[0] = 62.0; row2[8] = 80.0
-    for path in (zabatch.ZAB_PATH_GENERIC, zabatch.ZAB_PATH_FAST):
+    for name in ["generic"] + FAST_VARIANTS:
+        path = _paths(zabatch, monkeypatch)(name)
         with zabatch.Engine("DDT", n, path=path) as e:
             e.set_sliders(meta["default_sliders"]); e.prepare()
             ys = [e.process_host(x[:, :, 0:700], block=512)]

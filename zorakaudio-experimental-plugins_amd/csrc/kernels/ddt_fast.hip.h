@@ -4,25 +4,26 @@
 // run per frame by jsfx_process_block, dsp_jsfx_aot.py:5713-5905); HOW it computes it is MI355X-first:
 //
 //   * DDT's per-frame work is feed-forward in the INPUT history (sparse taps into the bL/bR delay rings) followed
-//     by LINEAR constant-coefficient one-poles (dirZ*, eZ*, lZ*, and the seven UI meters). So time is data-parallel:
-//     ONE WAVEFRONT PER INSTANCE, each lane owns KF=4 consecutive frames of a 256-frame chunk.
-//   * The mono delay history M[n] = 0.5*(L[n]+R[n]) (the only thing the taps read: :467-468) lives in an LDS ring of
-//     W doubles, de-interleaved by 4: frame n sits in plane (n&3) at position (n>>2) mod W/4. A lane's 4 stores go to
-//     4 planes at one position; a tap gather `frame - delay` of the whole wave reads 64 consecutive doubles of one
-//     plane (conflict-free for every delay), and because frame = 4*lane + uniform, plane and position offset are
-//     wave-uniform: the address math is scalar except one add and one mask per gather.
-//   * Tap parameters (delays, gains) are wave-uniform: staged once in LDS as two lists -- early taps, late taps, each
-//     in source order -- and read as broadcasts. Each list feeds its own pair of accumulators with separate multiply
-//     and add (no FMA contraction) in source order, so sumE*/sumL* are bit-identical to the serial reference.
+//     by LINEAR constant-coefficient one-poles (dirZ*, eZ*, lZ*, and the seven UI meters). So time is data-parallel.
+//     One WORKGROUP PER INSTANCE made of NW wavefronts (NW = 1, 2, 4 or 8, chosen so that the batch fills the chip);
+//     each wavefront takes one 256-frame chunk per iteration, each lane 4 consecutive frames of it.
+//   * The mono delay history M[n] = 0.5*(L[n]+R[n]) (the only thing the taps read: :467-468) lives in one LDS ring
+//     shared by the workgroup (plain circular layout plus a 256-slot mirror of its head behind its tail).
+//   * Tap phase: lane l takes frames {l, 64+l, 128+l, 192+l} of its chunk, so the gather `frame - delay` of a wave reads
+//     64 consecutive ring slots per k (conflict-free for every delay) and the four k differ by a constant 512 bytes:
+//     one masked address per (tap, channel), the rest are ds_read immediates. Tap parameters are wave-uniform LDS
+//     broadcasts, staged as two lists (early taps, late taps, each in source order). The four sums then move to the
+//     "4 consecutive frames per lane" layout through a per-wave LDS transpose.
 //   * The six filter recurrences y[n] = (1-a) x[n] + a y[n-1]: 4 serial steps inside the lane, a weighted 64-lane scan
 //     of the lane aggregates with coefficient a^4 done with DPP (row_shr 1/2/4/8, row_bcast15, row_bcast31 -- no LDS
-//     crossbar traffic, no lane masks), then a 4-step fix-up. Lane 0 of a full chunk reproduces the serial rounding
-//     exactly; other lanes differ by O(1e-16) relative.
+//     crossbar traffic, no lane masks), a chunk-to-chunk carry chain across the NW waves through 6 doubles of LDS per
+//     wave, then a 4-step fix-up. Wave 0 injects the running state at its first frame, so lane 0 of its chunk
+//     reproduces the serial rounding exactly; everything else differs by O(1e-16) relative (FMA, re-association).
 //   * The seven meter one-poles are only observable as state after the launch, so they are carried as per-lane
-//     weighted partial sums and reduced across the wave once, at the end.
+//     weighted partial sums and reduced once, at the end.
 //   * HBM traffic per frame: 8 B in + 8 B out (float4 per lane per channel, 1 KiB per wave instruction); the f64
 //     rings in mem[] are written only for the last 16384 frames of a launch (older slots would be overwritten).
-//     vars[] / tap tables are touched once per launch.
+//     vars[] / tap tables are touched once per launch. Measured with FETCH_SIZE/WRITE_SIZE: 1.0002x these bytes.
 //
 // State contract: on exit vars[] and mem[] hold what the serial path would hold (all @sample temporaries of the last
 // frame included), within the scan's rounding for the filter states -- tests/test_ddt_gpu.py compares both paths.
@@ -30,27 +31,25 @@
 
 #include <map>
 #include <mutex>
+#include <type_traits>
 
-#define ZA_FAST_KERNEL_NAME "zab_ddt_fast"
+#define ZA_FAST_KERNEL_NAME "zab_ddt_fast"   /* + _nw2 / _nw4 / _nw8: waves per instance */
 #define DDT_KF 4                       /* frames per lane */
 #define DDT_CHUNK (64 * DDT_KF)        /* frames per wave iteration */
 #define DDT_MAXTAPS 64
 #define DDT_RING 16384                 /* BUF_LEN of the script */
+#define DDT_MAXNW 8
 
-struct DdtTap { int32_t dL8, dR8; double gL, gR; };          // 8*delay (bytes) and gains; read as wave-uniform broadcasts
+struct DdtTap { int32_t dL8, dR8; double gL, gR; };          // 8*delay (bytes) and gains of one tap (wave-uniform when used)
+struct DdtTapRegs { int dpack; double gL, gR; };             // lane j of every wave keeps staged tap j: dL | dR << 16, gains
 struct DdtPole {
   double a, c1;        // pole and (1 - pole)
   double ap[4];        // a^1..a^4
   double sp[4];        // (a^4)^(2^j), j = 0..3 : in-row scan step coefficients
+  double a256;         // a^256: decay of a state across one chunk
 };
 
 // ---- wave-level helpers ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double ddt_uniform(double v) {
-  int2 t = __builtin_bit_cast(int2, v);
-  t.x = __builtin_amdgcn_readfirstlane(t.x);
-  t.y = __builtin_amdgcn_readfirstlane(t.y);
-  return __builtin_bit_cast(double, t);
-}
 __device__ __forceinline__ double ddt_readlane(double v, int l) {
   int2 t = __builtin_bit_cast(int2, v);
   t.x = __builtin_amdgcn_readlane(t.x, l);
@@ -71,7 +70,7 @@ __device__ __forceinline__ double ddt_dpp(double v) {
 #define DDT_ROW_BCAST31 0x143
 
 __device__ __forceinline__ double ddt_clamp(double x, double a, double b) { return x < a ? a : (x > b ? b : x); }
-__device__ __forceinline__ double ddt_ipow(double base, int e) {   // base^e, e >= 0, square-and-multiply
+__device__ __forceinline__ double ddt_ipow(double base, int64_t e) {   // base^e, e >= 0, square-and-multiply
   double r = 1.0;
   while (e) { if (e & 1) r *= base; base *= base; e >>= 1; }
   return r;
@@ -89,93 +88,81 @@ __device__ __forceinline__ double ddt_scan(double g, const DdtPole& p, double cb
   return g;
 }
 
-// One recurrence over the chunk. x[k]: inputs in, outputs out. carry: wave-uniform y before the chunk's first valid
-// frame in, y at the chunk's last frame out. PARTIAL chunks (only the first of a launch) mask the leading slots.
+// In-lane part of one recurrence: x[k] <- response of the lane's 4 frames to their own inputs (plus `inject`, the state
+// before the chunk, at the chunk's first valid frame when this wave owns the head of the chain). Returns the inclusive
+// scan G of the lane aggregates (y at the end of each lane, given zero state before the chunk apart from `inject`).
 template <bool PARTIAL>
-__device__ __forceinline__ void ddt_pole_run(const DdtPole& p, double cb1, double cb2, double (&x)[DDT_KF], double& carry,
-                                             int lane, int first_lane, int first_k) {
+__device__ __forceinline__ double ddt_pole_local(const DdtPole& p, double cb1, double cb2, double (&x)[DDT_KF], double inject,
+                                                 bool head, int lane, int first_lane, int first_k) {
   double z = 0.0;
 #pragma unroll
   for (int k = 0; k < DDT_KF; ++k) {
     double prev = z;
     if (PARTIAL) {
-      if (lane == first_lane && k == first_k) prev = carry;
+      if (head && lane == first_lane && k == first_k) prev = inject;
     } else {
-      if (k == 0 && lane == 0) prev = carry;
+      if (head && k == 0 && lane == 0) prev = inject;
     }
-    z = __builtin_fma(p.a, prev, p.c1 * x[k]);           // (1-a)*x + a*prev, one rounding fewer than the script
+    z = __builtin_fma(p.a, prev, p.c1 * x[k]);           // (1-a)*x + a*prev
     if (PARTIAL) {
       const bool valid = (lane > first_lane) || (lane == first_lane && k >= first_k);
       z = valid ? z : 0.0;
     }
     x[k] = z;
   }
-  const double g = ddt_scan(z, p, cb1, cb2);
-  const double cin = ddt_dpp<DDT_WAVE_SHR1, 0xF>(g);      // y at the end of the previous lane (0 for lane 0)
-#pragma unroll
-  for (int k = 0; k < DDT_KF; ++k) x[k] = __builtin_fma(p.ap[k], cin, x[k]);
-  carry = ddt_readlane(g, 63);
+  return ddt_scan(z, p, cb1, cb2);
 }
 
 struct DdtCtx {
-  // wave-uniform launch constants
+  // workgroup-uniform launch constants
   const float *in0, *in1;
   float *out0, *out1;
   double* Mem;
   double* ring;
-  const DdtTap* taps;
   const DdtPole* P;
+  double* T;           // this wave's [4][DDT_CHUNK] transpose area
   int64_t frames, wofs0, rL, rR;
-  double* T;           // [4][DDT_CHUNK] transpose area: tap sums go strided -> blocked through here
+  double* V;           // vars[] of the instance: the last frame's @sample temporaries are stored as they are produced
+  double* SPL;
   int bufmask, W, m8, nE, nT, mon;
   double col, one_m_col, directGain, wetp, dryp, out_gain;
   bool vec_ok;
 };
 
-struct DdtLast {   // @sample temporaries of the launch's final frame (lane 63, k = 3)
-  double mono, srcL, srcR, dInL, dInR, sEL, sER, sLL, sLR, yL, yR, oL, oR, sdir, sear, slat, stot, dL, dR, c, spl0, spl1;
+struct DdtChunk {  // per-lane registers that live across the two workgroup barriers of an iteration
+  float x0[DDT_KF], x1[DDT_KF];   // the chunk's input frames as read (f32 -> f64 is exact, so convert at each use)
+  double y[6][DDT_KF];
+  double G[6];
 };
 
-// Tap phase mapping: lane l handles frames {l, 64+l, 128+l, 192+l} of the chunk ("strided"), so a gather of
-// frame - delay reads 64 consecutive ring slots per k and the four k differ by a constant 512 bytes: one masked
-// address per (tap, channel), the rest are ds_read_b64 immediates. The ring keeps a 256-slot mirror of its head
-// behind its tail so those +512k offsets never need a wrap.
+// Phase A: read the chunk's audio, publish M to the shared ring (and the f64 L/R rings of mem[] when they survive).
 template <bool PARTIAL>
-__device__ __forceinline__ void ddt_chunk(const DdtCtx& C, int lane, int64_t f0, double (&carry)[6], const double (&cb1)[3],
-                                          const double (&cb2)[3], double (&accM)[6], double& accC, double dM, double dC,
-                                          double wM, double wC, const double (&cwM)[DDT_KF], const double (&cwC)[DDT_KF],
-                                          bool want_last, DdtLast& last) {
+__device__ __forceinline__ void ddt_phase_a(const DdtCtx& C, DdtChunk& K, int lane, int64_t f0, const float4& p0, const float4& p1) {
   const int64_t t0 = f0 + DDT_KF * lane;
-  int first_lane = 0, first_k = 0;
-  if (PARTIAL) {
-    const int firstv = (int)(-f0);
-    first_lane = firstv / DDT_KF;
-    first_k = firstv % DDT_KF;
-  }
-  double x0[DDT_KF], x1[DDT_KF], M[DDT_KF];
-  if (C.vec_ok && (!PARTIAL || t0 >= 0)) {
+  if (!PARTIAL && C.vec_ok) {                              // prefetched one iteration ahead (ddt_prefetch)
+    K.x0[0] = p0.x; K.x0[1] = p0.y; K.x0[2] = p0.z; K.x0[3] = p0.w;
+    K.x1[0] = p1.x; K.x1[1] = p1.y; K.x1[2] = p1.z; K.x1[3] = p1.w;
+  } else if (C.vec_ok && t0 >= 0) {
     const float4 v0 = *reinterpret_cast<const float4*>(C.in0 + t0);
     const float4 v1 = *reinterpret_cast<const float4*>(C.in1 + t0);
-    x0[0] = v0.x; x0[1] = v0.y; x0[2] = v0.z; x0[3] = v0.w;
-    x1[0] = v1.x; x1[1] = v1.y; x1[2] = v1.z; x1[3] = v1.w;
+    K.x0[0] = v0.x; K.x0[1] = v0.y; K.x0[2] = v0.z; K.x0[3] = v0.w;
+    K.x1[0] = v1.x; K.x1[1] = v1.y; K.x1[2] = v1.z; K.x1[3] = v1.w;
   } else {
 #pragma unroll
     for (int k = 0; k < DDT_KF; ++k) {
       const bool ok = t0 + k >= 0;
-      x0[k] = ok ? (double)C.in0[t0 + k] : 0.0;
-      x1[k] = ok ? (double)C.in1[t0 + k] : 0.0;
+      K.x0[k] = ok ? C.in0[t0 + k] : 0.0f;
+      K.x1[k] = ok ? C.in1[t0 + k] : 0.0f;
     }
   }
-  // ring stores (plain circular layout + mirror of the first 256 slots behind slot W)
   const int nb = (int)((C.wofs0 + f0) & 0x3fffffff);      // uniform; W divides 2^30 so low bits suffice
-  __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int k = 0; k < DDT_KF; ++k) {
-    M[k] = 0.5 * (x0[k] + x1[k]);                         // mono (:445) == ring value 0.5*(L+R) (:467)
+    const double M = 0.5 * ((double)K.x0[k] + (double)K.x1[k]);   // mono (:445) == ring value 0.5*(L+R) (:467)
     if (!PARTIAL || t0 + k >= 0) {
       const int slot = (nb + DDT_KF * lane + k) & (C.W - 1);
-      C.ring[slot] = M[k];
-      if (slot < DDT_CHUNK) C.ring[C.W + slot] = M[k];
+      C.ring[slot] = M;
+      if (slot < DDT_CHUNK) C.ring[C.W + slot] = M;
     }
   }
   if (f0 + DDT_CHUNK > C.frames - DDT_RING) {             // :441-442, only slots that survive the launch
@@ -184,89 +171,152 @@ __device__ __forceinline__ void ddt_chunk(const DdtCtx& C, int lane, int64_t f0,
       const int64_t t = t0 + k;
       if (t >= 0 && t >= C.frames - DDT_RING) {
         const int64_t ri = (C.wofs0 + t) & C.bufmask;
-        C.Mem[C.rL + ri] = x0[k];
-        C.Mem[C.rR + ri] = x1[k];
+        C.Mem[C.rL + ri] = (double)K.x0[k];
+        C.Mem[C.rR + ri] = (double)K.x1[k];
       }
     }
   }
-  __builtin_amdgcn_wave_barrier();
+}
 
-  // ---- tap loops (:459-484), strided lanes: each accumulator sees its taps in source order, multiply then add ----
-  double y[6][DDT_KF];
+// Tap sums over taps [i0, i1) of the staged list. Tap j's parameters live in lane j's registers and are broadcast with
+// v_readlane (no memory latency); the eight ring reads of a tap are issued one tap ahead of their FMAs, so the LDS latency is
+// paid once per run instead of once per tap.
+__device__ __forceinline__ DdtTap ddt_tap_get(const DdtTapRegs& R, int i) {
+  DdtTap t;
+  const int pk = __builtin_amdgcn_readlane(R.dpack, i);
+  t.dL8 = (pk & 0xffff) << 3;
+  t.dR8 = (int)((unsigned)pk >> 16) << 3;
+  t.gL = ddt_readlane(R.gL, i);
+  t.gR = ddt_readlane(R.gR, i);
+  return t;
+}
+__device__ __forceinline__ void ddt_tap_fetch(const char* ringb, int lane8nb, int m8, const DdtTap& tp, double (&l)[DDT_KF],
+                                              double (&r)[DDT_KF]) {
+  const char* pl = ringb + ((lane8nb - tp.dL8) & m8);
+  const char* pr = ringb + ((lane8nb - tp.dR8) & m8);
+#pragma unroll
+  for (int k = 0; k < DDT_KF; ++k) {
+    l[k] = *reinterpret_cast<const double*>(pl + 512 * k);
+    r[k] = *reinterpret_cast<const double*>(pr + 512 * k);
+  }
+}
+__device__ __forceinline__ void ddt_tap_acc(const DdtTap& tp, const double (&l)[DDT_KF], const double (&r)[DDT_KF],
+                                            double (&acc)[2][DDT_KF]) {
+#pragma unroll
+  for (int k = 0; k < DDT_KF; ++k) {
+    acc[0][k] = __builtin_fma(tp.gL, l[k], acc[0][k]);
+    acc[1][k] = __builtin_fma(tp.gR, r[k], acc[1][k]);
+  }
+}
+__device__ __forceinline__ void ddt_tap_run(const DdtCtx& C, const DdtTapRegs& R, const char* ringb, int lane8nb, int i0, int i1,
+                                            double (&acc)[2][DDT_KF]) {
+  if (i0 >= i1) return;
+  const int last = i1 - 1;
+  double al[DDT_KF], ar[DDT_KF], bl[DDT_KF], br[DDT_KF];
+  DdtTap ta = ddt_tap_get(R, i0), tb;
+  ddt_tap_fetch(ringb, lane8nb, C.m8, ta, al, ar);
+  int i = i0;
+  for (; i + 1 < i1; i += 2) {                             // pairs; the fetch past the end re-reads the last tap
+    tb = ddt_tap_get(R, i + 1);
+    ddt_tap_fetch(ringb, lane8nb, C.m8, tb, bl, br);
+    ddt_tap_acc(ta, al, ar, acc);
+    ta = ddt_tap_get(R, i + 2 < last ? i + 2 : last);
+    ddt_tap_fetch(ringb, lane8nb, C.m8, ta, al, ar);
+    ddt_tap_acc(tb, bl, br, acc);
+  }
+  if (i < i1) ddt_tap_acc(ta, al, ar, acc);                // odd count: the last tap is already in (ta, al, ar)
+}
+
+// Phase B: taps (:459-484), transpose, in-lane recurrences + scans. Leaves y (zero-state responses) and G in K.
+template <bool PARTIAL>
+__device__ __forceinline__ void ddt_phase_b(const DdtCtx& C, const DdtTapRegs& R, DdtChunk& K, int lane, int64_t f0, const double (&carry)[6], bool head,
+                                            const double (&cb1)[3], const double (&cb2)[3], bool want_last) {
+  int first_lane = 0, first_k = 0;
+  if (PARTIAL) {
+    const int firstv = (int)(-f0);
+    first_lane = firstv / DDT_KF;
+    first_k = firstv % DDT_KF;
+  }
+  const int nb = (int)((C.wofs0 + f0) & 0x3fffffff);
   {
     const char* ringb = reinterpret_cast<const char*>(C.ring);
     const int lane8nb = (8 * lane + 8 * nb) & C.m8;       // byte address of frame (nb + lane) in the ring
     double sE[2][DDT_KF], sL[2][DDT_KF];
 #pragma unroll
     for (int k = 0; k < DDT_KF; ++k) sE[0][k] = sE[1][k] = sL[0][k] = sL[1][k] = 0.0;
-#define DDT_TAP(acc)                                                                                   \
+    // strided -> blocked through the wave's own [2][256] LDS area: lane l wrote frames 64k+l, reads back frames 4l..4l+3
+    // (a wave's LDS accesses execute in order, so only the compiler needs the fence)
+#define DDT_TRANSPOSE(acc, dst)                                                                        \
     {                                                                                                  \
-      const DdtTap tp = C.taps[i];                                                                     \
-      const char* pl = ringb + ((lane8nb - tp.dL8) & C.m8);                                            \
-      const char* pr = ringb + ((lane8nb - tp.dR8) & C.m8);                                            \
       _Pragma("unroll") for (int k = 0; k < DDT_KF; ++k) {                                             \
-        acc[0][k] = __builtin_fma(tp.gL, *reinterpret_cast<const double*>(pl + 512 * k), acc[0][k]);   \
-        acc[1][k] = __builtin_fma(tp.gR, *reinterpret_cast<const double*>(pr + 512 * k), acc[1][k]);   \
+        C.T[64 * k + lane] = acc[0][k];                                                                \
+        C.T[DDT_CHUNK + 64 * k + lane] = acc[1][k];                                                    \
       }                                                                                                \
+      __builtin_amdgcn_wave_barrier();                                                                 \
+      _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                                  \
+        const double2 lo = *reinterpret_cast<const double2*>(C.T + c * DDT_CHUNK + DDT_KF * lane);     \
+        const double2 hi = *reinterpret_cast<const double2*>(C.T + c * DDT_CHUNK + DDT_KF * lane + 2); \
+        K.y[dst + c][0] = lo.x; K.y[dst + c][1] = lo.y; K.y[dst + c][2] = hi.x; K.y[dst + c][3] = hi.y; \
+      }                                                                                                \
+      __builtin_amdgcn_wave_barrier();                                                                 \
     }
-    for (int i = 0; i < C.nE; ++i) DDT_TAP(sE)
-    for (int i = C.nE; i < C.nT; ++i) DDT_TAP(sL)
-#undef DDT_TAP
-    // strided -> blocked: lane l wrote frames 64k+l, reads back frames 4l..4l+3
-#pragma unroll
-    for (int k = 0; k < DDT_KF; ++k) {
-      C.T[0 * DDT_CHUNK + 64 * k + lane] = sE[0][k];
-      C.T[1 * DDT_CHUNK + 64 * k + lane] = sE[1][k];
-      C.T[2 * DDT_CHUNK + 64 * k + lane] = sL[0][k];
-      C.T[3 * DDT_CHUNK + 64 * k + lane] = sL[1][k];
-    }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int sgn = 0; sgn < 4; ++sgn) {
-      const double2 lo = *reinterpret_cast<const double2*>(C.T + sgn * DDT_CHUNK + DDT_KF * lane);
-      const double2 hi = *reinterpret_cast<const double2*>(C.T + sgn * DDT_CHUNK + DDT_KF * lane + 2);
-      y[2 + sgn][0] = lo.x; y[2 + sgn][1] = lo.y; y[2 + sgn][2] = hi.x; y[2 + sgn][3] = hi.y;
-    }
+    ddt_tap_run(C, R, ringb, lane8nb, 0, C.nE, sE);
+    DDT_TRANSPOSE(sE, 2)
+    ddt_tap_run(C, R, ringb, lane8nb, C.nE, C.nT, sL);
+    DDT_TRANSPOSE(sL, 4)
+#undef DDT_TRANSPOSE
   }
-
-  // ---- one-poles (:450-454, 486-490) ---------------------------------------------------------------------------------
+  // direct path (:444-451)
 #pragma unroll
   for (int k = 0; k < DDT_KF; ++k) {
-    const double mc = M[k] * C.col;
-    const double srcL = __builtin_fma(x0[k], C.one_m_col, mc);
-    const double srcR = __builtin_fma(x1[k], C.one_m_col, mc);
-    y[0][k] = C.directGain * srcL;
-    y[1][k] = C.directGain * srcR;
+    const double x0 = (double)K.x0[k], x1 = (double)K.x1[k];
+    const double mc = (0.5 * (x0 + x1)) * C.col;
+    K.y[0][k] = C.directGain * __builtin_fma(x0, C.one_m_col, mc);
+    K.y[1][k] = C.directGain * __builtin_fma(x1, C.one_m_col, mc);
   }
-  if (want_last) {
+  if (want_last && lane == 63) {                           // the launch's final frame: leave its temporaries in vars[]
     const int q = DDT_KF - 1;
-    last.mono = M[q];
-    last.srcL = x0[q] * C.one_m_col + M[q] * C.col; last.srcR = x1[q] * C.one_m_col + M[q] * C.col;
-    last.dInL = y[0][q]; last.dInR = y[1][q];
-    last.sEL = y[2][q]; last.sER = y[3][q]; last.sLL = y[4][q]; last.sLR = y[5][q];
+    const double x0 = (double)K.x0[q], x1 = (double)K.x1[q], M = 0.5 * (x0 + x1);
+    double* V = C.V;
+    V[ZA_VAR_mono] = M;
+    V[ZA_VAR_srcL] = __builtin_fma(x0, C.one_m_col, M * C.col); V[ZA_VAR_srcR] = __builtin_fma(x1, C.one_m_col, M * C.col);
+    V[ZA_VAR_dInL] = K.y[0][q]; V[ZA_VAR_dInR] = K.y[1][q];
+    V[ZA_VAR_sumEL] = K.y[2][q]; V[ZA_VAR_sumER] = K.y[3][q]; V[ZA_VAR_sumLL] = K.y[4][q]; V[ZA_VAR_sumLR] = K.y[5][q];
   }
-  ddt_pole_run<PARTIAL>(C.P[0], cb1[0], cb2[0], y[0], carry[0], lane, first_lane, first_k);
-  ddt_pole_run<PARTIAL>(C.P[0], cb1[0], cb2[0], y[1], carry[1], lane, first_lane, first_k);
-  ddt_pole_run<PARTIAL>(C.P[1], cb1[1], cb2[1], y[2], carry[2], lane, first_lane, first_k);
-  ddt_pole_run<PARTIAL>(C.P[1], cb1[1], cb2[1], y[3], carry[3], lane, first_lane, first_k);
-  ddt_pole_run<PARTIAL>(C.P[2], cb1[2], cb2[2], y[4], carry[4], lane, first_lane, first_k);
-  ddt_pole_run<PARTIAL>(C.P[2], cb1[2], cb2[2], y[5], carry[5], lane, first_lane, first_k);
+  // one-poles (:453-454, 486-490): local responses + wave scans
+#pragma unroll
+  for (int s = 0; s < 6; ++s)
+    K.G[s] = ddt_pole_local<PARTIAL>(C.P[s >> 1], cb1[s >> 1], cb2[s >> 1], K.y[s], carry[s], head, lane, first_lane, first_k);
+}
 
-  // ---- output mix (:492-505) and meters (:510-536) -----------------------------------------------------------------
+// Phase C: apply the state carried into the chunk, mix (:492-505), meters (:510-536), store audio.
+template <bool PARTIAL>
+__device__ __forceinline__ void ddt_phase_c(const DdtCtx& C, DdtChunk& K, int lane, int64_t f0, const double (&cw)[6], bool chained,
+                                            const double (&ql)[3], double (&accM)[6], double& accC, double dMi, double dCi,
+                                            double wM, double wC, const double (&cwM)[DDT_KF], const double (&cwC)[DDT_KF],
+                                            bool want_last) {
+#pragma unroll
+  for (int s = 0; s < 6; ++s) {
+    double cin = ddt_dpp<DDT_WAVE_SHR1, 0xF>(K.G[s]);      // y at the end of the previous lane (0 for lane 0)
+    if (chained) cin = __builtin_fma(ql[s >> 1], cw[s], cin);   // + a^(4*lane) * state at the chunk's start
+#pragma unroll
+    for (int k = 0; k < DDT_KF; ++k) K.y[s][k] = __builtin_fma(C.P[s >> 1].ap[k], cin, K.y[s][k]);
+  }
   float o0[DDT_KF], o1[DDT_KF];
   double zM[6] = {0, 0, 0, 0, 0, 0}, zC = 0.0;
 #pragma unroll
   for (int k = 0; k < DDT_KF; ++k) {
-    const double dirZL = y[0][k], dirZR = y[1][k], eZL = y[2][k], eZR = y[3][k], lZL = y[4][k], lZR = y[5][k];
+    const double dirZL = K.y[0][k], dirZR = K.y[1][k], eZL = K.y[2][k], eZR = K.y[3][k], lZL = K.y[4][k], lZR = K.y[5][k];
     const double yL = dirZL + eZL + lZL, yR = dirZR + eZR + lZR;
     const double dL = eZL + lZL, dR = eZR + lZR;
     double oL, oR;
-    if (C.mon == 3) { oL = x0[k]; oR = x1[k]; }
+    const double x0 = (double)K.x0[k], x1 = (double)K.x1[k];
+    if (C.mon == 3) { oL = x0; oR = x1; }
     else if (C.mon == 1) { oL = dirZL; oR = dirZR; }
     else if (C.mon == 2) { oL = dL; oR = dR; }
     else { oL = yL; oR = yR; }
-    double s0 = __builtin_fma(C.dryp, x0[k], C.wetp * oL) * C.out_gain;
-    double s1 = __builtin_fma(C.dryp, x1[k], C.wetp * oR) * C.out_gain;
+    double s0 = __builtin_fma(C.dryp, x0, C.wetp * oL) * C.out_gain;
+    double s1 = __builtin_fma(C.dryp, x1, C.wetp * oR) * C.out_gain;
     s0 = s0 > 8.0 ? 8.0 : (s0 < -8.0 ? -8.0 : s0);
     s1 = s1 > 8.0 ? 8.0 : (s1 < -8.0 ? -8.0 : s1);
     o0[k] = (float)s0; o1[k] = (float)s1;
@@ -276,7 +326,7 @@ __device__ __forceinline__ void ddt_chunk(const DdtCtx& C, int lane, int64_t f0,
     const double s_tot = s_dir + s_ear + s_lat;
     const double adL = fabs(dL), adR = fabs(dR);
     // c = dL*dR / max(1e-7, |dL||dR| + 1e-7) (:534): the divisor is within [1e-7, ~1e2], so a hardware reciprocal
-    // refined by one Newton step (~1e-15 relative) replaces the full IEEE division sequence; c only feeds a meter.
+    // refined by two Newton steps (~1e-16 relative) replaces the full IEEE division sequence; c only feeds a meter.
     const double den = __builtin_fmax(0.0000001, __builtin_fma(adL, adR, 0.0000001));
     double rc = __builtin_amdgcn_rcp(den);
     rc = __builtin_fma(__builtin_fma(-den, rc, 1.0), rc, rc);
@@ -290,15 +340,19 @@ __device__ __forceinline__ void ddt_chunk(const DdtCtx& C, int lane, int64_t f0,
     zM[4] = __builtin_fma(cwM[k], adL, zM[4]);
     zM[5] = __builtin_fma(cwM[k], adR, zM[5]);
     zC = __builtin_fma(cwC[k], __builtin_fmin(__builtin_fmax(cc, -1.0), 1.0), zC);
-    if (want_last && k == DDT_KF - 1) {
-      last.yL = yL; last.yR = yR; last.oL = oL; last.oR = oR; last.sdir = s_dir; last.sear = s_ear; last.slat = s_lat;
-      last.stot = s_tot; last.dL = dL; last.dR = dR; last.c = cc; last.spl0 = s0; last.spl1 = s1;
+    if (want_last && k == DDT_KF - 1 && lane == 63) {
+      double* V = C.V;
+      V[ZA_VAR_yL] = yL; V[ZA_VAR_yR] = yR; V[ZA_VAR_oL] = oL; V[ZA_VAR_oR] = oR;
+      V[ZA_VAR_s_dir] = s_dir; V[ZA_VAR_s_ear] = s_ear; V[ZA_VAR_s_lat] = s_lat; V[ZA_VAR_s_tot] = s_tot;
+      V[ZA_VAR_dL] = dL; V[ZA_VAR_dR] = dR; V[ZA_VAR_c] = cc;
+      C.SPL[0] = s0; C.SPL[1] = s1;
     }
   }
 #pragma unroll
-  for (int q = 0; q < 6; ++q) accM[q] = __builtin_fma(accM[q], dM, wM * zM[q]);
-  accC = __builtin_fma(accC, dC, wC * zC);
+  for (int q = 0; q < 6; ++q) accM[q] = __builtin_fma(accM[q], dMi, wM * zM[q]);
+  accC = __builtin_fma(accC, dCi, wC * zC);
 
+  const int64_t t0 = f0 + DDT_KF * lane;
   if (C.vec_ok && (!PARTIAL || t0 >= 0)) {
     *reinterpret_cast<float4*>(C.out0 + t0) = make_float4(o0[0], o0[1], o0[2], o0[3]);
     *reinterpret_cast<float4*>(C.out1 + t0) = make_float4(o1[0], o1[1], o1[2], o1[3]);
@@ -309,14 +363,18 @@ __device__ __forceinline__ void ddt_chunk(const DdtCtx& C, int lane, int64_t f0,
   }
 }
 
-extern "C" __global__ void __launch_bounds__(64, 2) zab_ddt_fast(ZabBatch b, ZabAudio a, int W) {
+template <int NW>
+__device__ __forceinline__ void ddt_fast_body(const ZabBatch& b, const ZabAudio& a, int W) {
   extern __shared__ double ddt_lds[];
   double* ring = ddt_lds;                                  // [W + 256]: circular history + mirror of its first 256 slots
-  double* T = ddt_lds + W + DDT_CHUNK;                     // [4][256] transpose area
-  DdtTap* taps = (DdtTap*)(T + 4 * DDT_CHUNK);             // [DDT_MAXTAPS] early taps first, then late taps
-  DdtPole* P = (DdtPole*)(taps + DDT_MAXTAPS);             // [3]
+  double* Tall = ddt_lds + W + DDT_CHUNK;                  // [NW][2][256] per-wave transpose areas
+  double* gend = Tall + NW * 2 * DDT_CHUNK;                // [NW][6] chunk-end responses (zero incoming state)
+  double* mred = Tall;                                     // [NW][7] meter partials, after the last chunk (aliases Tall)
+  DdtTap* taps = (DdtTap*)Tall;                            // [DDT_MAXTAPS] staging only (aliases Tall): early taps, then late
+  DdtPole* P = (DdtPole*)(gend + NW * 6);                  // [3]
   int* scratch = (int*)(P + 3);                            // [4]
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
   const int inst = blockIdx.x;
 
   double* V = b.vars + (int64_t)inst * b.var_si;           // instance-major (checked by za_fast_applies)
@@ -330,10 +388,11 @@ extern "C" __global__ void __launch_bounds__(64, 2) zab_ddt_fast(ZabBatch b, Zab
   C.in1 = C.in0 + a.frame_stride;
   C.out0 = a.out + (int64_t)inst * 2 * a.frame_stride;
   C.out1 = C.out0 + a.frame_stride;
-  C.Mem = Mem; C.ring = ring; C.T = T; C.taps = taps; C.P = P; C.frames = frames;
+  C.V = V; C.SPL = b.spl + (int64_t)inst * b.sl_si;
+  C.Mem = Mem; C.ring = ring; C.T = Tall + wave * 2 * DDT_CHUNK; C.P = P; C.frames = frames;
   C.W = W; C.m8 = 8 * (W - 1);
 
-  // ---- per-launch scalars (wave-uniform) ---------------------------------------------------------------------------
+  // ---- per-launch scalars (workgroup-uniform) --------------------------------------------------------------------------
   const double mbase = V[ZA_VAR_m];
   C.rL = za_addr(mbase, V[ZA_VAR_bL]); C.rR = za_addr(mbase, V[ZA_VAR_bR]);
   const int64_t tDL = za_addr(mbase, V[ZA_VAR_bDL]), tDR = za_addr(mbase, V[ZA_VAR_bDR]);
@@ -354,58 +413,60 @@ extern "C" __global__ void __launch_bounds__(64, 2) zab_ddt_fast(ZabBatch b, Zab
   C.one_m_col = 1.0 - C.col;
   C.mon = za_i32(slider8);
 
-  if (lane < 3) {
+  const double poles[3] = {V[ZA_VAR_a_dir], V[ZA_VAR_a_early], V[ZA_VAR_a_late]};
+  if (tid < 3) {
     DdtPole pl;
-    const double pole = lane == 0 ? V[ZA_VAR_a_dir] : (lane == 1 ? V[ZA_VAR_a_early] : V[ZA_VAR_a_late]);
+    const double pole = poles[tid];
     pl.a = pole; pl.c1 = 1.0 - pole;
     pl.ap[0] = pole; pl.ap[1] = pole * pole; pl.ap[2] = pl.ap[1] * pole; pl.ap[3] = pl.ap[1] * pl.ap[1];
     pl.sp[0] = pl.ap[3];
     for (int j = 1; j < 4; ++j) pl.sp[j] = pl.sp[j - 1] * pl.sp[j - 1];
-    P[lane] = pl;
+    pl.a256 = ddt_ipow(pole, DDT_CHUNK);
+    P[tid] = pl;
   }
   double carry[6] = {V[ZA_VAR_dirZL], V[ZA_VAR_dirZR], V[ZA_VAR_eZL], V[ZA_VAR_eZR], V[ZA_VAR_lZL], V[ZA_VAR_lZR]};
-  // per-lane scan constants q^((l&15)+1), q^(l-31), q = a^4
-  double cb1[3], cb2[3];
-  {
-    const double poles[3] = {V[ZA_VAR_a_dir], V[ZA_VAR_a_early], V[ZA_VAR_a_late]};
+  // per-lane constants of the three poles: q^((l&15)+1), q^(l-31) for the scan, q^l for the cross-wave carry (q = a^4)
+  double cb1[3], cb2[3], ql[3];
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      const double q = (poles[p] * poles[p]) * (poles[p] * poles[p]);
-      cb1[p] = ddt_ipow(q, (lane & 15) + 1);
-      cb2[p] = ddt_ipow(q, lane >= 32 ? lane - 31 : 0);
-    }
+  for (int p = 0; p < 3; ++p) {
+    const double q = (poles[p] * poles[p]) * (poles[p] * poles[p]);
+    cb1[p] = ddt_ipow(q, (lane & 15) + 1);
+    cb2[p] = ddt_ipow(q, lane >= 32 ? lane - 31 : 0);
+    ql[p] = ddt_ipow(q, lane);
   }
 
   // meters: m = (1-aM)*val + aM*m  (:128-131,518-536); six with aM, the correlation one with 0.9990
   const double aM = 0.9985, aC = 0.9990;
   const double cM = 1.0 - aM, cC = 1.0 - aC;
   const double wM = ddt_ipow((aM * aM) * (aM * aM), 63 - lane), wC = ddt_ipow((aC * aC) * (aC * aC), 63 - lane);
-  const double dM = ddt_ipow(aM, DDT_CHUNK), dC = ddt_ipow(aC, DDT_CHUNK);
+  const double dMi = ddt_ipow(aM, DDT_CHUNK * NW), dCi = ddt_ipow(aC, DDT_CHUNK * NW);   // a wave's chunks are NW apart
   double cwM[DDT_KF], cwC[DDT_KF];
 #pragma unroll
   for (int k = 0; k < DDT_KF; ++k) { cwM[k] = cM * ddt_ipow(aM, DDT_KF - 1 - k); cwC[k] = cC * ddt_ipow(aC, DDT_KF - 1 - k); }
   double accM[6] = {0, 0, 0, 0, 0, 0}, accC = 0.0;
 
-  // ---- stage tap lists: early taps (baseD < splitSamp) then late taps, each in source order ---------------------
-  bool early = false;
-  DdtTap mine = {0, 0, 0.0, 0.0};
-  if (lane < tapN) {
-    mine.dL8 = 8 * za_i32(Mem[tDL + lane]);
-    mine.dR8 = 8 * za_i32(Mem[tDR + lane]);
-    mine.gL = Mem[tGL + lane];
-    mine.gR = Mem[tGR + lane];
-    early = (double)za_i32(Mem[tD0 + lane]) < splitSamp;
+  // ---- stage tap lists (wave 0): early taps (baseD < splitSamp) then late taps, each in source order -------------------
+  int nE = 0;
+  if (wave == 0) {
+    bool early = false;
+    DdtTap mine = {0, 0, 0.0, 0.0};
+    if (lane < tapN) {
+      mine.dL8 = 8 * za_i32(Mem[tDL + lane]);
+      mine.dR8 = 8 * za_i32(Mem[tDR + lane]);
+      mine.gL = Mem[tGL + lane];
+      mine.gR = Mem[tGR + lane];
+      early = (double)za_i32(Mem[tD0 + lane]) < splitSamp;
+    }
+    const unsigned long long emask = __ballot(lane < tapN && early);
+    const unsigned long long lmask = __ballot(lane < tapN && !early);
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    nE = __popcll(emask);
+    if (lane < tapN) taps[early ? __popcll(emask & below) : nE + __popcll(lmask & below)] = mine;
+    if (lane == tapN - 1) { scratch[0] = mine.dL8 >> 3; scratch[1] = mine.dR8 >> 3; }   // source-order last tap
+    if (lane == 0) scratch[2] = nE;
   }
-  const unsigned long long emask = __ballot(lane < tapN && early);
-  const unsigned long long lmask = __ballot(lane < tapN && !early);
-  const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  C.nE = __popcll(emask);
-  C.nT = tapN;
-  if (lane < tapN) taps[early ? __popcll(emask & below) : C.nE + __popcll(lmask & below)] = mine;
-  if (lane == tapN - 1) { scratch[0] = mine.dL8 >> 3; scratch[1] = mine.dR8 >> 3; }   // source-order last tap (state temporaries)
-
-  const int H = W - DDT_CHUNK;                             // history frames kept (> max tap delay)
-  for (int j = lane; j < H; j += 64) {
+  const int H = W - NW * DDT_CHUNK;                        // history frames kept (> max tap delay)
+  for (int j = tid; j < H; j += NW * 64) {
     const int64_t n = C.wofs0 - H + j;
     const int64_t ri = n & C.bufmask;
     const int slot = (int)(n & (W - 1));
@@ -413,51 +474,119 @@ extern "C" __global__ void __launch_bounds__(64, 2) zab_ddt_fast(ZabBatch b, Zab
     ring[slot] = mv;
     if (slot < DDT_CHUNK) ring[W + slot] = mv;
   }
+  __syncthreads();
+  C.nE = scratch[2];
+  C.nT = tapN;
+  DdtTapRegs R;                                            // lane j keeps staged tap j for the whole launch
+  {
+    const DdtTap t = taps[lane];                           // entries >= tapN are never broadcast
+    R.dpack = (t.dL8 >> 3) | ((t.dR8 >> 3) << 16);         // delays < 16384 (checked by the plan kernel)
+    R.gL = t.gL; R.gR = t.gR;
+  }
 
   C.vec_ok = ((frames & 3) == 0) && ((a.frame_stride & 3) == 0) && ((((uintptr_t)C.in0) | ((uintptr_t)C.out0)) & 15) == 0;
 
   const int64_t nchunks = (frames + DDT_CHUNK - 1) / DDT_CHUNK;
-  DdtLast last = {};
-  int64_t c = 0;
   const int64_t f_first = frames - DDT_CHUNK * nchunks;    // <= 0; chunks are end-aligned
-  if (f_first < 0) {
-    ddt_chunk<true>(C, lane, f_first, carry, cb1, cb2, accM, accC, dM, dC, wM, wC, cwM, cwC, nchunks == 1, last);
-    c = 1;
-  }
-  for (; c < nchunks; ++c)
-    ddt_chunk<false>(C, lane, f_first + DDT_CHUNK * c, carry, cb1, cb2, accM, accC, dM, dC, wM, wC, cwM, cwC,
-                     c == nchunks - 1, last);
-
-  // ---- meters: m_final = a^frames * m_start + sum over lanes of the weighted partials ---------------------------------
-  double red[7];
+  const int64_t niter = (nchunks + NW - 1) / NW;
+  DdtChunk K;
+  int64_t my_last_chunk = -1;
+  // The HBM read of a wave's next chunk is issued a whole iteration ahead of its use.
+  float4 pf0 = make_float4(0.f, 0.f, 0.f, 0.f), pf1 = pf0;
+  auto prefetch = [&](const int64_t c) __attribute__((always_inline)) {
+    const int64_t t0 = f_first + DDT_CHUNK * c + DDT_KF * lane;
+    if (C.vec_ok && c < nchunks && t0 >= 0) {
+      pf0 = *reinterpret_cast<const float4*>(C.in0 + t0);
+      pf1 = *reinterpret_cast<const float4*>(C.in1 + t0);
+    }
+  };
+  if (f_first >= 0) prefetch(wave);
+  // One iteration = NW consecutive chunks, one per wave. PART: the launch's first chunk starts before frame 0.
+  auto iteration = [&](auto part_c, const int64_t it) __attribute__((always_inline)) {
+    constexpr bool PART = decltype(part_c)::value;
+    const int64_t c = it * NW + wave;
+    const bool active = c < nchunks;
+    const int64_t f0 = f_first + DDT_CHUNK * c;
+    const bool want_last = active && c == nchunks - 1;
+    const bool head = (wave == 0);                         // wave 0 owns the head of this iteration's carry chain
+    if (active) ddt_phase_a<PART>(C, K, lane, f0, pf0, pf1);
+    prefetch(c + NW);                                      // this wave's next chunk: in flight across phases B and C
+    __syncthreads();                                       // ring holds every frame of this iteration
+    if (active) {
+      ddt_phase_b<PART>(C, R, K, lane, f0, carry, head, cb1, cb2, want_last);
+      if (lane == 63) {
 #pragma unroll
-  for (int q = 0; q < 6; ++q) red[q] = accM[q];
-  red[6] = accC;
+        for (int s = 0; s < 6; ++s) gend[wave * 6 + s] = K.G[s];
+      }
+      my_last_chunk = c;
+    }
+    __syncthreads();                                       // chunk-end responses published; taps of this iteration done
+    // carry chain: state entering wave w's chunk = a^256 * (state entering w-1) + response of w-1; wave 0 injected `carry`
+    double cw[6] = {0, 0, 0, 0, 0, 0};
+    {
+      double run[6] = {0, 0, 0, 0, 0, 0};
+      const int nact = (int)((nchunks - it * NW) < NW ? (nchunks - it * NW) : NW);
+#pragma unroll
+      for (int u = 0; u < NW; ++u) {
+        if (u < nact) {
+          if (u == wave) {
+#pragma unroll
+            for (int s = 0; s < 6; ++s) cw[s] = run[s];
+          }
+#pragma unroll
+          for (int s = 0; s < 6; ++s) run[s] = __builtin_fma(P[s >> 1].a256, run[s], gend[u * 6 + s]);
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 6; ++s) carry[s] = run[s];       // state after this iteration's last chunk (same in every wave)
+    }
+    if (active) ddt_phase_c<PART>(C, K, lane, f0, cw, wave != 0, ql, accM, accC, dMi, dCi, wM, wC, cwM, cwC, want_last);
+  };
+  int64_t it = 0;
+  if (f_first < 0) iteration(std::true_type{}, it++);     // workgroup-uniform
+  for (; it < niter; ++it) iteration(std::false_type{}, it);
+
+  // ---- meters: m_final = a^frames * m_start + sum over waves/lanes of the weighted partials ----------------------------
+  double red[7];
+  {
+    // a wave's partials are relative to the end of ITS last chunk; bring them to the end of the launch
+    const int64_t behind = my_last_chunk >= 0 ? (nchunks - 1 - my_last_chunk) * DDT_CHUNK : 0;
+    const double fM = ddt_ipow(aM, behind), fC = ddt_ipow(aC, behind);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) red[q] = accM[q] * fM;
+    red[6] = accC * fC;
+  }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1)
 #pragma unroll
     for (int q = 0; q < 7; ++q) red[q] += __shfl_xor(red[q], d, 64);
-
+  if (lane == 0) {                                         // (every wave is past the loop's last barrier: Tall is free)
+#pragma unroll
+    for (int q = 0; q < 7; ++q) mred[wave * 7 + q] = red[q];
+  }
   __syncthreads();
-  // ---- state write-back (lane 63 owns the launch's last frame) --------------------------------------------------------
-  if (lane == 63) {
+
+  // ---- state write-back: lane 63 of the wave that processed the launch's last chunk ------------------------------------
+  const int last_wave = (int)((nchunks - 1) % NW);
+  if (wave == last_wave && lane == 63) {
+    double tot[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int u = 0; u < NW; ++u)
+      for (int q = 0; q < 7; ++q) tot[q] += mred[u * 7 + q];
     const double pM = pow(aM, (double)frames), pC = pow(aC, (double)frames);
-    V[ZA_VAR_m_dirE] = pM * V[ZA_VAR_m_dirE] + red[0];
-    V[ZA_VAR_m_earlyE] = pM * V[ZA_VAR_m_earlyE] + red[1];
-    V[ZA_VAR_m_lateE] = pM * V[ZA_VAR_m_lateE] + red[2];
-    V[ZA_VAR_m_totalE] = pM * V[ZA_VAR_m_totalE] + red[3];
-    V[ZA_VAR_m_diffL] = pM * V[ZA_VAR_m_diffL] + red[4];
-    V[ZA_VAR_m_diffR] = pM * V[ZA_VAR_m_diffR] + red[5];
-    V[ZA_VAR_m_diffCorr] = pC * V[ZA_VAR_m_diffCorr] + red[6];
+    V[ZA_VAR_m_dirE] = pM * V[ZA_VAR_m_dirE] + tot[0];
+    V[ZA_VAR_m_earlyE] = pM * V[ZA_VAR_m_earlyE] + tot[1];
+    V[ZA_VAR_m_lateE] = pM * V[ZA_VAR_m_lateE] + tot[2];
+    V[ZA_VAR_m_totalE] = pM * V[ZA_VAR_m_totalE] + tot[3];
+    V[ZA_VAR_m_diffL] = pM * V[ZA_VAR_m_diffL] + tot[4];
+    V[ZA_VAR_m_diffR] = pM * V[ZA_VAR_m_diffR] + tot[5];
+    V[ZA_VAR_m_diffCorr] = pC * V[ZA_VAR_m_diffCorr] + tot[6];
     V[ZA_VAR_dirZL] = carry[0]; V[ZA_VAR_dirZR] = carry[1];
     V[ZA_VAR_eZL] = carry[2]; V[ZA_VAR_eZR] = carry[3];
     V[ZA_VAR_lZL] = carry[4]; V[ZA_VAR_lZR] = carry[5];
     V[ZA_VAR_wofs] = V[ZA_VAR_wofs] + (double)frames;
     // @sample temporaries of the last frame, exactly as the script leaves them
     const int64_t nlast = C.wofs0 + frames - 1;
-    V[ZA_VAR_distN] = distN; V[ZA_VAR_col] = C.col; V[ZA_VAR_mono] = last.mono;
-    V[ZA_VAR_srcL] = last.srcL; V[ZA_VAR_srcR] = last.srcR; V[ZA_VAR_dInL] = last.dInL; V[ZA_VAR_dInR] = last.dInR;
-    V[ZA_VAR_sumEL] = last.sEL; V[ZA_VAR_sumER] = last.sER; V[ZA_VAR_sumLL] = last.sLL; V[ZA_VAR_sumLR] = last.sLR;
+    V[ZA_VAR_distN] = distN; V[ZA_VAR_col] = C.col;
     V[ZA_VAR_i] = (double)tapN;
     if (tapN > 0) {
       const int dLl = scratch[0], dRl = scratch[1];
@@ -469,17 +598,17 @@ extern "C" __global__ void __launch_bounds__(64, 2) zab_ddt_fast(ZabBatch b, Zab
       V[ZA_VAR_gL] = Mem[tGL + tapN - 1]; V[ZA_VAR_gR] = Mem[tGR + tapN - 1];
       V[ZA_VAR_baseD] = (double)za_i32(Mem[tD0 + tapN - 1]);
     }
-    V[ZA_VAR_yL] = last.yL; V[ZA_VAR_yR] = last.yR; V[ZA_VAR_mon] = (double)C.mon;
-    V[ZA_VAR_oL] = last.oL; V[ZA_VAR_oR] = last.oR;
-    V[ZA_VAR_s_dir] = last.sdir; V[ZA_VAR_s_ear] = last.sear; V[ZA_VAR_s_lat] = last.slat; V[ZA_VAR_s_tot] = last.stot;
+    V[ZA_VAR_mon] = (double)C.mon;
     V[ZA_VAR_aM] = aM;
-    V[ZA_VAR_dL] = last.dL; V[ZA_VAR_dR] = last.dR; V[ZA_VAR_c] = last.c;
-    double* SPL = b.spl + (int64_t)inst * b.sl_si;
-    SPL[0] = last.spl0; SPL[1] = last.spl1;
     const int64_t hi = (C.rL > C.rR ? C.rL : C.rR) + DDT_RING;
     if (b.mem_high[inst] < hi) b.mem_high[inst] = hi;
   }
 }
+
+extern "C" __global__ void __launch_bounds__(64, 2) zab_ddt_fast(ZabBatch b, ZabAudio a, int W) { ddt_fast_body<1>(b, a, W); }
+extern "C" __global__ void __launch_bounds__(128, 2) zab_ddt_fast_nw2(ZabBatch b, ZabAudio a, int W) { ddt_fast_body<2>(b, a, W); }
+extern "C" __global__ void __launch_bounds__(256, 2) zab_ddt_fast_nw4(ZabBatch b, ZabAudio a, int W) { ddt_fast_body<4>(b, a, W); }
+extern "C" __global__ void __launch_bounds__(512, 2) zab_ddt_fast_nw8(ZabBatch b, ZabAudio a, int W) { ddt_fast_body<8>(b, a, W); }
 
 // ---- plan: max tap delay over the batch (decides the LDS ring length) -----------------------------------------------
 __device__ int ddt_plan_word[2];
@@ -507,42 +636,75 @@ extern "C" __global__ void zab_ddt_plan(ZabBatch b) {
   if (bad) atomicMax(&ddt_plan_word[1], 1);
 }
 
-struct DdtPlan { uint64_t epoch; int W; };
+struct DdtPlan { uint64_t epoch; int dmax; bool ok; };
 static std::mutex ddt_mu;
 static std::map<const void*, DdtPlan> ddt_plans;
 
-static int ddt_ring_len(const ZabBatch* b) {
+static DdtPlan ddt_plan(const ZabBatch* b) {
   std::lock_guard<std::mutex> lk(ddt_mu);
   auto it = ddt_plans.find(b->vars);
-  if (it != ddt_plans.end() && it->second.epoch == b->epoch) return it->second.W;
+  if (it != ddt_plans.end() && it->second.epoch == b->epoch) return it->second;
   int zero[2] = {0, 0}, res[2] = {0, 1};
-  if (hipMemcpyToSymbol(HIP_SYMBOL(ddt_plan_word), zero, sizeof zero) != hipSuccess) return 0;
-  hipLaunchKernelGGL(zab_ddt_plan, dim3((b->n_inst + 255) / 256), dim3(256), 0, 0, *b);
-  if (hipMemcpyFromSymbol(res, HIP_SYMBOL(ddt_plan_word), sizeof res) != hipSuccess) return 0;
-  int W = 0;
-  if (!res[1]) {
-    W = 1024;
-    while (W < res[0] + DDT_CHUNK + 1) W <<= 1;
-    if (W > 16384) W = 0;                                  // 128 KiB + tables still fit the 160 KiB LDS; beyond: generic
+  DdtPlan p{b->epoch, 0, false};
+  if (hipMemcpyToSymbol(HIP_SYMBOL(ddt_plan_word), zero, sizeof zero) == hipSuccess) {
+    hipLaunchKernelGGL(zab_ddt_plan, dim3((b->n_inst + 255) / 256), dim3(256), 0, 0, *b);
+    if (hipMemcpyFromSymbol(res, HIP_SYMBOL(ddt_plan_word), sizeof res) == hipSuccess) { p.dmax = res[0]; p.ok = !res[1]; }
   }
-  ddt_plans[b->vars] = DdtPlan{b->epoch, W};
-  return W;
+  ddt_plans[b->vars] = p;
+  return p;
+}
+
+// waves per instance: the register budget allows two waves per SIMD, so aim at 2 x 1024 SIMDs resident waves and no more
+// (measured on MI355X, 480 000 frames: N=1024 -> NW 1/2/4 = 7.9/5.95/6.2 ms; N=4096 -> NW 1/2 = 20.8/22.6 ms)
+static int ddt_pick_nw(int n_inst) {
+  int nw = 1;
+  while (nw < DDT_MAXNW && (int64_t)n_inst * nw < 2048) nw <<= 1;
+  if (const char* e = getenv("ZAB_DDT_NW")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) nw = v; }
+  return nw;
+}
+static size_t ddt_lds_bytes(int W, int nw) {
+  return (size_t)(W + DDT_CHUNK + nw * 2 * DDT_CHUNK + nw * 6) * sizeof(double) + 3 * sizeof(DdtPole) + 16;
+}
+// ring length (power of two) and waves per instance; W == 0: not applicable (generic kernel takes over)
+static void ddt_geometry(const ZabBatch* b, int& W, int& nw) {
+  const DdtPlan p = ddt_plan(b);
+  W = 0; nw = 1;
+  if (!p.ok) return;
+  for (nw = ddt_pick_nw(b->n_inst); nw >= 1; nw >>= 1) {
+    int w = 1024;
+    while (w < p.dmax + nw * DDT_CHUNK + 1) w <<= 1;
+    if (w <= 16384 && ddt_lds_bytes(w, nw) <= 160 * 1024 - 512) { W = w; return; }
+  }
+  nw = 1;
 }
 
 static int32_t za_fast_applies(const ZabBatch* b, const ZabAudio* a) {
   if (!b->instance_major || b->var_se != 1 || b->mem_se != 1 || b->sl_se != 1) return 0;
   if (a->frames <= 0) return 0;
-  return ddt_ring_len(b) > 0 ? 1 : 0;
+  int W, nw;
+  ddt_geometry(b, W, nw);
+  return W > 0 ? 1 : 0;
 }
 
 static hipError_t za_launch_fast(const ZabBatch* b, const ZabAudio* a, hipStream_t st) {
-  const int W = ddt_ring_len(b);
+  int W, nw;
+  ddt_geometry(b, W, nw);
   if (W <= 0) return hipErrorInvalidValue;
-  const size_t lds = (size_t)(W + 5 * DDT_CHUNK) * sizeof(double) + DDT_MAXTAPS * sizeof(DdtTap) + 3 * sizeof(DdtPole) + 16;
+  const size_t lds = ddt_lds_bytes(W, nw);
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute((const void*)zab_ddt_fast, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+    const int cap = 160 * 1024 - 512;
+    (void)hipFuncSetAttribute((const void*)zab_ddt_fast, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute((const void*)zab_ddt_fast_nw2, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute((const void*)zab_ddt_fast_nw4, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute((const void*)zab_ddt_fast_nw8, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
   });
-  hipLaunchKernelGGL(zab_ddt_fast, dim3(b->n_inst), dim3(64), lds, st, *b, *a, W);
+  const dim3 grid(b->n_inst), block(64 * nw);
+  switch (nw) {
+    case 1: hipLaunchKernelGGL(zab_ddt_fast, grid, block, lds, st, *b, *a, W); break;
+    case 2: hipLaunchKernelGGL(zab_ddt_fast_nw2, grid, block, lds, st, *b, *a, W); break;
+    case 4: hipLaunchKernelGGL(zab_ddt_fast_nw4, grid, block, lds, st, *b, *a, W); break;
+    default: hipLaunchKernelGGL(zab_ddt_fast_nw8, grid, block, lds, st, *b, *a, W); break;
+  }
   return hipGetLastError();
 }
