@@ -106,3 +106,25 @@ def test_dot_device_vs_port():
         assert np.abs(y[i].astype(np.float64) - ref).max() <= AUDIO_EPS, i
         assert_state_close(names, v[i], p.vars(), what=f"DOT vars[{i}]")
         assert np.abs(mem[i] - p.mem(0, 57344)).max() <= SCALAR_EPS, i
+
+
+HOST_ASSISTED = ["IPCProbeA", "IPCProbeB", "GesturePad", "3DPannerManager", "PsychoConvolver", "CMD", "Contour",
+                 "TextureXY", "3DPanner", "Texture"]
+
+
+@pytest.mark.parametrize("leaf", HOST_ASSISTED)
+def test_host_assisted_leaves_build_and_are_refused_loudly(leaf):
+    """Leaves whose default path calls host services (msg bus / file slots / MIDI: SURVEY §8f.3-4, not built yet) go through
+    the translator and load, but the engine must not run them with stubbed host calls: the device latches
+    ZA_ERR_UNSUPPORTED and the C ABI returns ZAB_E_UNSUPPORTED."""
+    import zabatch
+    if not zabatch.module_path(leaf).exists():
+        pytest.skip(f"module for {leaf} not built")
+    meta = zabatch.leaf_meta(leaf)
+    assert any(f.startswith("host:") for f in meta["features"])
+    with zabatch.Engine(leaf, 3, mem_cap=1 << 16) as e:
+        e.set_sliders(meta["default_sliders"])
+        with pytest.raises(zabatch.ZabError) as ei:
+            e.prepare()
+            e.process_host(np.zeros((3, e.nch, 64), np.float32), block=64)
+        assert ei.value.code in (-5, -4), ei.value          # unsupported (or arena too small before getting there)

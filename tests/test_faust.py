@@ -1,0 +1,95 @@
+"""Faust leaves: FaustJuceProcessor::processBlock -> mydsp::compute, f32.
+
+PARITY UNPINNED: no Faust compiler / stdfaust.lib in the reference tree and no reference fixture for these leaves, so the
+checker is the build's own CPU restatement (oracle/faust_ref.c), pinned only by properties that follow from the .dsp text:
+  * ClickBeGoneSG: while nothing triggers, the output is the input delayed by exactly 15 samples (xC = x@15, mix = 0);
+    Monitor=Delta is then identically zero; Savitzky-Golay predictors reproduce any cubic exactly (their defining property).
+  * ModTilt: Tilt = 0 dB makes g_hi = g_lo = 1, hence r0 = 1, g = 1, trim = 1 and output == input bit for bit.
+The GPU kernels are compared with the restatement: bit-exact where only + - * / max min sqrt are involved (ClickBeGoneSG),
+<= 1e-6 where a per-sample log10/pow is (ModTilt).
+"""
+import numpy as np
+import pytest
+
+FAUST = {"ClickBeGoneSG": [50, 50, 1500, 1, 0], "ModTilt": [-4.5, 3.0, 0.8]}
+
+
+def _noise(ids, frames):
+    from zajit import noise
+    return noise.white_noise(ids, frames)
+
+
+def _ref():
+    from oracle import faust_ref
+    faust_ref.build()
+    return faust_ref
+
+
+def test_ui_zones_parsed_from_the_dsp_sources():
+    from zajit import faust
+    ui = faust.parse_ui('a = hslider("Amount [%]", 50, 0, 100, 1) / 100;\n// x = hslider("no", 1,2,3,4);\n'
+                        'm = nentry("Mode[style:menu{\'Fast\':0;\'Slow\':1}]", 1, 0, 2, 1);')
+    assert [(u["label"], u["default"], u["min"], u["max"], u["step"]) for u in ui] == [("Amount", 50, 0, 100, 1), ("Mode", 1, 0, 2, 1)]
+
+
+def test_clickbegone_is_a_15_sample_delay_when_nothing_triggers():
+    fr = _ref()
+    t = np.arange(4000, dtype=np.float64)
+    fade = 0.5 - 0.5 * np.cos(np.pi * np.minimum(t / 1000.0, 1.0))        # no onset click
+    x = (fade * np.stack([0.3 * np.sin(2 * np.pi * 100 * t / 48000), 0.2 * np.cos(2 * np.pi * 60 * t / 48000)])).astype(np.float32)
+    y = fr.FaustRef("ClickBeGoneSG", 48000).compute(x, FAUST["ClickBeGoneSG"])
+    assert np.array_equal(y[:, 215:], x[:, 200:-15])      # (the first frames of the fade-in are below the 1e-6 floor of e_norm)
+    d = fr.FaustRef("ClickBeGoneSG", 48000).compute(x, [50, 50, 1500, 1, 1])
+    assert not d[:, 215:].any()
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_clickbegone_predictors_reproduce_cubics(mode):
+    """Force the replacement path (white-noise burst makes `active`), then feed a cubic: pred == x@15 up to f32 rounding."""
+    fr = _ref()
+    r = fr.FaustRef("ClickBeGoneSG", 48000)
+    r.compute(_noise([3], 2000)[0], [100, 100, 300, mode, 0])
+    n = 64
+    t = np.arange(n, dtype=np.float64) / n
+    cub = (0.2 * t ** 3 - 0.1 * t ** 2 + 0.05 * t + 0.01).astype(np.float32)
+    x = np.stack([cub, -cub])
+    y = r.compute(x, [100, 100, 300, mode, 0])
+    assert np.abs(y[:, 46:] - x[:, 31:n - 15]).max() < 2e-6        # history fully inside the cubic from frame 31 on
+
+
+def test_modtilt_zero_tilt_is_identity_and_blocks_do_not_matter():
+    fr = _ref()
+    x = _noise([5], 3000)[0]
+    assert np.array_equal(fr.FaustRef("ModTilt", 48000).compute(x, [0.0, 3.0, 1.0]), x)
+    a = fr.FaustRef("ModTilt", 48000).compute(x, FAUST["ModTilt"], block=512)
+    b = fr.FaustRef("ModTilt", 48000).compute(x, FAUST["ModTilt"], block=77)
+    assert np.array_equal(a, b) and np.abs(a - x).max() > 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("leaf", sorted(FAUST))
+def test_gpu_matches_restatement(leaf):
+    import zabatch
+    fr = _ref()
+    n, frames = 70, 3000                                  # two workgroups, ragged tile tail
+    x = _noise(range(40, 40 + n), frames)
+    x[:, :, 1500:] *= 0.02                                # a quiet half so both branches of the detectors are exercised
+    rows = np.zeros((n, 64)); rows[:, :len(FAUST[leaf])] = FAUST[leaf]
+    if leaf == "ClickBeGoneSG":
+        rows[:, 0] = np.linspace(0, 100, n); rows[:, 1] = np.linspace(100, 0, n); rows[:, 3] = np.arange(n) % 3
+        rows[:, 4] = (np.arange(n) // 3) % 2
+    else:
+        rows[:, 0] = np.linspace(-6, 3, n); rows[:, 1] = np.linspace(2, 5, n); rows[:, 2] = np.linspace(0, 1, n)
+    with zabatch.Engine(leaf, n) as e:
+        e.set_sliders(rows); e.prepare()
+        y1 = e.process_host(x[:, :, :1700], block=512)
+        y2 = e.process_host(x[:, :, 1700:], block=512)    # state carried across launches
+        st = e.read_vars()
+    y = np.concatenate([y1, y2], axis=2)
+    tol = 0.0 if leaf == "ClickBeGoneSG" else 1e-6
+    for i in range(n):
+        r = fr.FaustRef(leaf, 48000)
+        want = r.compute(x[i], rows[i, :8].astype(np.float32))
+        err = np.abs(y[i].astype(np.float64) - want).max()
+        assert err <= tol, (leaf, i, err)
+        assert np.abs(st[i] - r.state()).max() <= tol, (leaf, i)

@@ -1,0 +1,111 @@
+// faust_lane.hip.h -- batch kernels for the Faust leaves: FaustJuceProcessor::processBlock ->
+// mydsp::compute(count, inputs, outputs)  (src/FaustJuceProcessor.cpp:462-482, ABI src/faust_support_min.h:41-53).
+//
+// The reference compiles each .dsp with the Faust compiler (-single: FAUSTFLOAT = float, all arithmetic f32). That compiler
+// and stdfaust.lib are not part of the reference tree, so every leaf here is a hand-written restatement of its .dsp
+// (csrc/faust/<leaf>.hip.h, citing the .dsp lines) -- "parity unpinned", see DESIGN.md.
+//
+// Mapping: ONE LANE PER INSTANCE, 64 instances per single-wave workgroup; the leaf's recursive state (a few floats and short
+// delay lines) stays in registers for the whole launch. Audio is instance-major planar, so a wave stages a
+// [NCH][64 instances][TT frames] tile through LDS exactly like the JSFX generic kernel (zab_generic.hip.h): HBM accesses
+// are 128-byte row segments, the per-lane walk is bank-conflict free (+1 padding). In and out alias (in-place), as in
+// FaustJuceProcessor::processBlock.
+//
+// A leaf type L provides:
+//   NCH, NSTATE, NPARAM, names[], struct Ctl, control(params, sr) -> Ctl  (the "fSlow"/"fConst" values of a Faust compute()),
+//   frame(st, ctl, x)  -- one sample, x[NCH] in place.
+// State lives in ZabBatch::vars between launches (floats widened to f64: exact), sliders[k] is the k-th UI zone.
+#pragma once
+
+#include "../zab_module.h"
+
+#define ZF_FN __device__ __forceinline__
+
+// control-rate transcendental functions: evaluated in f64 and rounded once (the CPU restatement does the same), so the
+// coefficients on both sides are the same floats
+ZF_FN float zf_exp(float x) { return (float)exp((double)x); }
+ZF_FN float zf_log10(float x) { return (float)log10((double)x); }
+ZF_FN float zf_pow(float x, float y) { return (float)pow((double)x, (double)y); }
+ZF_FN float zf_sin(float x) { return (float)sin((double)x); }
+ZF_FN float zf_cos(float x) { return (float)cos((double)x); }
+ZF_FN float zf_min(float a, float b) { return fminf(a, b); }
+ZF_FN float zf_max(float a, float b) { return fmaxf(a, b); }
+// ma.SR = min(192000, max(1, fSampleRate))
+ZF_FN float zf_sr(double srate) { return fminf(192000.0f, fmaxf(1.0f, (float)(int)srate)); }
+
+template <class L>
+__global__ void __launch_bounds__(64) zf_prepare(ZabBatch b) {   // dsp->init(sampleRate): instanceClear
+  const int inst = blockIdx.x * 64 + threadIdx.x;
+  if (inst >= b.n_inst) return;
+#pragma unroll
+  for (int k = 0; k < L::NSTATE; ++k) b.vars[k * b.var_se + inst * b.var_si] = 0.0;
+  b.flags[inst] = ZAB_FLAG_PREPARED;
+}
+
+template <class L, int TT>
+__global__ void __launch_bounds__(64) zf_process(ZabBatch b, ZabAudio a) {
+  __shared__ float tile[L::NCH][64][TT + 1];
+  const int lane = threadIdx.x;
+  const int inst0 = blockIdx.x * 64;
+  const int inst = inst0 + lane;
+  const bool active = inst < b.n_inst;
+  float st[L::NSTATE];
+  float par[L::NPARAM];
+  typename L::Ctl ctl;
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < L::NSTATE; ++k) st[k] = (float)b.vars[k * b.var_se + inst * b.var_si];
+#pragma unroll
+    for (int k = 0; k < L::NPARAM; ++k) par[k] = (float)b.sliders[k * b.sl_se + inst * b.sl_si];
+    ctl = L::control(par, zf_sr(b.srate));     // zones are pushed before every compute(): per-launch constants
+    b.flags[inst] &= ~ZAB_FLAG_SLIDER_DIRTY;
+  }
+  for (int64_t t0 = 0; t0 < a.frames; t0 += TT) {
+    const int tn = (int)((a.frames - t0 < TT) ? (a.frames - t0) : TT);
+    for (int idx = lane; idx < 64 * L::NCH * TT; idx += 64) {
+      const int t = idx % TT, rc = idx / TT, ch = rc % L::NCH, row = rc / L::NCH;
+      float x = 0.0f;
+      if (t < tn && inst0 + row < b.n_inst) x = a.in[((int64_t)(inst0 + row) * L::NCH + ch) * a.frame_stride + t0 + t];
+      tile[ch][row][t] = x;
+    }
+    __syncthreads();
+    if (active) {
+      for (int t = 0; t < tn; ++t) {
+        float x[L::NCH];
+#pragma unroll
+        for (int ch = 0; ch < L::NCH; ++ch) x[ch] = tile[ch][lane][t];
+        L::frame(st, ctl, x);
+#pragma unroll
+        for (int ch = 0; ch < L::NCH; ++ch) tile[ch][lane][t] = x[ch];
+      }
+    }
+    __syncthreads();
+    for (int idx = lane; idx < 64 * L::NCH * TT; idx += 64) {
+      const int t = idx % TT, rc = idx / TT, ch = rc % L::NCH, row = rc / L::NCH;
+      if (t < tn && inst0 + row < b.n_inst)
+        a.out[((int64_t)(inst0 + row) * L::NCH + ch) * a.frame_stride + t0 + t] = tile[ch][row][t];
+    }
+    __syncthreads();
+  }
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < L::NSTATE; ++k) b.vars[k * b.var_se + inst * b.var_si] = (double)st[k];
+  }
+}
+
+template <class L> static hipError_t zf_launch_prepare(const ZabBatch* b, hipStream_t st) {
+  hipLaunchKernelGGL(zf_prepare<L>, dim3((b->n_inst + 63) / 64), dim3(64), 0, st, *b);
+  return hipGetLastError();
+}
+template <class L> static hipError_t zf_launch_process(const ZabBatch* b, const ZabAudio* a, hipStream_t st) {
+  constexpr int TT = L::NCH <= 2 ? 64 : (L::NCH <= 4 ? 32 : 16);
+  hipLaunchKernelGGL((zf_process<L, TT>), dim3((b->n_inst + 63) / 64), dim3(64), 0, st, *b, *a);
+  return hipGetLastError();
+}
+template <class L> static hipError_t zf_launch_slider(const ZabBatch*, hipStream_t) { return hipSuccess; }   // constants are per launch
+
+#define ZF_DEFINE_MODULE(L, KEY)                                                                                        \
+  static const ZabModule zf_module = {                                                                                  \
+      ZAB_MODULE_ABI, KEY, L::NSTATE, L::NCH, L::NCH, L::NCH, 1, 0, 0, 1, 0, 64, L::names, 0, 0, 0,                     \
+      zf_launch_prepare<L>, zf_launch_process<L>, zf_launch_slider<L>, nullptr, nullptr, nullptr, "zf_process"};     \
+  extern "C" const ZabModule* zab_module_get(void) { return &zf_module; }
