@@ -156,10 +156,8 @@ def main() -> int:
     dl = eng.read_mem(32768, 64, 0, 1)[0][:tapN]
     dr = eng.read_mem(32768 + 64, 64, 0, 1)[0][:tapN]
     dmax = int(max(dl.max(), dr.max()))
-    W = 1024
-    while W < dmax + 257:
-        W *= 2
-    alg = algorithmic_bytes_per_launch(n_inst, frames, {"H": W - 256, "tapN": tapN, "nvars": len(names)})
+    # history the taps can reach back into = Dmax frames (the kernel stages a power-of-two ring; the surplus is not counted)
+    alg = algorithmic_bytes_per_launch(n_inst, frames, {"H": dmax, "tapN": tapN, "nvars": len(names)})
 
     if rank == 0:
         total_samples = job.units      # SUM over ranks

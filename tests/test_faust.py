@@ -66,11 +66,21 @@ def test_modtilt_zero_tilt_is_identity_and_blocks_do_not_matter():
     assert np.array_equal(a, b) and np.abs(a - x).max() > 1e-3
 
 
+VARIANTS = [("ClickBeGoneSG", "generic"), ("ClickBeGoneSG", "wave1"), ("ClickBeGoneSG", "wave4"),
+            ("ModTilt", "generic")]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("leaf", sorted(FAUST))
-def test_gpu_matches_restatement(leaf):
+@pytest.mark.parametrize("leaf,variant", VARIANTS)
+def test_gpu_matches_restatement(leaf, variant, monkeypatch):
+    """generic = one lane per instance; waveG = the hand-written ClickBeGoneSG kernel (one lane per frame for the feed-forward
+    parts, G instances per wavefront for the recursions). Both must give the restatement's bits."""
     import zabatch
     fr = _ref()
+    path = zabatch.ZAB_PATH_GENERIC
+    if variant.startswith("wave"):
+        monkeypatch.setenv("ZAB_CBG_G", variant[4:])
+        path = zabatch.ZAB_PATH_FAST
     n, frames = 70, 3000                                  # two workgroups, ragged tile tail
     x = _noise(range(40, 40 + n), frames)
     x[:, :, 1500:] *= 0.02                                # a quiet half so both branches of the detectors are exercised
@@ -80,9 +90,10 @@ def test_gpu_matches_restatement(leaf):
         rows[:, 4] = (np.arange(n) // 3) % 2
     else:
         rows[:, 0] = np.linspace(-6, 3, n); rows[:, 1] = np.linspace(2, 5, n); rows[:, 2] = np.linspace(0, 1, n)
-    with zabatch.Engine(leaf, n) as e:
+    with zabatch.Engine(leaf, n, path=path) as e:
         e.set_sliders(rows); e.prepare()
         y1 = e.process_host(x[:, :, :1700], block=512)
+        assert e.used_fast_path() == variant.startswith("wave")
         y2 = e.process_host(x[:, :, 1700:], block=512)    # state carried across launches
         st = e.read_vars()
     y = np.concatenate([y1, y2], axis=2)

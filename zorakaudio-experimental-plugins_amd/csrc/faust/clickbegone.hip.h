@@ -48,80 +48,102 @@ struct ZfClickBeGone {
     return c;
   }
 
-  // sig@(d): d = 0 is the current sample, h[d-1] the d-th previous one
-  ZF_FN static float at(const float* h, float cur, int d) { return d == 0 ? cur : h[d - 1]; }
+  // sig@(d) accessors: registers (d = 0 is the current sample, h[d-1] the d-th previous one) or a contiguous LDS row
+  struct RegHist { const float* h; float cur; ZF_FN float operator()(int d) const { return d == 0 ? cur : h[d - 1]; } };
+  struct RowHist { const float* p; ZF_FN float operator()(int d) const { return p[-d]; } };
 
-  ZF_FN static float sg11(const float* h, float x) {                                            // :51
-    return (-36.0f * at(h, x, 20) + 9.0f * at(h, x, 19) + 44.0f * at(h, x, 18) + 69.0f * at(h, x, 17) + 84.0f * at(h, x, 16) +
-            89.0f * at(h, x, 15) + 84.0f * at(h, x, 14) + 69.0f * at(h, x, 13) + 44.0f * at(h, x, 12) + 9.0f * at(h, x, 11) -
-            36.0f * at(h, x, 10)) / 429.0f;
+  template <class H> ZF_FN static float sg11(const H& at) {                                            // :51
+    return (-36.0f * at(20) + 9.0f * at(19) + 44.0f * at(18) + 69.0f * at(17) + 84.0f * at(16) +
+            89.0f * at(15) + 84.0f * at(14) + 69.0f * at(13) + 44.0f * at(12) + 9.0f * at(11) -
+            36.0f * at(10)) / 429.0f;
   }
-  ZF_FN static float sg15(const float* h, float x) {                                            // :53
-    return (-78.0f * at(h, x, 22) - 13.0f * at(h, x, 21) + 42.0f * at(h, x, 20) + 87.0f * at(h, x, 19) + 122.0f * at(h, x, 18) +
-            147.0f * at(h, x, 17) + 162.0f * at(h, x, 16) + 167.0f * at(h, x, 15) + 162.0f * at(h, x, 14) + 147.0f * at(h, x, 13) +
-            122.0f * at(h, x, 12) + 87.0f * at(h, x, 11) + 42.0f * at(h, x, 10) - 13.0f * at(h, x, 9) - 78.0f * at(h, x, 8)) / 1105.0f;
+  template <class H> ZF_FN static float sg15(const H& at) {                                            // :53
+    return (-78.0f * at(22) - 13.0f * at(21) + 42.0f * at(20) + 87.0f * at(19) + 122.0f * at(18) +
+            147.0f * at(17) + 162.0f * at(16) + 167.0f * at(15) + 162.0f * at(14) + 147.0f * at(13) +
+            122.0f * at(12) + 87.0f * at(11) + 42.0f * at(10) - 13.0f * at(9) - 78.0f * at(8)) / 1105.0f;
   }
-  ZF_FN static float sg21(const float* h, float x) {                                            // :55
-    return (-171.0f * at(h, x, 25) - 76.0f * at(h, x, 24) + 9.0f * at(h, x, 23) + 84.0f * at(h, x, 22) + 149.0f * at(h, x, 21) +
-            204.0f * at(h, x, 20) + 249.0f * at(h, x, 19) + 284.0f * at(h, x, 18) + 309.0f * at(h, x, 17) + 324.0f * at(h, x, 16) +
-            329.0f * at(h, x, 15) + 324.0f * at(h, x, 14) + 309.0f * at(h, x, 13) + 284.0f * at(h, x, 12) + 249.0f * at(h, x, 11) +
-            204.0f * at(h, x, 10) + 149.0f * at(h, x, 9) + 84.0f * at(h, x, 8) + 9.0f * at(h, x, 7) - 76.0f * at(h, x, 6) -
-            171.0f * at(h, x, 5)) / 3059.0f;
+  template <class H> ZF_FN static float sg21(const H& at) {                                            // :55
+    return (-171.0f * at(25) - 76.0f * at(24) + 9.0f * at(23) + 84.0f * at(22) + 149.0f * at(21) +
+            204.0f * at(20) + 249.0f * at(19) + 284.0f * at(18) + 309.0f * at(17) + 324.0f * at(16) +
+            329.0f * at(15) + 324.0f * at(14) + 309.0f * at(13) + 284.0f * at(12) + 249.0f * at(11) +
+            204.0f * at(10) + 149.0f * at(9) + 84.0f * at(8) + 9.0f * at(7) - 76.0f * at(6) -
+            171.0f * at(5)) / 3059.0f;
   }
-  ZF_FN static float sg31(const float* h, float x) {                                            // :57
-    return (-406.0f * at(h, x, 30) - 261.0f * at(h, x, 29) - 126.0f * at(h, x, 28) - 1.0f * at(h, x, 27) + 114.0f * at(h, x, 26) +
-            219.0f * at(h, x, 25) + 314.0f * at(h, x, 24) + 399.0f * at(h, x, 23) + 474.0f * at(h, x, 22) + 539.0f * at(h, x, 21) +
-            594.0f * at(h, x, 20) + 639.0f * at(h, x, 19) + 674.0f * at(h, x, 18) + 699.0f * at(h, x, 17) + 714.0f * at(h, x, 16) +
-            719.0f * at(h, x, 15) + 714.0f * at(h, x, 14) + 699.0f * at(h, x, 13) + 674.0f * at(h, x, 12) + 639.0f * at(h, x, 11) +
-            594.0f * at(h, x, 10) + 539.0f * at(h, x, 9) + 474.0f * at(h, x, 8) + 399.0f * at(h, x, 7) + 314.0f * at(h, x, 6) +
-            219.0f * at(h, x, 5) + 114.0f * at(h, x, 4) - 1.0f * at(h, x, 3) - 126.0f * at(h, x, 2) - 261.0f * at(h, x, 1) -
-            406.0f * at(h, x, 0)) / 9889.0f;
+  template <class H> ZF_FN static float sg31(const H& at) {                                            // :57
+    return (-406.0f * at(30) - 261.0f * at(29) - 126.0f * at(28) - 1.0f * at(27) + 114.0f * at(26) +
+            219.0f * at(25) + 314.0f * at(24) + 399.0f * at(23) + 474.0f * at(22) + 539.0f * at(21) +
+            594.0f * at(20) + 639.0f * at(19) + 674.0f * at(18) + 699.0f * at(17) + 714.0f * at(16) +
+            719.0f * at(15) + 714.0f * at(14) + 699.0f * at(13) + 674.0f * at(12) + 639.0f * at(11) +
+            594.0f * at(10) + 539.0f * at(9) + 474.0f * at(8) + 399.0f * at(7) + 314.0f * at(6) +
+            219.0f * at(5) + 114.0f * at(4) - 1.0f * at(3) - 126.0f * at(2) - 261.0f * at(1) -
+            406.0f * at(0)) / 9889.0f;
   }
-  ZF_FN static float small_pred(int m, const float* h, float x) { return m <= 0 ? sg11(h, x) : (m == 1 ? sg15(h, x) : sg21(h, x)); }
-  ZF_FN static float large_pred(int m, const float* h, float x) { return m <= 0 ? sg15(h, x) : (m == 1 ? sg21(h, x) : sg31(h, x)); }
+  template <class H> ZF_FN static float small_pred(int m, const H& at) { return m <= 0 ? sg11(at) : (m == 1 ? sg15(at) : sg21(at)); }
+  template <class H> ZF_FN static float large_pred(int m, const H& at) { return m <= 0 ? sg15(at) : (m == 1 ? sg21(at) : sg31(at)); }
+
+  // ---- the sample function, split where the .dsp's recursions are (so the wave kernel can run the feed-forward parts
+  //      with one lane per FRAME and only the recursions serially) ----------------------------------------------------
+  struct Pred { float xC_L, xC_R, pred_L, pred_R, e_norm; };
+  template <class H> ZF_FN static Pred predict(const Ctl& c, const H& aL, const H& aR) {          // :79-93 (feed-forward)
+    Pred q;
+    q.xC_L = aL(15); q.xC_R = aR(15);
+    const float small_L = small_pred(c.mode, aL), small_R = small_pred(c.mode, aR);
+    const float large_L = large_pred(c.mode, aL), large_R = large_pred(c.mode, aR);
+    const float eA = zf_max(fabsf(q.xC_L - small_L), fabsf(q.xC_R - small_R)) / (zf_max(fabsf(small_L), fabsf(small_R)) + 1e-6f);
+    const float eB = zf_max(fabsf(q.xC_L - large_L), fabsf(q.xC_R - large_R)) / (zf_max(fabsf(large_L), fabsf(large_R)) + 1e-6f);
+    const bool useA = eA <= eB;
+    q.pred_L = useA ? small_L : large_L; q.pred_R = useA ? small_R : large_R; q.e_norm = useA ? eA : eB;
+    return q;
+  }
+  // recursion 1: hpf -> env -> base (:63-75); uL = L - L@1
+  ZF_FN static void detect(float* st, const Ctl& c, float uL, float uR, float& env, float& base) {
+    const float hpL = c.a * uL + c.a * st[S_HPL];
+    const float hpR = c.a * uR + c.a * st[S_HPR];
+    st[S_HPL] = hpL; st[S_HPR] = hpR;
+    const float ehf = zf_max(fabsf(hpL), fabsf(hpR));
+    env = zf_max(st[S_ENV] * c.env_rel, ehf);
+    st[S_ENV] = env;
+    base = env * c.base_a + st[S_BASE] * c.one_m_base_a;
+    st[S_BASE] = base;
+  }
+  ZF_FN static float trigger(const Ctl& c, float env, float base, float e_norm) {                // :77,95 (feed-forward)
+    const float ratio = env / (base + 1e-12f);
+    return (float)((int)(ratio > c.ratio_thr) * (int)(e_norm > c.err_thr));
+  }
+  ZF_FN static float hold_step(float* st, const Ctl& c, float trig) {                             // recursion 2 (:98-99)
+    const float hold = zf_max(st[S_HOLD] * c.relHold, trig);
+    st[S_HOLD] = hold;
+    return hold;
+  }
+  ZF_FN static void mixdown(const Ctl& c, const Pred& q, float hold, float& oL, float& oR) {      // :100-114 (feed-forward)
+    const bool active = hold > 1e-3f;
+    const float mix_base = active ? zf_min(zf_max((q.e_norm - c.err_thr) / c.range_eps, 0.0f), 1.0f) : 0.0f;
+    const float mix = mix_base * c.mix_max;
+    const float outL = q.xC_L * (1.0f - mix) + q.pred_L * mix;
+    const float outR = q.xC_R * (1.0f - mix) + q.pred_R * mix;
+    oL = c.monitor ? outL - q.xC_L : outL;
+    oR = c.monitor ? outR - q.xC_R : outR;
+  }
 
   ZF_FN static void frame(float* st, const Ctl& c, float* x) {
     const float L = x[0], R = x[1];
     float* hL = st + S_HL;
     float* hR = st + S_HR;
-    // hpf_jsfx(a) = (_ <: (_, _@1) : -) : *(a) : (+ ~ *(a))                                     :63
-    const float hpL = c.a * (L - hL[0]) + c.a * st[S_HPL];
-    const float hpR = c.a * (R - hR[0]) + c.a * st[S_HPR];
-    st[S_HPL] = hpL; st[S_HPR] = hpR;
-    const float ehf = zf_max(fabsf(hpL), fabsf(hpR));                                           // :72
-    const float env = zf_max(st[S_ENV] * c.env_rel, ehf);                                       // :73  max ~ *(env_rel)
-    st[S_ENV] = env;
-    const float base = env * c.base_a + st[S_BASE] * c.one_m_base_a;                            // :74-75
-    st[S_BASE] = base;
-    const float ratio = env / (base + 1e-12f);                                                  // :77
-    const float xC_L = at(hL, L, 15), xC_R = at(hR, R, 15);                                     // :79-80
-    const float small_L = small_pred(c.mode, hL, L), small_R = small_pred(c.mode, hR, R);       // :82-85
-    const float large_L = large_pred(c.mode, hL, L), large_R = large_pred(c.mode, hR, R);
-    const float eA = zf_max(fabsf(xC_L - small_L), fabsf(xC_R - small_R)) / (zf_max(fabsf(small_L), fabsf(small_R)) + 1e-6f);
-    const float eB = zf_max(fabsf(xC_L - large_L), fabsf(xC_R - large_R)) / (zf_max(fabsf(large_L), fabsf(large_R)) + 1e-6f);
-    const bool useA = eA <= eB;                                                                 // :90-93
-    const float pred_L = useA ? small_L : large_L, pred_R = useA ? small_R : large_R, e_norm = useA ? eA : eB;
-    const float trig = (float)((int)(ratio > c.ratio_thr) * (int)(e_norm > c.err_thr));         // :95
-    const float hold = zf_max(st[S_HOLD] * c.relHold, trig);                                    // :98-99
-    st[S_HOLD] = hold;
-    const bool active = hold > 1e-3f;                                                           // :100
-    const float mix_base = active ? zf_min(zf_max((e_norm - c.err_thr) / c.range_eps, 0.0f), 1.0f) : 0.0f;   // :103-104
-    const float mix = mix_base * c.mix_max;
-    const float outL = xC_L * (1.0f - mix) + pred_L * mix;                                      // :107-108
-    const float outR = xC_R * (1.0f - mix) + pred_R * mix;
-    x[0] = c.monitor ? outL - xC_L : outL;                                                      // :110-114
-    x[1] = c.monitor ? outR - xC_R : outR;
+    const RegHist aL{hL, L}, aR{hR, R};
+    float env, base;
+    detect(st, c, L - hL[0], R - hR[0], env, base);
+    const Pred q = predict(c, aL, aR);
+    const float hold = hold_step(st, c, trigger(c, env, base, q.e_norm));
+    mixdown(c, q, hold, x[0], x[1]);
 #pragma unroll
     for (int d = HIST - 1; d > 0; --d) { hL[d] = hL[d - 1]; hR[d] = hR[d - 1]; }
     hL[0] = L; hR[0] = R;
   }
 };
 
-#define ZF_N(s) s
 const char* const ZfClickBeGone::names[ZfClickBeGone::NSTATE] = {
     "hpL", "hpR", "env", "base", "hold",
     "L@1", "L@2", "L@3", "L@4", "L@5", "L@6", "L@7", "L@8", "L@9", "L@10", "L@11", "L@12", "L@13", "L@14", "L@15",
     "L@16", "L@17", "L@18", "L@19", "L@20", "L@21", "L@22", "L@23", "L@24", "L@25", "L@26", "L@27", "L@28", "L@29", "L@30",
     "R@1", "R@2", "R@3", "R@4", "R@5", "R@6", "R@7", "R@8", "R@9", "R@10", "R@11", "R@12", "R@13", "R@14", "R@15",
     "R@16", "R@17", "R@18", "R@19", "R@20", "R@21", "R@22", "R@23", "R@24", "R@25", "R@26", "R@27", "R@28", "R@29", "R@30"};
-#undef ZF_N

@@ -1,0 +1,180 @@
+// clickbegone_wave.hip.h -- hand-written gfx950 kernel for Restoration/ClickBeGoneSG (BASELINE config C5: 1024 instances per
+// GPU). Same arithmetic, operation for operation, as the lane-per-instance kernel (clickbegone.hip.h) and therefore the
+// same bits; what changes is WHERE each operation runs:
+//
+//   * the .dsp is feed-forward except for four short recursions (two HPFs -> envelope -> baseline, and the hold envelope).
+//     Everything feed-forward -- the Savitzky-Golay predictors (36..52 taps per channel), the error norms with their
+//     divisions, the trigger ratio, the final mix -- is computed with ONE LANE PER FRAME, 64 frames of one instance at a
+//     time, reading the input history from an LDS row;
+//   * the recursions run ONE LANE PER INSTANCE over the 64 frames of the chunk (2 x 64 dependent steps of a few flops),
+//     exchanging per-frame values with the frame-parallel phases through LDS.
+//   A workgroup is one wavefront serving G instances (G = 1 or 4, picked from the batch size): with 1024 instances
+//   and G = 1 the chip runs 1024 wavefronts instead of the 16 a lane-per-instance mapping gives, and each spends ~12
+//   serial VALU ops per frame instead of ~150.
+//   * HBM: 8 B in + 8 B out per frame, 256-byte row segments per wave access; state is read and written once per launch.
+#pragma once
+
+#include "clickbegone.hip.h"
+
+#define ZF_CBG_FAST_NAME "zf_cbg_wave"
+
+template <int G>
+__global__ void __launch_bounds__(64) zf_cbg_wave(ZabBatch b, ZabAudio a) {
+  using L = ZfClickBeGone;
+  __shared__ float xs[G][2][96];        // [0..31]: the previous chunk's last 32 frames, [32..95]: this chunk
+  __shared__ float us[G][2][65];        // HPF input x - x@1
+  __shared__ float pp[G][5][64];        // Pred fields per frame
+  __shared__ float eb[G][2][65];        // env, base per frame
+  __shared__ float th[G][65];           // trigger, then hold, per frame
+  __shared__ L::Ctl ctls[G];
+  const int lane = threadIdx.x;
+  const int inst0 = blockIdx.x * G;
+  const int ng = (b.n_inst - inst0) < G ? (b.n_inst - inst0) : G;     // live instances of this wave (uniform)
+  const float SR = zf_sr(b.srate);
+
+  // ---- launch prologue: recursion state + constants in lane g, history rows in LDS ---------------------------------
+  float st[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  L::Ctl myc = {};
+  if (lane < ng) {
+    const int inst = inst0 + lane;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) st[k] = (float)b.vars[k * b.var_se + inst * b.var_si];
+    float par[L::NPARAM];
+#pragma unroll
+    for (int k = 0; k < L::NPARAM; ++k) par[k] = (float)b.sliders[k * b.sl_se + inst * b.sl_si];
+    myc = L::control(par, SR);
+    ctls[lane] = myc;
+    b.flags[inst] &= ~ZAB_FLAG_SLIDER_DIRTY;
+  }
+  for (int g = 0; g < ng; ++g) {
+    const int inst = inst0 + g;
+    if (lane < 32) {                                                  // xs[g][ch][32 - d] = x@d, d = 1..30 (lane = 32 - d)
+      const int d = 32 - lane;
+      float hl = 0.f, hr = 0.f;
+      if (d >= 1 && d <= L::HIST) {
+        hl = (float)b.vars[(L::S_HL + d - 1) * b.var_se + inst * b.var_si];
+        hr = (float)b.vars[(L::S_HR + d - 1) * b.var_se + inst * b.var_si];
+      }
+      xs[g][0][lane] = hl; xs[g][1][lane] = hr;
+    }
+  }
+  __syncthreads();
+
+  // the HBM read of chunk k+1 is issued before chunk k is processed (registers), so its latency hides behind the phases
+  float nxL[G], nxR[G];
+  auto fetch = [&](int64_t t0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const bool ok = g < ng && t0 + lane < a.frames;
+      const float* in = a.in + (int64_t)(inst0 + g) * 2 * a.frame_stride + t0;
+      nxL[g] = ok ? in[lane] : 0.0f;
+      nxR[g] = ok ? in[a.frame_stride + lane] : 0.0f;
+    }
+  };
+  fetch(0);
+  for (int64_t t0 = 0; t0 < a.frames; t0 += 64) {
+    const int tn = (int)((a.frames - t0 < 64) ? (a.frames - t0) : 64);
+    // ---- A: this chunk's input rows -------------------------------------------------------------------------------
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      if (g < ng) { xs[g][0][32 + lane] = nxL[g]; xs[g][1][32 + lane] = nxR[g]; }
+    }
+    fetch(t0 + 64);
+    __syncthreads();
+    // ---- B: feed-forward, lane = frame: predictors, error norms, HPF input ---------------------------------------------
+    for (int g = 0; g < ng; ++g) {
+      const L::Ctl c = ctls[g];
+      const L::RowHist aL{&xs[g][0][32 + lane]}, aR{&xs[g][1][32 + lane]};
+      const L::Pred q = L::predict(c, aL, aR);
+      pp[g][0][lane] = q.xC_L; pp[g][1][lane] = q.xC_R; pp[g][2][lane] = q.pred_L; pp[g][3][lane] = q.pred_R; pp[g][4][lane] = q.e_norm;
+      us[g][0][lane] = aL(0) - aL(1);
+      us[g][1][lane] = aR(0) - aR(1);
+    }
+    __syncthreads();
+    // ---- C: recursion 1, lane = instance -------------------------------------------------------------------------------
+    if (lane < ng) {
+      if (tn == 64) {                                                 // full chunk: straight-line code, LDS reads up front
+        float ul[64], ur[64];
+#pragma unroll
+        for (int n = 0; n < 64; ++n) { ul[n] = us[lane][0][n]; ur[n] = us[lane][1][n]; }
+#pragma unroll
+        for (int n = 0; n < 64; ++n) {
+          float env, base;
+          L::detect(st, myc, ul[n], ur[n], env, base);
+          eb[lane][0][n] = env; eb[lane][1][n] = base;
+        }
+      } else {
+        for (int n = 0; n < tn; ++n) {
+          float env, base;
+          L::detect(st, myc, us[lane][0][n], us[lane][1][n], env, base);
+          eb[lane][0][n] = env; eb[lane][1][n] = base;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- D: feed-forward: trigger --------------------------------------------------------------------------------------
+    for (int g = 0; g < ng; ++g) th[g][lane] = L::trigger(ctls[g], eb[g][0][lane], eb[g][1][lane], pp[g][4][lane]);
+    __syncthreads();
+    // ---- E: recursion 2, lane = instance -------------------------------------------------------------------------------
+    if (lane < ng) {
+      if (tn == 64) {
+        float tr[64];
+#pragma unroll
+        for (int n = 0; n < 64; ++n) tr[n] = th[lane][n];
+#pragma unroll
+        for (int n = 0; n < 64; ++n) th[lane][n] = L::hold_step(st, myc, tr[n]);
+      } else {
+        for (int n = 0; n < tn; ++n) th[lane][n] = L::hold_step(st, myc, th[lane][n]);
+      }
+    }
+    __syncthreads();
+    // ---- F: feed-forward: mix and store; roll the history rows ----------------------------------------------------------
+    for (int g = 0; g < ng; ++g) {
+      const L::Ctl c = ctls[g];
+      L::Pred q;
+      q.xC_L = pp[g][0][lane]; q.xC_R = pp[g][1][lane]; q.pred_L = pp[g][2][lane]; q.pred_R = pp[g][3][lane]; q.e_norm = pp[g][4][lane];
+      float oL, oR;
+      L::mixdown(c, q, th[g][lane], oL, oR);
+      float* out = a.out + (int64_t)(inst0 + g) * 2 * a.frame_stride + t0;
+      if (lane < tn) { out[lane] = oL; out[a.frame_stride + lane] = oR; }
+      // frames tn-32 .. tn-1 of the extended row become the next chunk's (or the next launch's) history
+      float keepL = 0.f, keepR = 0.f;
+      if (lane < 32) { keepL = xs[g][0][tn + lane]; keepR = xs[g][1][tn + lane]; }
+      __syncthreads();
+      if (lane < 32) { xs[g][0][lane] = keepL; xs[g][1][lane] = keepR; }
+    }
+    __syncthreads();
+  }
+
+  // ---- launch epilogue ----------------------------------------------------------------------------------------------------
+  if (lane < ng) {
+    const int inst = inst0 + lane;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) b.vars[k * b.var_se + inst * b.var_si] = (double)st[k];
+  }
+  for (int g = 0; g < ng; ++g) {
+    const int inst = inst0 + g;
+    if (lane < 32) {
+      const int d = 32 - lane;
+      if (d >= 1 && d <= L::HIST) {
+        b.vars[(L::S_HL + d - 1) * b.var_se + inst * b.var_si] = (double)xs[g][0][lane];
+        b.vars[(L::S_HR + d - 1) * b.var_se + inst * b.var_si] = (double)xs[g][1][lane];
+      }
+    }
+  }
+}
+
+static int zf_cbg_pick_g(int n_inst) {
+  // measured on MI355X (48 000 frames): N=1024: G=1 3.6 ms, G=4 8.3 ms; N=4096: 8.6 / 8.7 ms; N=16384: G=4 21 ms
+  int g = n_inst <= 4096 ? 1 : 4;
+  if (const char* e = getenv("ZAB_CBG_G")) { const int v = atoi(e); if (v == 1 || v == 4) g = v; }
+  return g;
+}
+static int32_t zf_cbg_applies(const ZabBatch*, const ZabAudio* a) { return a->frames > 0 ? 1 : 0; }
+static hipError_t zf_cbg_launch(const ZabBatch* b, const ZabAudio* a, hipStream_t st) {
+  const int g = zf_cbg_pick_g(b->n_inst);
+  const dim3 grid((b->n_inst + g - 1) / g), block(64);
+  if (g == 1) hipLaunchKernelGGL(zf_cbg_wave<1>, grid, block, 0, st, *b, *a);
+  else hipLaunchKernelGGL(zf_cbg_wave<4>, grid, block, 0, st, *b, *a);
+  return hipGetLastError();
+}
