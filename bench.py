@@ -144,6 +144,7 @@ def main() -> int:
     # device duration of each launch of the timed region: HIP event pairs recorded on the engine's own stream
     kernel_ms = eng.timing_history(min(args.steps, 64))
     used_fast = eng.used_fast_path()
+    kernel_name = eng.last_kernel_name()
     import sharding
     job = sharding.reduce_stats(sharding.RunStats(elapsed_s=elapsed, units=float(n_inst) * NCH * frames * args.steps),
                                 dist, device="cuda" if dist is not None else None)
@@ -187,12 +188,12 @@ def main() -> int:
             "data": "synthetic",
             "config": {"workload": f"DDT x{n_inst} instances per GPU, defaults, 48 kHz stereo, {frames} frames white noise, block={BLOCK}",
                        "leaf": "Spatialization/DDT", "instances_total": world * n_inst, "frames_per_step": frames,
-                       "kernel": "zab_ddt_fast" if used_fast else "zab_DDT_process", "sharding": f"instances x{world}, no collective"},
+                       "kernel": kernel_name, "sharding": f"instances x{world}, no collective"},
             "mframes_per_s": total_samples / NCH / elapsed / 1e6,
             "realtime_factor_per_instance": frames / SRATE / (elapsed / args.steps),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "zab_ddt_fast" if used_fast else "zab_DDT_process", "kernel_ms": k_ms,
+                         "kernel": kernel_name, "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": alg, "bytes_per_frame": alg / (n_inst * frames)},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -150,6 +150,9 @@ int zab_last_timing(zab_engine* e, double* kernel_ms, int32_t* launches);
 int zab_timing_history(zab_engine* e, double* kernel_ms, int32_t max_entries);
 void* zab_stream(zab_engine* e);   /* hipStream_t of the engine */
 int zab_used_fast_path(zab_engine* e); /* 1 if the most recent zab_process ran the leaf's hand-written kernel */
+/* Name of the kernel the most recent zab_process launched (as rocprofv3 --kernel-trace lists it; templated kernels by the
+ * substring before the template arguments). Valid until the next zab_process on any engine of the same leaf. */
+const char* zab_last_kernel_name(zab_engine* e);
 
 #ifdef __cplusplus
 }

@@ -33,7 +33,8 @@
 #include <mutex>
 #include <type_traits>
 
-#define ZA_FAST_KERNEL_NAME "zab_ddt_fast"   /* + _nw2 / _nw4 / _nw8: waves per instance */
+static char ddt_kernel_name[24] = "zab_ddt_fast";   /* + _nw2 / _nw4 / _nw8 once a launch has picked the waves per instance */
+#define ZA_FAST_KERNEL_NAME ddt_kernel_name
 #define DDT_KF 4                       /* frames per lane */
 #define DDT_CHUNK (64 * DDT_KF)        /* frames per wave iteration */
 #define DDT_MAXTAPS 64
@@ -56,12 +57,18 @@ __device__ __forceinline__ double ddt_readlane(double v, int l) {
   t.y = __builtin_amdgcn_readlane(t.y, l);
   return __builtin_bit_cast(double, t);
 }
-// DPP move of a double; lanes without a source (or masked out by ROWS) receive 0.
+// DPP move of a double; lanes without a source (or masked out by ROWS) receive 0. With every row enabled the old value of
+// the destination is never kept (bound_ctrl zero-fills), so the plain mov form is used and no zero has to be materialised.
 template <int CTRL, int ROWS>
 __device__ __forceinline__ double ddt_dpp(double v) {
   int2 t = __builtin_bit_cast(int2, v);
-  t.x = __builtin_amdgcn_update_dpp(0, t.x, CTRL, ROWS, 0xF, true);
-  t.y = __builtin_amdgcn_update_dpp(0, t.y, CTRL, ROWS, 0xF, true);
+  if (ROWS == 0xF) {
+    t.x = __builtin_amdgcn_mov_dpp(t.x, CTRL, 0xF, 0xF, true);
+    t.y = __builtin_amdgcn_mov_dpp(t.y, CTRL, 0xF, 0xF, true);
+  } else {
+    t.x = __builtin_amdgcn_update_dpp(0, t.x, CTRL, ROWS, 0xF, true);
+    t.y = __builtin_amdgcn_update_dpp(0, t.y, CTRL, ROWS, 0xF, true);
+  }
   return __builtin_bit_cast(double, t);
 }
 #define DDT_ROW_SHR(n) (0x110 | (n))
@@ -320,10 +327,11 @@ __device__ __forceinline__ void ddt_phase_c(const DdtCtx& C, DdtChunk& K, int la
     s0 = s0 > 8.0 ? 8.0 : (s0 < -8.0 ? -8.0 : s0);
     s1 = s1 > 8.0 ? 8.0 : (s1 < -8.0 ? -8.0 : s1);
     o0[k] = (float)s0; o1[k] = (float)s1;
-    const double s_dir = 0.5 * (fabs(dirZL) + fabs(dirZR));
-    const double s_ear = 0.5 * (fabs(eZL) + fabs(eZR));
-    const double s_lat = 0.5 * (fabs(lZL) + fabs(lZR));
-    const double s_tot = s_dir + s_ear + s_lat;
+    // meters (:510-531): the 0.5 of s_dir/s_ear/s_lat is applied once to the reduced sums (exact: a power of two), and
+    // the s_tot one-pole, being linear, is the sum of the three (final reduction)
+    const double s_dir2 = fabs(dirZL) + fabs(dirZR);
+    const double s_ear2 = fabs(eZL) + fabs(eZR);
+    const double s_lat2 = fabs(lZL) + fabs(lZR);
     const double adL = fabs(dL), adR = fabs(dR);
     // c = dL*dR / max(1e-7, |dL||dR| + 1e-7) (:534): the divisor is within [1e-7, ~1e2], so a hardware reciprocal
     // refined by two Newton steps (~1e-16 relative) replaces the full IEEE division sequence; c only feeds a meter.
@@ -333,17 +341,17 @@ __device__ __forceinline__ void ddt_phase_c(const DdtCtx& C, DdtChunk& K, int la
     rc = __builtin_fma(__builtin_fma(-den, rc, 1.0), rc, rc);
     const double cc = (dL * dR) * rc;
     // lane-local one-pole with zero start == sum_k val_k * (1-a) a^(3-k): linear, so accumulate with weights
-    zM[0] = __builtin_fma(cwM[k], s_dir, zM[0]);
-    zM[1] = __builtin_fma(cwM[k], s_ear, zM[1]);
-    zM[2] = __builtin_fma(cwM[k], s_lat, zM[2]);
-    zM[3] = __builtin_fma(cwM[k], s_tot, zM[3]);
+    zM[0] = __builtin_fma(cwM[k], s_dir2, zM[0]);
+    zM[1] = __builtin_fma(cwM[k], s_ear2, zM[1]);
+    zM[2] = __builtin_fma(cwM[k], s_lat2, zM[2]);
     zM[4] = __builtin_fma(cwM[k], adL, zM[4]);
     zM[5] = __builtin_fma(cwM[k], adR, zM[5]);
     zC = __builtin_fma(cwC[k], __builtin_fmin(__builtin_fmax(cc, -1.0), 1.0), zC);
     if (want_last && k == DDT_KF - 1 && lane == 63) {
       double* V = C.V;
       V[ZA_VAR_yL] = yL; V[ZA_VAR_yR] = yR; V[ZA_VAR_oL] = oL; V[ZA_VAR_oR] = oR;
-      V[ZA_VAR_s_dir] = s_dir; V[ZA_VAR_s_ear] = s_ear; V[ZA_VAR_s_lat] = s_lat; V[ZA_VAR_s_tot] = s_tot;
+      const double s_dir = 0.5 * s_dir2, s_ear = 0.5 * s_ear2, s_lat = 0.5 * s_lat2;
+      V[ZA_VAR_s_dir] = s_dir; V[ZA_VAR_s_ear] = s_ear; V[ZA_VAR_s_lat] = s_lat; V[ZA_VAR_s_tot] = s_dir + s_ear + s_lat;
       V[ZA_VAR_dL] = dL; V[ZA_VAR_dR] = dR; V[ZA_VAR_c] = cc;
       C.SPL[0] = s0; C.SPL[1] = s1;
     }
@@ -572,6 +580,8 @@ __device__ __forceinline__ void ddt_fast_body(const ZabBatch& b, const ZabAudio&
     double tot[7] = {0, 0, 0, 0, 0, 0, 0};
     for (int u = 0; u < NW; ++u)
       for (int q = 0; q < 7; ++q) tot[q] += mred[u * 7 + q];
+    tot[0] *= 0.5; tot[1] *= 0.5; tot[2] *= 0.5;
+    tot[3] = tot[0] + tot[1] + tot[2];
     const double pM = pow(aM, (double)frames), pC = pow(aC, (double)frames);
     V[ZA_VAR_m_dirE] = pM * V[ZA_VAR_m_dirE] + tot[0];
     V[ZA_VAR_m_earlyE] = pM * V[ZA_VAR_m_earlyE] + tot[1];
@@ -700,6 +710,7 @@ static hipError_t za_launch_fast(const ZabBatch* b, const ZabAudio* a, hipStream
     (void)hipFuncSetAttribute((const void*)zab_ddt_fast_nw8, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
   });
   const dim3 grid(b->n_inst), block(64 * nw);
+  snprintf(ddt_kernel_name, sizeof ddt_kernel_name, nw == 1 ? "zab_ddt_fast" : "zab_ddt_fast_nw%d", nw);
   switch (nw) {
     case 1: hipLaunchKernelGGL(zab_ddt_fast, grid, block, lds, st, *b, *a, W); break;
     case 2: hipLaunchKernelGGL(zab_ddt_fast_nw2, grid, block, lds, st, *b, *a, W); break;

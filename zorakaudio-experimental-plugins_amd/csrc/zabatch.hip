@@ -576,5 +576,10 @@ int zab_timing_history(zab_engine* e, double* kernel_ms, int32_t max_entries) {
 void* zab_stream(zab_engine* e) { return e ? (void*)e->stream : nullptr; }
 
 int zab_used_fast_path(zab_engine* e) { return e && e->used_fast ? 1 : 0; }
+const char* zab_last_kernel_name(zab_engine* e) {
+  if (!e) return "";
+  const char* n = e->used_fast ? e->mod->fast_kernel_name : e->mod->generic_kernel_name;
+  return n ? n : "";
+}
 
 }  // extern "C"

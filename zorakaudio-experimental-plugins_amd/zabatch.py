@@ -50,7 +50,7 @@ ABI_SYMBOLS = [
     "zab_var_index", "zab_set_sliders", "zab_get_sliders", "zab_prepare", "zab_process", "zab_sync", "zab_read_vars",
     "zab_read_mem", "zab_write_mem", "zab_read_mem_high", "zab_device_alloc", "zab_device_free", "zab_device_upload",
     "zab_device_download", "zab_device_noise", "zab_last_timing", "zab_timing_history", "zab_stream",
-    "zab_used_fast_path", "zab_gmem_read", "zab_gmem_write", "zab_gmem_seq", "zab_pool_upload",
+    "zab_used_fast_path", "zab_last_kernel_name", "zab_gmem_read", "zab_gmem_write", "zab_gmem_seq", "zab_pool_upload",
 ]
 
 _lib = None
@@ -95,6 +95,8 @@ def load_runtime():
     L.zab_timing_history.argtypes = [vp, C.POINTER(d), i32]
     L.zab_stream.restype = vp; L.zab_stream.argtypes = [vp]
     L.zab_used_fast_path.argtypes = [vp]
+    L.zab_last_kernel_name.argtypes = [vp]
+    L.zab_last_kernel_name.restype = C.c_char_p
     L.zab_gmem_read.argtypes = [vp, i64, i64, C.POINTER(d)]
     L.zab_gmem_write.argtypes = [vp, i64, i64, C.POINTER(d)]
     L.zab_gmem_seq.argtypes = [vp, i64, C.POINTER(C.c_uint64)]
@@ -249,6 +251,9 @@ class Engine:
 
     def used_fast_path(self) -> bool:
         return bool(self.L.zab_used_fast_path(self.h))
+
+    def last_kernel_name(self) -> str:
+        return self.L.zab_last_kernel_name(self.h).decode()
 
     # -- state
     def read_vars(self, first=0, count=None) -> np.ndarray:
