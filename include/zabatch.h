@@ -117,6 +117,30 @@ int zab_read_mem(zab_engine* e, int32_t first, int32_t count, int64_t start, int
 int zab_write_mem(zab_engine* e, int32_t first, int32_t count, int64_t start, int64_t n, const double* src);
 int zab_read_mem_high(zab_engine* e, int32_t first, int32_t count, int64_t* dst); /* write high-water marks */
 
+/* Single-instance state exchange in the layout of the reference's DSPJSFX_State (dsp_jsfx_aot.py:5991-6025) and raw
+ * section calls: what a per-leaf shim exporting jsfx_init / jsfx_slider / jsfx_block / jsfx_sample / jsfx_process_block
+ * (prototypes dsp_jsfx_aot.py:6088-6102) needs so that src/JSFXJuceProcessor.cpp can link against this engine unchanged
+ * (zajit/shim.py generates that shim). Null pointers skip a field. Both calls synchronise.
+ * MIDI queues and runtimeOpaque are host-side objects and are not mirrored. */
+typedef struct zab_host_state {
+  double* spl;                    /* [64]   DSPJSFX_State::spl */
+  double* sliders;                /* [64]   ::sliders */
+  double* vars;                   /* [nvars] ::vars */
+  double* mem;                    /* [mem_n] ::mem (host allocation, src/JSFXJuceProcessor.cpp:8958-8963) */
+  int64_t mem_n;                  /*        ::memN; at most zab_info.mem_cap cells are exchanged */
+  int64_t* pending_masks;         /* [3]    pendingSlider{Change,Automate,AutomateEnd}Mask */
+  uint32_t* rand_mt;              /* [624]  ::randMT */
+  uint32_t* rand_index;           /*        ::randIndex */
+  int64_t* slider_visible_mask;   /*        ::sliderVisibleMask */
+  int32_t* slider_visibility_init;/*        ::sliderVisibilityInit */
+} zab_host_state;
+int zab_state_upload(zab_engine* e, int32_t instance, const zab_host_state* h);
+int zab_state_download(zab_engine* e, int32_t instance, zab_host_state* h);
+enum { ZAB_SECTION_INIT = 0, ZAB_SECTION_SLIDER = 1, ZAB_SECTION_BLOCK = 2, ZAB_SECTION_SAMPLE = 3 };
+/* Run one section on every instance exactly as a direct call of the generated section function would: no state
+ * reset, no slider-alias sync, spl[] untouched by the wrapper. samplesblock = st->samplesblock for the call. */
+int zab_run_section(zab_engine* e, int32_t section, int32_t samplesblock);
+
 /* gmem[] segment of the engine (leaves that use gmem; reference: DspJsfxGmemAttachment, src/DspJsfxGmem.cpp).
  * One segment of 1 Mi cells per engine, shared by all its instances. read/write move raw doubles; seq returns the
  * write-sequence counter of a 1024-cell page, or the global one for page < 0. */

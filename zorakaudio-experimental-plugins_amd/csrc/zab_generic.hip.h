@@ -208,6 +208,29 @@ extern "C" __global__ void __launch_bounds__(64) ZA_KERNEL(slider)(ZabBatch b) {
   b.flags[inst] &= ~ZAB_FLAG_SLIDER_DIRTY;
 }
 
+// Single-section entry for the jsfx_init/jsfx_slider/jsfx_block/jsfx_sample compatibility shim (include/zabatch.h,
+// zab_run_section): the raw section on the state as it stands, no reset, no float conversion -- what a direct call of
+// the reference's generated section function does (dsp_jsfx_aot.py:4188).
+extern "C" __global__ void __launch_bounds__(64) ZA_KERNEL(section)(ZabBatch b, int which, double samplesblock) {
+  const int inst = blockIdx.x * 64 + threadIdx.x;
+  if (inst >= b.n_inst) return;
+  ZaS s;
+  za_state_load(s, b, inst);
+  s.samplesblock = samplesblock;
+  s.block_size = (int)samplesblock;
+  switch (which) {
+    case 0: za_section_init(s); break;
+    case 1: za_section_slider(s); break;
+    case 2: za_section_block(s); break;
+    default: za_section_sample(s); break;
+  }
+  za_state_store(s, b, inst);
+}
+static hipError_t za_launch_section(const ZabBatch* b, int which, double samplesblock, hipStream_t st) {
+  hipLaunchKernelGGL(ZA_KERNEL(section), dim3((b->n_inst + 63) / 64), dim3(64), 0, st, *b, which, samplesblock);
+  return hipGetLastError();
+}
+
 static hipError_t za_launch_slider(const ZabBatch* b, hipStream_t st) {
   hipLaunchKernelGGL(ZA_KERNEL(slider), dim3((b->n_inst + 63) / 64), dim3(64), 0, st, *b);
   return hipGetLastError();

@@ -6,7 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define ZAB_MODULE_ABI 7
+#define ZAB_MODULE_ABI 8
 
 enum { ZAB_FLAG_SLIDER_DIRTY = 1u, ZAB_FLAG_PREPARED = 2u };
 
@@ -69,6 +69,8 @@ struct ZabModule {
   hipError_t (*launch_fast)(const ZabBatch*, const ZabAudio*, hipStream_t);
   const char* fast_kernel_name;
   const char* generic_kernel_name;
+  // one raw section (0 init, 1 slider, 2 block, 3 sample) on every instance; null for leaves without sections (Faust)
+  hipError_t (*launch_section)(const ZabBatch*, int which, double samplesblock, hipStream_t);
 };
 
 extern "C" const ZabModule* zab_module_get(void);

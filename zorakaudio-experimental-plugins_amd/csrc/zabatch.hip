@@ -63,6 +63,18 @@ __global__ void zab_k_noise(float* dst, int n_inst, int nch, int64_t frames, int
     }
 }
 
+// ---- one instance's strided state <-> a contiguous staging buffer (zab_state_upload / zab_state_download) ----------
+template <class T>
+__global__ void zab_k_gather(const T* base, int64_t se, int64_t n, T* staging) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) staging[k] = base[k * se];
+}
+template <class T>
+__global__ void zab_k_scatter(T* base, int64_t se, int64_t n, const T* staging) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) base[k * se] = staging[k];
+}
+
 }  // namespace
 
 struct zab_engine {
@@ -83,6 +95,8 @@ struct zab_engine {
   unsigned long long *gmem_cells = nullptr, *gmem_page_seq = nullptr, *gmem_global_seq = nullptr;
   uint64_t gmem_cell_count = 0;
   uint32_t pool_generation = 0;
+  void* state_stage = nullptr;      // device staging for zab_state_upload/download
+  int64_t state_stage_bytes = 0;
   float* stage_in = nullptr;
   float* stage_out = nullptr;
   int64_t stage_bytes = 0;
@@ -226,6 +240,7 @@ int zab_destroy(zab_engine* e) {
   for (void* p : e->owned) hipFree(p);
   if (e->stage_in) hipFree(e->stage_in);
   if (e->stage_out) hipFree(e->stage_out);
+  if (e->state_stage) hipFree(e->state_stage);
   for (int i = 0; i < zab_engine::kTimingSlots; ++i) {
     if (e->ev0[i]) hipEventDestroy(e->ev0[i]);
     if (e->ev1[i]) hipEventDestroy(e->ev1[i]);
@@ -574,6 +589,108 @@ int zab_timing_history(zab_engine* e, double* kernel_ms, int32_t max_entries) {
   return (int)have;
 }
 void* zab_stream(zab_engine* e) { return e ? (void*)e->stream : nullptr; }
+
+// ---- single-instance state exchange + raw section calls (the jsfx_* compatibility shim sits on these) -----------------
+extern "C++" {
+#define HIP_TRYW(w, expr)                                                                                   \
+  do {                                                                                                      \
+    hipError_t e_ = (expr);                                                                                 \
+    if (e_ != hipSuccess) return fail(ZAB_E_HIP, "[%s] %s failed: %s", w, #expr, hipGetErrorString(e_));    \
+  } while (0)
+static int ensure_state_stage(zab_engine* e, int64_t bytes) {
+  const char* what = "staging";
+  if (bytes <= e->state_stage_bytes) return ZAB_OK;
+  if (e->state_stage) (void)hipFree(e->state_stage);
+  e->state_stage = nullptr; e->state_stage_bytes = 0;
+  HIP_TRYW(what, hipMalloc(&e->state_stage, (size_t)bytes));
+  e->state_stage_bytes = bytes;
+  return ZAB_OK;
+}
+template <class T>
+static int put_strided(zab_engine* e, const char* what, T* base, int64_t se, int64_t n, const T* src) {
+  if (!src || n <= 0) return ZAB_OK;
+  if (se == 1) { HIP_TRYW(what, hipMemcpyAsync(base, src, sizeof(T) * n, hipMemcpyHostToDevice, e->stream)); return ZAB_OK; }
+  int rc = ensure_state_stage(e, (int64_t)sizeof(T) * n);
+  if (rc) return rc;
+  HIP_TRYW(what, hipMemcpyAsync(e->state_stage, src, sizeof(T) * n, hipMemcpyHostToDevice, e->stream));
+  hipLaunchKernelGGL(zab_k_scatter<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, base, se, n, (const T*)e->state_stage);
+  HIP_TRYW(what, hipGetLastError());
+  HIP_TRYW(what, hipStreamSynchronize(e->stream));      // the staging buffer is reused by the next field
+  return ZAB_OK;
+}
+template <class T>
+static int get_strided(zab_engine* e, const char* what, const T* base, int64_t se, int64_t n, T* dst) {
+  if (!dst || n <= 0) return ZAB_OK;
+  if (se == 1) { HIP_TRYW(what, hipMemcpyAsync(dst, base, sizeof(T) * n, hipMemcpyDeviceToHost, e->stream)); HIP_TRYW(what, hipStreamSynchronize(e->stream)); return ZAB_OK; }
+  int rc = ensure_state_stage(e, (int64_t)sizeof(T) * n);
+  if (rc) return rc;
+  hipLaunchKernelGGL(zab_k_gather<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, base, se, n, (T*)e->state_stage);
+  HIP_TRYW(what, hipGetLastError());
+  HIP_TRYW(what, hipMemcpyAsync(dst, e->state_stage, sizeof(T) * n, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRYW(what, hipStreamSynchronize(e->stream));
+  return ZAB_OK;
+}
+}  // extern "C++"
+
+int zab_state_upload(zab_engine* e, int32_t inst, const zab_host_state* h) {
+  if (!e || !h || inst < 0 || inst >= e->b.n_inst) return fail(ZAB_E_ARG, "zab_state_upload: bad argument");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  ZabBatch& b = e->b;
+  int rc;
+  if ((rc = put_strided(e, "spl", b.spl + inst * b.sl_si, b.sl_se, 64, h->spl))) return rc;
+  if ((rc = put_strided(e, "sliders", b.sliders + inst * b.sl_si, b.sl_se, 64, h->sliders))) return rc;
+  if ((rc = put_strided(e, "vars", b.vars + inst * b.var_si, b.var_se, e->mod->nvars, h->vars))) return rc;
+  if (h->mem) {
+    const int64_t n = h->mem_n < b.mem_cap ? h->mem_n : b.mem_cap;
+    if ((rc = put_strided(e, "mem", b.mem + inst * b.mem_si, b.mem_se, n, h->mem))) return rc;
+  }
+  if (h->pending_masks) {
+    for (int k = 0; k < 3; ++k) HIP_TRY(hipMemcpyAsync(b.pend + (int64_t)k * b.n_pad + inst, h->pending_masks + k, 8, hipMemcpyHostToDevice, e->stream));
+  }
+  if ((rc = put_strided(e, "randMT", b.mt + inst * b.mt_si, b.mt_se, 624, h->rand_mt))) return rc;
+  if (h->rand_index) HIP_TRY(hipMemcpyAsync(b.mti + inst, h->rand_index, 4, hipMemcpyHostToDevice, e->stream));
+  if (h->slider_visible_mask) HIP_TRY(hipMemcpyAsync(b.vis_mask + inst, h->slider_visible_mask, 8, hipMemcpyHostToDevice, e->stream));
+  if (h->slider_visibility_init) HIP_TRY(hipMemcpyAsync(b.vis_init + inst, h->slider_visibility_init, 4, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->b.epoch++;
+  e->prepared = true;              // the host's state object is authoritative: it has run (or will run) the sections itself
+  return ZAB_OK;
+}
+
+int zab_state_download(zab_engine* e, int32_t inst, zab_host_state* h) {
+  if (!e || !h || inst < 0 || inst >= e->b.n_inst) return fail(ZAB_E_ARG, "zab_state_download: bad argument");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  const ZabBatch& b = e->b;
+  int rc;
+  if ((rc = get_strided(e, "spl", b.spl + inst * b.sl_si, b.sl_se, 64, h->spl))) return rc;
+  if ((rc = get_strided(e, "sliders", b.sliders + inst * b.sl_si, b.sl_se, 64, h->sliders))) return rc;
+  if ((rc = get_strided(e, "vars", b.vars + inst * b.var_si, b.var_se, e->mod->nvars, h->vars))) return rc;
+  if (h->mem) {
+    const int64_t n = h->mem_n < b.mem_cap ? h->mem_n : b.mem_cap;
+    if ((rc = get_strided(e, "mem", b.mem + inst * b.mem_si, b.mem_se, n, h->mem))) return rc;
+  }
+  if (h->pending_masks) {
+    for (int k = 0; k < 3; ++k) HIP_TRY(hipMemcpy(h->pending_masks + k, b.pend + (int64_t)k * b.n_pad + inst, 8, hipMemcpyDeviceToHost));
+  }
+  if ((rc = get_strided(e, "randMT", b.mt + inst * b.mt_si, b.mt_se, 624, h->rand_mt))) return rc;
+  if (h->rand_index) HIP_TRY(hipMemcpy(h->rand_index, b.mti + inst, 4, hipMemcpyDeviceToHost));
+  if (h->slider_visible_mask) HIP_TRY(hipMemcpy(h->slider_visible_mask, b.vis_mask + inst, 8, hipMemcpyDeviceToHost));
+  if (h->slider_visibility_init) HIP_TRY(hipMemcpy(h->slider_visibility_init, b.vis_init + inst, 4, hipMemcpyDeviceToHost));
+  return ZAB_OK;
+}
+
+int zab_run_section(zab_engine* e, int32_t section, int32_t samplesblock) {
+  if (!e || section < ZAB_SECTION_INIT || section > ZAB_SECTION_SAMPLE) return fail(ZAB_E_ARG, "zab_run_section: bad argument");
+  if (!e->mod->launch_section) return fail(ZAB_E_UNSUPPORTED, "zab_run_section: %s has no JSFX sections", e->mod->name);
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  hipError_t he = e->mod->launch_section(&e->b, section, (double)samplesblock, e->stream);
+  if (he != hipSuccess) return fail(ZAB_E_HIP, "section launch failed: %s", hipGetErrorString(he));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->prepared = true;              // the caller drives the @init/@slider sequence itself
+  e->b.epoch++;
+  return check_device_errors(e, "zab_run_section");
+}
 
 int zab_used_fast_path(zab_engine* e) { return e && e->used_fast ? 1 : 0; }
 const char* zab_last_kernel_name(zab_engine* e) {

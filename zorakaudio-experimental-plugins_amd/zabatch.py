@@ -50,7 +50,7 @@ ABI_SYMBOLS = [
     "zab_var_index", "zab_set_sliders", "zab_get_sliders", "zab_prepare", "zab_process", "zab_sync", "zab_read_vars",
     "zab_read_mem", "zab_write_mem", "zab_read_mem_high", "zab_device_alloc", "zab_device_free", "zab_device_upload",
     "zab_device_download", "zab_device_noise", "zab_last_timing", "zab_timing_history", "zab_stream",
-    "zab_used_fast_path", "zab_last_kernel_name", "zab_gmem_read", "zab_gmem_write", "zab_gmem_seq", "zab_pool_upload",
+    "zab_used_fast_path", "zab_last_kernel_name", "zab_state_upload", "zab_state_download", "zab_run_section", "zab_gmem_read", "zab_gmem_write", "zab_gmem_seq", "zab_pool_upload",
 ]
 
 _lib = None
