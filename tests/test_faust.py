@@ -104,3 +104,56 @@ def test_gpu_matches_restatement(leaf, variant, monkeypatch):
         err = np.abs(y[i].astype(np.float64) - want).max()
         assert err <= tol, (leaf, i, err)
         assert np.abs(st[i] - r.state()).max() <= tol, (leaf, i)
+
+
+def _build_host(key, tmp_path):
+    import subprocess
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    pkg = root / "zorakaudio-experimental-plugins_amd"
+    hdr = pkg / "_gen" / f"{key}_mydsp.h"
+    if not hdr.exists():
+        pytest.skip("adapter header not generated")
+    exe = tmp_path / f"faust_host_{key}"
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", f'-DZAB_MYDSP_HEADER="{hdr.name}"', "-I", str(hdr.parent),
+                        "-I", str(root / "include"), str(root / "tests" / "hosts" / "faust_host.cpp"), "-o", str(exe),
+                        "-L", str(pkg / "lib"), "-lzabatch", f"-Wl,-rpath,{pkg / 'lib'}"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+@pytest.mark.parametrize("key", sorted(FAUST))
+def test_mydsp_adapter_compiles_against_the_faust_interface(key, tmp_path):
+    """the generated class is a `dsp` (same virtuals as the reference's faust_support_min.h) and registers the
+    .dsp's UI zones in order; buildUserInterface needs no GPU."""
+    import subprocess
+    exe = _build_host(key, tmp_path)
+    out = subprocess.run([str(exe), "-", "-", "0", "1", "48000"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    got = [ln.rsplit("=", 1) for ln in out.stdout.splitlines() if ln]
+    from zajit import faust
+    meta = __import__("zabatch").leaf_meta(key)
+    assert [g[0] for g in got] == [meta["sliders"][str(i)]["label"] for i in range(len(got))]
+    assert [float(g[1]) for g in got] == [meta["sliders"][str(i)]["default"] for i in range(len(got))]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("key", sorted(FAUST))
+def test_mydsp_adapter_runs_the_leaf(key, tmp_path):
+    import subprocess
+    import zabatch
+    fr = _ref()
+    exe = _build_host(key, tmp_path)
+    frames, block = 2500, 512
+    x = _noise([77], frames)[0]
+    x[:, 1200:] *= 0.05
+    (tmp_path / "in.f32").write_bytes(np.ascontiguousarray(x).tobytes())
+    meta = zabatch.leaf_meta(key)
+    zones = list(FAUST[key])
+    args = [f'{meta["sliders"][str(i)]["label"]}={zones[i]}' for i in range(len(zones))]
+    r = subprocess.run([str(exe), str(tmp_path / "in.f32"), str(tmp_path / "out.f32"), str(frames), str(block), "48000"] + args,
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and not r.stderr, r.stderr
+    y = np.frombuffer((tmp_path / "out.f32").read_bytes(), dtype=np.float32).reshape(2, frames)
+    want = fr.FaustRef(key, 48000).compute(x, np.array(zones, np.float32), block=block)
+    assert np.abs(y.astype(np.float64) - want).max() <= (0.0 if key == "ClickBeGoneSG" else 1e-6)
