@@ -14,7 +14,7 @@ import numpy as np
 
 HERE = Path(__file__).resolve().parent
 OUT = HERE / "_port"
-LEAVES = {"ClickBeGoneSG": 0, "ModTilt": 1}
+LEAVES = {"ClickBeGoneSG": 0, "ModTilt": 1, "GTS": 2, "VAR": 3, "RED": 4}
 
 
 def lib_path() -> Path:
@@ -68,6 +68,6 @@ class FaustRef:
         return y
 
     def state(self) -> np.ndarray:
-        o = np.zeros(256, dtype=np.float32)
+        o = np.zeros(1024, dtype=np.float32)
         n = self.L.fref_state(self.leaf, self.st, o.ctypes.data_as(C.POINTER(C.c_float)))
         return o[:n].copy()

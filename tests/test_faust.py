@@ -11,7 +11,22 @@ The GPU kernels are compared with the restatement: bit-exact where only + - * / 
 import numpy as np
 import pytest
 
-FAUST = {"ClickBeGoneSG": [50, 50, 1500, 1, 0], "ModTilt": [-4.5, 3.0, 0.8]}
+FAUST = {"ClickBeGoneSG": [50, 50, 1500, 1, 0], "ModTilt": [-4.5, 3.0, 0.8], "GTS": [1.5, 6.0, -4.0, 0.9, -2.0],
+         "VAR": [60, 70, -55], "RED": [14, 60, 300]}
+NCH = {"RED": 6}
+# bit-exact where only + - * / max min sqrt (and f64-evaluated, once-rounded libm calls) are involved; GTS evaluates ~129
+# expf per sample with the platform's own expf on each side
+TOL = {"ClickBeGoneSG": 0.0, "ModTilt": 1e-6, "GTS": 2e-6, "VAR": 1e-6, "RED": 1e-6}
+
+
+def _input(leaf, ids, frames):
+    """[len(ids), nch, frames] noise; RED gets wet (1/2), aux (3/4) and a reference pair (5/6) that goes silent half way."""
+    x = _noise(ids, frames)
+    if NCH.get(leaf, 2) == 6:
+        ref = 0.2 * _noise([i + 1000 for i in ids], frames)
+        ref[:, :, frames // 2:] = 0.0
+        x = np.concatenate([x, 0.1 * x[:, ::-1], ref], axis=1)
+    return np.ascontiguousarray(x)
 
 
 def _noise(ids, frames):
@@ -67,7 +82,25 @@ def test_modtilt_zero_tilt_is_identity_and_blocks_do_not_matter():
 
 
 VARIANTS = [("ClickBeGoneSG", "generic"), ("ClickBeGoneSG", "wave1"), ("ClickBeGoneSG", "wave4"),
-            ("ModTilt", "generic")]
+            ("ModTilt", "generic"), ("GTS", "generic"), ("VAR", "generic"), ("RED", "generic")]
+
+
+def test_gts_var_red_restatement_properties():
+    """Properties that follow from the .dsp texts: GTS's Gaussian kernel has unit DC gain (a settled DC input comes out as
+    DC x sustain gain x output gain); VAR with Air Amount 0 and RED with Amount 0 dB are bit-exact pass-throughs, and RED never
+    touches channels 3..6."""
+    fr = _ref()
+    dc = np.full((2, 30000), 0.25, np.float32)
+    y = fr.FaustRef("GTS", 48000).compute(dc, [2.0, 3.0, -6.0, 1.0, 0.0])
+    assert abs(float(y[0, -1]) - 0.25 * 10 ** (-6 / 20)) < 1e-4
+    x = _noise([9], 4000)[0]
+    assert np.array_equal(fr.FaustRef("VAR", 48000).compute(x, [0, 50, -60]), x)
+    assert np.abs(fr.FaustRef("VAR", 48000).compute(x, [100, 100, -90]) - x).max() > 1e-3
+    x6 = _input("RED", [9], 6000)[0]
+    y6 = fr.FaustRef("RED", 48000).compute(x6, [0, 50, 350])
+    assert np.array_equal(y6, x6)
+    y6 = fr.FaustRef("RED", 48000).compute(x6, [24, 100, 350])
+    assert np.array_equal(y6[2:], x6[2:]) and np.abs(y6[:2] - x6[:2]).max() > 1e-2
 
 
 @pytest.mark.gpu
@@ -82,14 +115,20 @@ def test_gpu_matches_restatement(leaf, variant, monkeypatch):
         monkeypatch.setenv("ZAB_CBG_G", variant[4:])
         path = zabatch.ZAB_PATH_FAST
     n, frames = 70, 3000                                  # two workgroups, ragged tile tail
-    x = _noise(range(40, 40 + n), frames)
-    x[:, :, 1500:] *= 0.02                                # a quiet half so both branches of the detectors are exercised
+    x = _input(leaf, list(range(40, 40 + n)), frames)
+    x[:, :2, 1500:] *= 0.02                               # a quiet half so both branches of the detectors are exercised
     rows = np.zeros((n, 64)); rows[:, :len(FAUST[leaf])] = FAUST[leaf]
     if leaf == "ClickBeGoneSG":
         rows[:, 0] = np.linspace(0, 100, n); rows[:, 1] = np.linspace(100, 0, n); rows[:, 3] = np.arange(n) % 3
         rows[:, 4] = (np.arange(n) // 3) % 2
-    else:
+    elif leaf == "ModTilt":
         rows[:, 0] = np.linspace(-6, 3, n); rows[:, 1] = np.linspace(2, 5, n); rows[:, 2] = np.linspace(0, 1, n)
+    elif leaf == "GTS":
+        rows[:, 0] = np.linspace(0.1, 8, n); rows[:, 1] = np.linspace(-12, 12, n); rows[:, 3] = np.linspace(0, 1, n)
+    elif leaf == "VAR":
+        rows[:, 0] = np.linspace(0, 100, n); rows[:, 1] = np.linspace(100, 0, n); rows[:, 2] = np.linspace(-90, -30, n)
+    else:
+        rows[:, 0] = np.linspace(0, 24, n); rows[:, 1] = np.linspace(0, 100, n); rows[:, 2] = np.linspace(50, 1200, n)
     with zabatch.Engine(leaf, n, path=path) as e:
         e.set_sliders(rows); e.prepare()
         y1 = e.process_host(x[:, :, :1700], block=512)
@@ -97,8 +136,8 @@ def test_gpu_matches_restatement(leaf, variant, monkeypatch):
         y2 = e.process_host(x[:, :, 1700:], block=512)    # state carried across launches
         st = e.read_vars()
     y = np.concatenate([y1, y2], axis=2)
-    tol = 0.0 if leaf == "ClickBeGoneSG" else 1e-6
-    for i in range(n):
+    tol = TOL[leaf]
+    for i in (range(n) if leaf != "GTS" else range(0, n, 6)):     # (the GTS restatement costs ~130 expf per sample)
         r = fr.FaustRef(leaf, 48000)
         want = r.compute(x[i], rows[i, :8].astype(np.float32))
         err = np.abs(y[i].astype(np.float64) - want).max()
@@ -145,8 +184,8 @@ def test_mydsp_adapter_runs_the_leaf(key, tmp_path):
     fr = _ref()
     exe = _build_host(key, tmp_path)
     frames, block = 2500, 512
-    x = _noise([77], frames)[0]
-    x[:, 1200:] *= 0.05
+    x = _input(key, [77], frames)[0]
+    x[:2, 1200:] *= 0.05
     (tmp_path / "in.f32").write_bytes(np.ascontiguousarray(x).tobytes())
     meta = zabatch.leaf_meta(key)
     zones = list(FAUST[key])
@@ -154,6 +193,6 @@ def test_mydsp_adapter_runs_the_leaf(key, tmp_path):
     r = subprocess.run([str(exe), str(tmp_path / "in.f32"), str(tmp_path / "out.f32"), str(frames), str(block), "48000"] + args,
                        capture_output=True, text=True)
     assert r.returncode == 0 and not r.stderr, r.stderr
-    y = np.frombuffer((tmp_path / "out.f32").read_bytes(), dtype=np.float32).reshape(2, frames)
+    y = np.frombuffer((tmp_path / "out.f32").read_bytes(), dtype=np.float32).reshape(NCH.get(key, 2), frames)
     want = fr.FaustRef(key, 48000).compute(x, np.array(zones, np.float32), block=block)
-    assert np.abs(y.astype(np.float64) - want).max() <= (0.0 if key == "ClickBeGoneSG" else 1e-6)
+    assert np.abs(y.astype(np.float64) - want).max() <= TOL[key]
