@@ -11,9 +11,16 @@
 //     fft.c:1086-1176 (the "two for one" real transform)
 // Known answers: tests/golden/wdl_fft.npz (produced by the reference WDL build).
 //
-// The transform itself is this repo's own: an iterative radix-2 decimation-in-time FFT in a per-instance scratch buffer
-// (natural order), then a scatter into the WDL order. One lane executes one instance's transform (generic kernels);
-// a wave-cooperative / MFMA batched variant for large STFT workloads is a later-round kernel.
+// The transform itself is this repo's own: an iterative radix-2 decimation-in-time FFT (natural order), then a scatter
+// into the WDL order. Two execution forms with identical arithmetic per butterfly (hence identical bits):
+//   * wave-cooperative (device, n <= 4096 complex): the generic kernels run one INSTANCE per lane, so a call site is
+//     reached by up to 64 lanes, each wanting its own transform. The lanes that reached the call take the requests one
+//     by one (ballot / readlane broadcast of the requester's base, size and mem pointer) and work on each together:
+//     the buffer is staged in a 64 KiB LDS array, every pass's n/2 butterflies are spread over the participating
+//     lanes, and the result is written back in the order the builtin defines. fft / ifft / fft_permute / fft_ipermute.
+//   * serial (CPU port; device for n > 4096 and for the real transforms): one lane, per-instance scratch in HBM.
+// (A 64 x 64 DFT-as-GEMM on the f64 MFMA pipe was priced and rejected: 4 real 64^3 GEMMs per stage x 2 stages = 4.2 Mflop
+// against 0.25 Mflop for the radix-2 FFT of 4096 points, for a matrix pipe that is only 2x the f64 vector rate.)
 #pragma once
 
 #include "zart.h"
@@ -24,17 +31,10 @@
 
 // cos/sin(2*pi*j/ZA_FFT_MAX), j < ZA_FFT_MAX/2; filled once per process by za_fft_table_init (host) / init kernel (device)
 #if defined(__HIPCC__)
+#define ZA_FFT_COOP_MAX 4096
 __device__ double za_fft_cos[ZA_FFT_MAX / 2];
 __device__ double za_fft_sin[ZA_FFT_MAX / 2];
-extern "C" __global__ void za_fft_table_kernel() {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < ZA_FFT_MAX / 2) {
-    double sn, cs;
-    sincos(6.283185307179586476925286766559 * (double)j / (double)ZA_FFT_MAX, &sn, &cs);
-    za_fft_cos[j] = cs;
-    za_fft_sin[j] = sn;
-  }
-}
+__device__ uint16_t za_fft_perm[2 * ZA_FFT_COOP_MAX];     // [n + i] = natural bin stored at position i of an n-point transform
 #else
 static double za_fft_cos[ZA_FFT_MAX / 2];
 static double za_fft_sin[ZA_FFT_MAX / 2];
@@ -75,6 +75,24 @@ ZA_FN uint32_t za_bitrev(uint32_t v, int bits) {
 }
 ZA_FN int za_log2(uint32_t n) { int b = 0; while ((1u << b) < n) ++b; return b; }
 
+#if defined(__HIPCC__)
+// fills the twiddle and permutation tables once per process (launched by the module before its first prepare)
+extern "C" __global__ void za_fft_table_kernel() {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < ZA_FFT_MAX / 2) {
+    double sn, cs;
+    sincos(6.283185307179586476925286766559 * (double)j / (double)ZA_FFT_MAX, &sn, &cs);
+    za_fft_cos[j] = cs;
+    za_fft_sin[j] = sn;
+  }
+  if (j >= ZA_FFT_MIN && j < 2 * ZA_FFT_COOP_MAX) {      // j = n + i with n the largest power of two <= j
+    uint32_t n = ZA_FFT_MIN;
+    while (2 * n <= (uint32_t)j) n <<= 1;
+    za_fft_perm[j] = (uint16_t)za_fft_bin_of_pos((uint32_t)j - n, n);
+  }
+}
+#endif
+
 ZA_FN bool za_fft_pow2(int64_t n) { return n >= ZA_FFT_MIN && n <= ZA_FFT_MAX && (n & (n - 1)) == 0; }
 ZA_FN bool za_fft_in_page(int64_t base, int64_t span) {
   if (base < 0 || span <= 0) return false;
@@ -100,6 +118,135 @@ ZA_FN bool za_fft_region(S& s, double baseD, int64_t span, int64_t& base, int64_
 
 #define ZA_M(a) s.mem[(a) * s.mem_stride]
 #define ZA_F(a) s.fft[(a) * s.fft_stride]
+
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+enum { ZA_COOP_FFT = 0, ZA_COOP_IFFT = 1, ZA_COOP_PERMUTE = 2, ZA_COOP_IPERMUTE = 3 };
+__device__ __forceinline__ int64_t za_readlane64(int64_t v, int l) {
+  const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffff), l), hi = __builtin_amdgcn_readlane((int)(v >> 32), l);
+  return ((int64_t)hi << 32) | (uint32_t)lo;
+}
+// Every lane that reached the builtin calls this (converged at the call site); `ok` says whether this lane has a valid
+// request (base, n). Returns true for the lanes whose request was served here.
+template <class S>
+__device__ __noinline__ bool za_fft_coop(S& s, bool ok, int64_t base, int n, int op) {
+  __shared__ double buf[2 * ZA_FFT_COOP_MAX];
+  __shared__ double tw[ZA_FFT_COOP_MAX];           // (cos, sin)(2 pi j / ZA_FFT_COOP_MAX), j < ZA_FFT_COOP_MAX / 2
+  __shared__ int tw_ready;                         // (LDS is not initialised: the magic value marks a staged table)
+  const bool mine = ok && n <= ZA_FFT_COOP_MAX;
+  const uint64_t active = __ballot(1);
+  uint64_t todo = __ballot(mine);
+  const int lane = (int)(threadIdx.x & 63);
+  const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
+  const int rank = __popcll(active & below), nact = __popcll(active);
+  // LDS survives between workgroups, so the marker alone could be a leftover: two table entries are checked with it
+  const int twk = ZA_FFT_COOP_MAX / 2 - 1, twq = ZA_FFT_MAX / ZA_FFT_COOP_MAX;
+  if (todo && (op == ZA_COOP_FFT || op == ZA_COOP_IFFT) &&
+      !(tw_ready == 0x5a17ab1e && tw[2] == za_fft_cos[twq] && tw[2 * twk + 1] == za_fft_sin[twk * twq])) {
+    // twiddles of the largest cooperative size, staged once per workgroup launch (the HBM table is 1 us away per read)
+    for (int j = rank; j < ZA_FFT_COOP_MAX / 2; j += nact) {
+      tw[2 * j] = za_fft_cos[j * (ZA_FFT_MAX / ZA_FFT_COOP_MAX)];
+      tw[2 * j + 1] = za_fft_sin[j * (ZA_FFT_MAX / ZA_FFT_COOP_MAX)];
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (rank == 0) tw_ready = 0x5a17ab1e;
+    __builtin_amdgcn_wave_barrier();
+  }
+  while (todo) {
+    const int l = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    double* const mp = (double*)za_readlane64((int64_t)(uintptr_t)s.mem, l);
+    const int64_t ms = za_readlane64(s.mem_stride, l), bl = za_readlane64(base, l);
+    const int nl = __builtin_amdgcn_readlane(n, l);
+    const int bits = za_log2((uint32_t)nl);
+#define ZA_G(a) mp[(bl + (a)) * ms]
+    // ---- stage the request's buffer in LDS, in the order its transform wants ----------------------------------------
+    // (eight HBM reads in flight per lane: one read per trip would cost a full memory latency per element)
+    for (int i0 = rank; i0 < nl; i0 += 8 * nact) {
+      double vr[8], vi[8];
+      uint32_t pm[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * nact;
+        const bool in = i < nl;
+        vr[u] = in ? ZA_G(2 * i) : 0.0;
+        vi[u] = in ? ZA_G(2 * i + 1) : 0.0;
+        pm[u] = (in && (op == ZA_COOP_IFFT || op == ZA_COOP_PERMUTE)) ? za_fft_perm[nl + i] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * nact;
+        if (i < nl) {
+          uint32_t dst;
+          if (op == ZA_COOP_FFT) dst = za_bitrev((uint32_t)i, bits);
+          else if (op == ZA_COOP_IFFT) dst = za_bitrev(pm[u], bits);
+          else if (op == ZA_COOP_PERMUTE) dst = pm[u];
+          else dst = (uint32_t)i;
+          buf[2 * dst] = vr[u];
+          buf[2 * dst + 1] = vi[u];
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (op == ZA_COOP_FFT || op == ZA_COOP_IFFT) {
+      const int sign = op == ZA_COOP_FFT ? -1 : +1;
+      for (int len = 2; len <= nl; len <<= 1) {
+        const int half = len >> 1, step = ZA_FFT_COOP_MAX / len;
+        // four independent butterflies per trip: all their LDS reads are issued before the first store, which the
+        // compiler cannot do by itself (it must assume the stores alias the next reads)
+        for (int idx0 = rank; idx0 < (nl >> 1); idx0 += 4 * nact) {
+          double ar[4], ai[4], br[4], bi[4], wr[4], wi[4];
+          int pa[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int idx = idx0 + u * nact;
+            const int ix = idx < (nl >> 1) ? idx : 0;
+            const int j = ix & (half - 1), i = ((ix - j) << 1) + j;          // butterfly (i, i + half) of group ix / half
+            pa[u] = idx < (nl >> 1) ? 2 * i : -1;
+            wr[u] = tw[2 * j * step]; wi[u] = tw[2 * j * step + 1];
+            ar[u] = buf[2 * i]; ai[u] = buf[2 * i + 1];
+            br[u] = buf[2 * (i + half)]; bi[u] = buf[2 * (i + half) + 1];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const double w_i = sign < 0 ? -wi[u] : wi[u];
+            const double tr = br[u] * wr[u] - bi[u] * w_i, ti = br[u] * w_i + bi[u] * wr[u];
+            if (pa[u] >= 0) {
+              const int a = pa[u], b = pa[u] + 2 * half;
+              buf[a] = ar[u] + tr; buf[a + 1] = ai[u] + ti;
+              buf[b] = ar[u] - tr; buf[b + 1] = ai[u] - ti;
+            }
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    // ---- write back in the order the builtin defines -------------------------------------------------------------------
+    for (int i0 = rank; i0 < nl; i0 += 8 * nact) {
+      uint32_t src[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * nact;
+        src[u] = (uint32_t)i;
+        if (i < nl && (op == ZA_COOP_FFT || op == ZA_COOP_IPERMUTE)) src[u] = za_fft_perm[nl + i];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * nact;
+        if (i < nl) {
+          ZA_G(2 * i) = buf[2 * src[u]];
+          ZA_G(2 * i + 1) = buf[2 * src[u] + 1];
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+#undef ZA_G
+  }
+  return mine;
+}
+#define ZA_FFT_TRY_COOP(op) if (za_fft_coop(s, ok, base, (int)n, op)) return 0.0
+#else
+#define ZA_FFT_TRY_COOP(op) (void)0
+#endif
 
 // natural-order in-scratch DIT butterflies on n complex values (already stored bit-reversed); sign = -1 forward, +1 inverse
 template <class S>
@@ -152,22 +299,28 @@ ZA_FN void za_fft_inv_core(S& s, int64_t base, int n) {
 
 template <class S> ZA_NOINLINE double za_fft(S& s, double baseD, double sizeD) {
   const int64_t n = za_round_idx(sizeD);
-  int64_t base;
-  if (!za_fft_pow2(n) || !za_fft_region(s, baseD, 2 * n, base, 2 * n)) return 0.0;
+  int64_t base = 0;
+  const bool ok = za_fft_pow2(n) && za_fft_region(s, baseD, 2 * n, base, 2 * n);
+  ZA_FFT_TRY_COOP(ZA_COOP_FFT);
+  if (!ok) return 0.0;
   za_fft_fwd_core(s, base, (int)n);
   return 0.0;
 }
 template <class S> ZA_NOINLINE double za_ifft(S& s, double baseD, double sizeD) {
   const int64_t n = za_round_idx(sizeD);
-  int64_t base;
-  if (!za_fft_pow2(n) || !za_fft_region(s, baseD, 2 * n, base, 2 * n)) return 0.0;
+  int64_t base = 0;
+  const bool ok = za_fft_pow2(n) && za_fft_region(s, baseD, 2 * n, base, 2 * n);
+  ZA_FFT_TRY_COOP(ZA_COOP_IFFT);
+  if (!ok) return 0.0;
   za_fft_inv_core(s, base, (int)n);
   return 0.0;
 }
 template <class S> ZA_NOINLINE double za_fft_permute(S& s, double baseD, double sizeD) {   // WDL order -> natural
   const int64_t n = za_round_idx(sizeD);
-  int64_t base;
-  if (!za_fft_pow2(n) || !za_fft_region(s, baseD, 2 * n, base, 2 * n)) return 0.0;
+  int64_t base = 0;
+  const bool ok = za_fft_pow2(n) && za_fft_region(s, baseD, 2 * n, base, 2 * n);
+  ZA_FFT_TRY_COOP(ZA_COOP_PERMUTE);
+  if (!ok) return 0.0;
   for (int i = 0; i < (int)n; ++i) {
     const uint32_t k = za_fft_bin_of_pos((uint32_t)i, (uint32_t)n);
     ZA_F(2 * k) = ZA_M(base + 2 * i);
@@ -178,8 +331,10 @@ template <class S> ZA_NOINLINE double za_fft_permute(S& s, double baseD, double 
 }
 template <class S> ZA_NOINLINE double za_fft_ipermute(S& s, double baseD, double sizeD) {  // natural -> WDL order
   const int64_t n = za_round_idx(sizeD);
-  int64_t base;
-  if (!za_fft_pow2(n) || !za_fft_region(s, baseD, 2 * n, base, 2 * n)) return 0.0;
+  int64_t base = 0;
+  const bool ok = za_fft_pow2(n) && za_fft_region(s, baseD, 2 * n, base, 2 * n);
+  ZA_FFT_TRY_COOP(ZA_COOP_IPERMUTE);
+  if (!ok) return 0.0;
   for (int i = 0; i < 2 * (int)n; ++i) ZA_F(i) = ZA_M(base + i);
   for (int i = 0; i < (int)n; ++i) {
     const uint32_t k = za_fft_bin_of_pos((uint32_t)i, (uint32_t)n);
