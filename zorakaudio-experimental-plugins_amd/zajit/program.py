@@ -399,6 +399,42 @@ class Program:
         return any(n in self.calls for n in names)
 
 
+# Section validity of host-coupled builtins: the rule table and the message text of the reference's
+# validate_builtin_sections (dsp_jsfx_aot.py:1544-1605), applied like there to the calls written directly in a section
+# (after user functions were specialised, so calls inside function bodies are not visited). The reference's own comm and
+# sample-pool tests pin the messages (scripts/run_dsp-jsfx_commtests.py:65-66, run_dsp-jsfx_sample_pool_tests.py:60).
+_BLOCK_ONLY = {"msg_send", "msg_sendto", "msg_recv", "msg_send_buf", "msg_sendto_buf", "msg_recv_buf", "msg_avail", "msg_kind",
+               "msg_length", "msg_dropped", "msg_clear", "msg_peer_count", "msg_peer_id", "msg_peer_name", "msg_peer_uid",
+               "msg_peer_caps", "msg_peer_alive", "gmem_get", "gmem_put", "gmem_fill", "gmem_zero", "gmem_copy",
+               "sample_export_mem", "sample_export_mem2"}
+_SETUP = {"comm_join", "msg_subscribe", "msg_unsubscribe", "msg_advertise", "instance_set_name", "instance_get_name",
+          "instance_uid", "gmem_attach", "gmem_attach_size", "track_name", "track_name_available", "track_name_seq",
+          "host_track_name", "host_track_name_available", "host_track_name_seq", "sample_pool_from_slot",
+          "sample_pool_set_mode", "sample_pool_set_budget_mb", "sample_pool_commit", "instance_id"}
+_POOL_RUNTIME = {"sample_pool_state", "sample_pool_selected", "sample_pool_loaded", "sample_pool_failed", "sample_pool_ram_mb",
+                 "sample_pool_generation", "sample_get", "sample_len", "sample_channels", "sample_srate", "sample_peak",
+                 "sample_rms", "sample_preview_bins", "sample_read", "sample_read_interp", "sample_read2",
+                 "sample_read2_interp", "sample_preview_read", "sample_name"}
+
+
+def validate_builtin_sections(programs) -> None:
+    def visit(section, n):
+        if isinstance(n, S.Call):
+            fn = n.fn
+            if fn in _BLOCK_ONLY and section != "block":
+                raise S.JsfxSyntaxError(f"{fn}() is only valid in @block at {n.line}:{n.col}")
+            if fn in _SETUP and section not in ("init", "slider", "block"):
+                raise S.JsfxSyntaxError(f"{fn}() is only valid in @init, @slider, or @block at {n.line}:{n.col}")
+            if fn in _POOL_RUNTIME and section not in ("init", "slider", "block", "sample"):
+                raise S.JsfxSyntaxError(f"{fn}() is only valid in @init, @slider, @block, or @sample at {n.line}:{n.col}")
+        for c in S.children(n):
+            visit(section, c)
+
+    for section, nodes in programs.items():
+        for node in nodes:
+            visit(section, node)
+
+
 def analyse(text: str, name: str = "jsfx") -> Program:
     secs = split_sections(text)
     progs = {}
@@ -409,6 +445,7 @@ def analyse(text: str, name: str = "jsfx") -> Program:
         else:
             progs[sec] = []
     progs, fns = lower_functions(progs)
+    validate_builtin_sections(progs)
     vars_ = collect_vars(progs, fns)
     opts = parse_options(text)
     decls = parse_slider_decls(text)
