@@ -14,9 +14,16 @@ pytestmark = pytest.mark.gpu
 CASES = sorted(p.stem for p in GOLDEN.glob("*_default.npz") if not p.stem.startswith("DDT"))
 
 
+@pytest.mark.parametrize("ipw", ["auto", "64", "4"])
 @pytest.mark.parametrize("case", CASES)
-def test_leaf_matches_reference_vm(case):
+def test_leaf_matches_reference_vm(case, ipw, monkeypatch):
+    """ipw = instances per wavefront of the lane-per-instance kernels (the engine spreads small batches over more wavefronts;
+    ZAB_IPW pins it so that full, partial and single-lane wavefronts are all exercised)."""
     import zabatch
+    if ipw != "auto":
+        monkeypatch.setenv("ZAB_IPW", ipw)
+    else:
+        monkeypatch.delenv("ZAB_IPW", raising=False)
     leaf = leaf_of(case)
     if not zabatch.module_path(leaf).exists():
         pytest.skip(f"module for {leaf} not built")

@@ -82,7 +82,8 @@ def test_modtilt_zero_tilt_is_identity_and_blocks_do_not_matter():
 
 
 VARIANTS = [("ClickBeGoneSG", "generic"), ("ClickBeGoneSG", "wave1"), ("ClickBeGoneSG", "wave4"),
-            ("ModTilt", "generic"), ("GTS", "generic"), ("VAR", "generic"), ("RED", "generic")]
+            ("ModTilt", "generic"), ("GTS", "generic"), ("VAR", "generic"), ("RED", "generic"),
+            ("ClickBeGoneSG", "generic64"), ("ModTilt", "generic64"), ("RED", "generic64")]   # 64 instances per wavefront
 
 
 def test_gts_var_red_restatement_properties():
@@ -111,6 +112,9 @@ def test_gpu_matches_restatement(leaf, variant, monkeypatch):
     import zabatch
     fr = _ref()
     path = zabatch.ZAB_PATH_GENERIC
+    monkeypatch.delenv("ZAB_IPW", raising=False)
+    if variant == "generic64":
+        monkeypatch.setenv("ZAB_IPW", "64")
     if variant.startswith("wave"):
         monkeypatch.setenv("ZAB_CBG_G", variant[4:])
         path = zabatch.ZAB_PATH_FAST

@@ -5,7 +5,7 @@
 // and stdfaust.lib are not part of the reference tree, so every leaf here is a hand-written restatement of its .dsp
 // (csrc/faust/<leaf>.hip.h, citing the .dsp lines) -- "parity unpinned", see DESIGN.md.
 //
-// Mapping: ONE LANE PER INSTANCE, 64 instances per single-wave workgroup; the leaf's recursive state (a few floats and short
+// Mapping: ONE LANE PER INSTANCE, b.ipw (<= 64, see zab_generic.hip.h) instances per single-wave workgroup; the leaf's recursive state (a few floats and short
 // delay lines) stays in registers for the whole launch. Audio is instance-major planar, so a wave stages a
 // [NCH][64 instances][TT frames] tile through LDS exactly like the JSFX generic kernel (zab_generic.hip.h): HBM accesses
 // are 128-byte row segments, the per-lane walk is bank-conflict free (+1 padding). In and out alias (in-place), as in
@@ -35,8 +35,8 @@ ZF_FN float zf_sr(double srate) { return fminf(192000.0f, fmaxf(1.0f, (float)(in
 
 template <class L>
 __global__ void __launch_bounds__(64) zf_prepare(ZabBatch b) {   // dsp->init(sampleRate): instanceClear
-  const int inst = blockIdx.x * 64 + threadIdx.x;
-  if (inst >= b.n_inst) return;
+  const int inst = blockIdx.x * b.ipw + threadIdx.x;
+  if ((int)threadIdx.x >= b.ipw || inst >= b.n_inst) return;
 #pragma unroll
   for (int k = 0; k < L::NSTATE; ++k) b.vars[k * b.var_se + inst * b.var_si] = 0.0;
   b.flags[inst] = ZAB_FLAG_PREPARED;
@@ -46,9 +46,10 @@ template <class L, int TT>
 __global__ void __launch_bounds__(64) zf_process(ZabBatch b, ZabAudio a) {
   __shared__ float tile[L::NCH][64][TT + 1];
   const int lane = threadIdx.x;
-  const int inst0 = blockIdx.x * 64;
+  const int ipw = b.ipw;
+  const int inst0 = blockIdx.x * ipw;
   const int inst = inst0 + lane;
-  const bool active = inst < b.n_inst;
+  const bool active = lane < ipw && inst < b.n_inst;
   float st[L::NSTATE];
   float par[L::NPARAM];
   typename L::Ctl ctl;
@@ -62,11 +63,23 @@ __global__ void __launch_bounds__(64) zf_process(ZabBatch b, ZabAudio a) {
   }
   for (int64_t t0 = 0; t0 < a.frames; t0 += TT) {
     const int tn = (int)((a.frames - t0 < TT) ? (a.frames - t0) : TT);
-    for (int idx = lane; idx < 64 * L::NCH * TT; idx += 64) {
-      const int t = idx % TT, rc = idx / TT, ch = rc % L::NCH, row = rc / L::NCH;
-      float x = 0.0f;
-      if (t < tn && inst0 + row < b.n_inst) x = a.in[((int64_t)(inst0 + row) * L::NCH + ch) * a.frame_stride + t0 + t];
-      tile[ch][row][t] = x;
+    // eight HBM reads in flight per lane (one read per trip costs a full memory latency per tile element)
+    for (int idx0 = lane; idx0 < ipw * L::NCH * TT; idx0 += 8 * 64) {
+      float xv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = idx0 + 64 * u;
+        const int t = idx % TT, rc = idx / TT, ch = rc % L::NCH, row = rc / L::NCH;
+        xv[u] = 0.0f;
+        if (idx < ipw * L::NCH * TT && t < tn && inst0 + row < b.n_inst)
+          xv[u] = a.in[((int64_t)(inst0 + row) * L::NCH + ch) * a.frame_stride + t0 + t];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = idx0 + 64 * u;
+        const int t = idx % TT, rc = idx / TT, ch = rc % L::NCH, row = rc / L::NCH;
+        if (idx < ipw * L::NCH * TT) tile[ch][row][t] = xv[u];
+      }
     }
     __syncthreads();
     if (active) {
@@ -80,7 +93,7 @@ __global__ void __launch_bounds__(64) zf_process(ZabBatch b, ZabAudio a) {
       }
     }
     __syncthreads();
-    for (int idx = lane; idx < 64 * L::NCH * TT; idx += 64) {
+    for (int idx = lane; idx < ipw * L::NCH * TT; idx += 64) {
       const int t = idx % TT, rc = idx / TT, ch = rc % L::NCH, row = rc / L::NCH;
       if (t < tn && inst0 + row < b.n_inst)
         a.out[((int64_t)(inst0 + row) * L::NCH + ch) * a.frame_stride + t0 + t] = tile[ch][row][t];
@@ -94,12 +107,12 @@ __global__ void __launch_bounds__(64) zf_process(ZabBatch b, ZabAudio a) {
 }
 
 template <class L> static hipError_t zf_launch_prepare(const ZabBatch* b, hipStream_t st) {
-  hipLaunchKernelGGL(zf_prepare<L>, dim3((b->n_inst + 63) / 64), dim3(64), 0, st, *b);
+  hipLaunchKernelGGL(zf_prepare<L>, dim3((b->n_inst + b->ipw - 1) / b->ipw), dim3(64), 0, st, *b);
   return hipGetLastError();
 }
 template <class L> static hipError_t zf_launch_process(const ZabBatch* b, const ZabAudio* a, hipStream_t st) {
   constexpr int TT = L::NCH <= 2 ? 64 : (L::NCH <= 4 ? 32 : 16);
-  hipLaunchKernelGGL((zf_process<L, TT>), dim3((b->n_inst + 63) / 64), dim3(64), 0, st, *b, *a);
+  hipLaunchKernelGGL((zf_process<L, TT>), dim3((b->n_inst + b->ipw - 1) / b->ipw), dim3(64), 0, st, *b, *a);
   return hipGetLastError();
 }
 template <class L> static hipError_t zf_launch_slider(const ZabBatch*, hipStream_t) { return hipSuccess; }   // constants are per launch

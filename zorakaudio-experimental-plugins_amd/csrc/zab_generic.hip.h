@@ -1,7 +1,9 @@
 // zab_generic.hip.h -- translator back end: the generic gfx950 kernels every leaf module gets.
 //
 // Included at the end of a generated module source, after the ZA_* defines, zart.h and the zajit section code.
-// Mapping: ONE LANE PER INSTANCE, 64 instances per single-wave workgroup. Each lane keeps its DSPJSFX_State
+// Mapping: ONE LANE PER INSTANCE, b.ipw (<= 64) instances per single-wave workgroup. A wave costs the same whether 1 or 64
+// of its lanes are live, so small batches are spread thin (ipw = 1 at 1024 instances: 1024 wavefronts, one per SIMD of
+// the chip, instead of 16 full ones) and only batches beyond ~64 Ki instances fill every lane. Each lane keeps its DSPJSFX_State
 // (vars / used sliders / used spl) in registers for the whole launch and walks the host blocks serially, exactly
 // as jsfx_process_block does (dsp_jsfx_aot.py:5713-5905):
 //     samplesblock = n; @block; if any pending slider mask -> @slider; for each frame: f32->f64 spl[], @sample,
@@ -34,6 +36,10 @@
 #endif
 
 typedef ZaState<ZA_NV> ZaS;
+
+#ifndef ZA_KERNEL_ENTRY
+#define ZA_KERNEL_ENTRY() (void)0      /* leaves with FFT builtins reset their LDS twiddle flag here (zart_fft.h) */
+#endif
 
 __device__ __forceinline__ void za_state_bind(ZaS& s, const ZabBatch& b, int inst) {
   s.srate = b.srate;
@@ -109,8 +115,9 @@ __device__ __forceinline__ void za_alias_sync(ZaS& s) {
 // prepareToPlay(): resetStateStructOnly (vars/spl zeroed, mem kept) -> sliders already pushed -> @init ->
 // alias re-apply -> @slider.   src/JSFXJuceProcessor.cpp:3251,3302-3318
 extern "C" __global__ void __launch_bounds__(64) ZA_KERNEL(prepare)(ZabBatch b) {
-  const int inst = blockIdx.x * 64 + threadIdx.x;
-  if (inst >= b.n_inst) return;
+  ZA_KERNEL_ENTRY();
+  const int inst = blockIdx.x * b.ipw + threadIdx.x;
+  if ((int)threadIdx.x >= b.ipw || inst >= b.n_inst) return;
   ZaS s;
   za_state_bind(s, b, inst);
 #pragma unroll
@@ -135,13 +142,15 @@ extern "C" __global__ void __launch_bounds__(64) ZA_KERNEL(prepare)(ZabBatch b) 
 }
 
 extern "C" __global__ void __launch_bounds__(64) ZA_KERNEL(process)(ZabBatch b, ZabAudio a) {
+  ZA_KERNEL_ENTRY();
 #if ZA_NCH > 0
   __shared__ float tile[ZA_NCH][64][ZA_TT + 1];
 #endif
   const int lane = threadIdx.x;
-  const int inst0 = blockIdx.x * 64;
+  const int ipw = b.ipw;
+  const int inst0 = blockIdx.x * ipw;
   const int inst = inst0 + lane;
-  const bool active = inst < b.n_inst;
+  const bool active = lane < ipw && inst < b.n_inst;
   ZaS s;
   if (active) {
     za_state_load(s, b, inst);
@@ -162,12 +171,23 @@ extern "C" __global__ void __launch_bounds__(64) ZA_KERNEL(process)(ZabBatch b, 
 #if ZA_HAS_SAMPLE && ZA_NCH > 0
     for (int t0 = 0; t0 < n; t0 += ZA_TT) {
       const int tn = (n - t0 < ZA_TT) ? (n - t0) : ZA_TT;
-      for (int idx = lane; idx < 64 * ZA_NCH * ZA_TT; idx += 64) {
-        const int t = idx % ZA_TT, rc = idx / ZA_TT, ch = rc % ZA_NCH, row = rc / ZA_NCH;
-        float x = 0.0f;
-        if (t < tn && inst0 + row < b.n_inst)
-          x = a.in[((int64_t)(inst0 + row) * ZA_NCH + ch) * a.frame_stride + pos + t0 + t];
-        tile[ch][row][t] = x;
+      // eight HBM reads in flight per lane (one read per trip costs a full memory latency per tile element)
+      for (int idx0 = lane; idx0 < ipw * ZA_NCH * ZA_TT; idx0 += 8 * 64) {
+        float xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int idx = idx0 + 64 * u;
+          const int t = idx % ZA_TT, rc = idx / ZA_TT, ch = rc % ZA_NCH, row = rc / ZA_NCH;
+          xv[u] = 0.0f;
+          if (idx < ipw * ZA_NCH * ZA_TT && t < tn && inst0 + row < b.n_inst)
+            xv[u] = a.in[((int64_t)(inst0 + row) * ZA_NCH + ch) * a.frame_stride + pos + t0 + t];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int idx = idx0 + 64 * u;
+          const int t = idx % ZA_TT, rc = idx / ZA_TT, ch = rc % ZA_NCH, row = rc / ZA_NCH;
+          if (idx < ipw * ZA_NCH * ZA_TT) tile[ch][row][t] = xv[u];
+        }
       }
       __syncthreads();
       if (active) {
@@ -182,7 +202,7 @@ extern "C" __global__ void __launch_bounds__(64) ZA_KERNEL(process)(ZabBatch b, 
         }
       }
       __syncthreads();
-      for (int idx = lane; idx < 64 * ZA_NCH * ZA_TT; idx += 64) {
+      for (int idx = lane; idx < ipw * ZA_NCH * ZA_TT; idx += 64) {
         const int t = idx % ZA_TT, rc = idx / ZA_TT, ch = rc % ZA_NCH, row = rc / ZA_NCH;
         if (t < tn && inst0 + row < b.n_inst)
           a.out[((int64_t)(inst0 + row) * ZA_NCH + ch) * a.frame_stride + pos + t0 + t] = tile[ch][row][t];
@@ -197,8 +217,9 @@ extern "C" __global__ void __launch_bounds__(64) ZA_KERNEL(process)(ZabBatch b, 
 
 // processBlock prologue for the hand-written kernels: instances whose sliders changed run @slider first (:3545-3547).
 extern "C" __global__ void __launch_bounds__(64) ZA_KERNEL(slider)(ZabBatch b) {
-  const int inst = blockIdx.x * 64 + threadIdx.x;
-  if (inst >= b.n_inst) return;
+  ZA_KERNEL_ENTRY();
+  const int inst = blockIdx.x * b.ipw + threadIdx.x;
+  if ((int)threadIdx.x >= b.ipw || inst >= b.n_inst) return;
   if (!(b.flags[inst] & ZAB_FLAG_SLIDER_DIRTY)) return;
   ZaS s;
   za_state_load(s, b, inst);
@@ -212,8 +233,9 @@ extern "C" __global__ void __launch_bounds__(64) ZA_KERNEL(slider)(ZabBatch b) {
 // zab_run_section): the raw section on the state as it stands, no reset, no float conversion -- what a direct call of
 // the reference's generated section function does (dsp_jsfx_aot.py:4188).
 extern "C" __global__ void __launch_bounds__(64) ZA_KERNEL(section)(ZabBatch b, int which, double samplesblock) {
-  const int inst = blockIdx.x * 64 + threadIdx.x;
-  if (inst >= b.n_inst) return;
+  ZA_KERNEL_ENTRY();
+  const int inst = blockIdx.x * b.ipw + threadIdx.x;
+  if ((int)threadIdx.x >= b.ipw || inst >= b.n_inst) return;
   ZaS s;
   za_state_load(s, b, inst);
   s.samplesblock = samplesblock;
@@ -227,12 +249,12 @@ extern "C" __global__ void __launch_bounds__(64) ZA_KERNEL(section)(ZabBatch b, 
   za_state_store(s, b, inst);
 }
 static hipError_t za_launch_section(const ZabBatch* b, int which, double samplesblock, hipStream_t st) {
-  hipLaunchKernelGGL(ZA_KERNEL(section), dim3((b->n_inst + 63) / 64), dim3(64), 0, st, *b, which, samplesblock);
+  hipLaunchKernelGGL(ZA_KERNEL(section), dim3((b->n_inst + b->ipw - 1) / b->ipw), dim3(64), 0, st, *b, which, samplesblock);
   return hipGetLastError();
 }
 
 static hipError_t za_launch_slider(const ZabBatch* b, hipStream_t st) {
-  hipLaunchKernelGGL(ZA_KERNEL(slider), dim3((b->n_inst + 63) / 64), dim3(64), 0, st, *b);
+  hipLaunchKernelGGL(ZA_KERNEL(slider), dim3((b->n_inst + b->ipw - 1) / b->ipw), dim3(64), 0, st, *b);
   return hipGetLastError();
 }
 static hipError_t za_launch_prepare(const ZabBatch* b, hipStream_t st) {
@@ -240,10 +262,10 @@ static hipError_t za_launch_prepare(const ZabBatch* b, hipStream_t st) {
   static std::once_flag za_fft_once;
   std::call_once(za_fft_once, [st] { hipLaunchKernelGGL(za_fft_table_kernel, dim3(ZA_FFT_MAX / 2 / 256), dim3(256), 0, st); });
 #endif
-  hipLaunchKernelGGL(ZA_KERNEL(prepare), dim3((b->n_inst + 63) / 64), dim3(64), 0, st, *b);
+  hipLaunchKernelGGL(ZA_KERNEL(prepare), dim3((b->n_inst + b->ipw - 1) / b->ipw), dim3(64), 0, st, *b);
   return hipGetLastError();
 }
 static hipError_t za_launch_process(const ZabBatch* b, const ZabAudio* a, hipStream_t st) {
-  hipLaunchKernelGGL(ZA_KERNEL(process), dim3((b->n_inst + 63) / 64), dim3(64), 0, st, *b, *a);
+  hipLaunchKernelGGL(ZA_KERNEL(process), dim3((b->n_inst + b->ipw - 1) / b->ipw), dim3(64), 0, st, *b, *a);
   return hipGetLastError();
 }

@@ -6,7 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define ZAB_MODULE_ABI 8
+#define ZAB_MODULE_ABI 9
 
 enum { ZAB_FLAG_SLIDER_DIRTY = 1u, ZAB_FLAG_PREPARED = 2u };
 
@@ -38,6 +38,8 @@ struct ZabBatch {
   double* fft;    int64_t fft_se, fft_si, fft_cap;   // FFT builtin scratch (null / 0 when unused)
   uint32_t* gmem_att;                          // per-instance "gmem attached" flag [n_pad] (null when unused)
   uint64_t epoch;                              // bumped by the runtime whenever host calls may have changed state
+  int32_t ipw;                                 // instances per wavefront of the lane-per-instance kernels (1..64, power of
+                                               // two): instance i runs in lane i % ipw of workgroup i / ipw
 };
 
 struct ZabAudio {

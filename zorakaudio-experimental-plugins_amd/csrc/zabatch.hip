@@ -12,6 +12,7 @@
 #include <dlfcn.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
@@ -166,10 +167,11 @@ int zab_create(const char* module, const zab_config* cfg, zab_engine** out) {
   if (!dl) return fail(ZAB_E_MODULE, "cannot load plugin module %s: %s", path.c_str(), dlerror());
   typedef const ZabModule* (*getter)(void);
   getter g = (getter)dlsym(dl, "zab_module_get");
-  if (!g) { dlclose(dl); return fail(ZAB_E_MODULE, "%s exports no zab_module_get", path.c_str()); }
+  // (a loaded module is never dlclose'd: its code object is registered with the HIP runtime, and unloading it under the
+  // runtime's feet has crashed the process)
+  if (!g) return fail(ZAB_E_MODULE, "%s exports no zab_module_get", path.c_str());
   const ZabModule* m = g();
   if (!m || m->abi != ZAB_MODULE_ABI) {
-    dlclose(dl);
     return fail(ZAB_E_MODULE, "%s: module ABI %d, runtime ABI %d", path.c_str(), m ? m->abi : -1, ZAB_MODULE_ABI);
   }
 
@@ -189,6 +191,23 @@ int zab_create(const char* module, const zab_config* cfg, zab_engine** out) {
   b.n_pad = (cfg->n_instances + 63) / 64 * 64;
   b.nvars = m->nvars;
   b.instance_major = m->prefer_instance_major ? 1 : 0;
+  {
+    // lanes per wavefront given to instances by the lane-per-instance kernels. A wavefront's run time does not depend on
+    // how many of its lanes are live, so a batch is spread over more wavefronts (shorter audio-tile staging per wave)
+    // until there are two per SIMD (256 CUs x 4 SIMDs); 16 is the floor: 16 lanes x 8 B = one 128-byte line per access
+    // to the interleaved state arrays.
+    // Measured on the catalog at 1024 instances (profiles/README.md): thinning pays for leaves with many channels (tile
+    // staging is NCH x ipw loads per frame: NeuroCV 18 ch 200 -> 87 ms, RED 6 ch 74 -> 39 ms) and is neutral to slightly
+    // negative for 2..4-channel leaves, so it is applied from 6 channels up.
+    int ipw = m->nch >= 6 ? 16 : 64;
+    while (ipw < 64 && (int64_t)cfg->n_instances > 2048ll * ipw) ipw <<= 1;
+    if (const char* f = getenv("ZAB_IPW")) { const int v = atoi(f); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) ipw = v; }
+    b.ipw = ipw;
+  }
+  if (const char* f = getenv("ZAB_FORCE_LAYOUT")) {     // experiments only: "im" / "il" overrides the module's preference
+    if (!strcmp(f, "im")) b.instance_major = 1;
+    if (!strcmp(f, "il")) b.instance_major = 0;
+  }
   b.mem_cap = cfg->mem_cap > 0 ? cfg->mem_cap : m->default_mem_cap;
   b.srate = cfg->srate;
   b.first_id = cfg->first_instance_id ? cfg->first_instance_id : 1;

@@ -120,6 +120,12 @@ ZA_FN bool za_fft_region(S& s, double baseD, int64_t span, int64_t& base, int64_
 #define ZA_F(a) s.fft[(a) * s.fft_stride]
 
 #if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+// twiddles (cos, sin)(2 pi j / ZA_FFT_COOP_MAX), j < ZA_FFT_COOP_MAX / 2, staged in LDS by the first cooperative transform of
+// a workgroup. LDS is neither cleared nor private between launches, so every kernel of an FFT leaf resets the flag on
+// entry (ZA_KERNEL_ENTRY in zab_generic.hip.h) instead of trusting whatever an earlier workgroup left behind.
+__shared__ double za_fft_tw[ZA_FFT_COOP_MAX];
+__shared__ int za_fft_tw_ready;
+#define ZA_KERNEL_ENTRY() do { za_fft_tw_ready = 0; __builtin_amdgcn_wave_barrier(); } while (0)
 enum { ZA_COOP_FFT = 0, ZA_COOP_IFFT = 1, ZA_COOP_PERMUTE = 2, ZA_COOP_IPERMUTE = 3 };
 __device__ __forceinline__ int64_t za_readlane64(int64_t v, int l) {
   const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffff), l), hi = __builtin_amdgcn_readlane((int)(v >> 32), l);
@@ -130,25 +136,21 @@ __device__ __forceinline__ int64_t za_readlane64(int64_t v, int l) {
 template <class S>
 __device__ __noinline__ bool za_fft_coop(S& s, bool ok, int64_t base, int n, int op) {
   __shared__ double buf[2 * ZA_FFT_COOP_MAX];
-  __shared__ double tw[ZA_FFT_COOP_MAX];           // (cos, sin)(2 pi j / ZA_FFT_COOP_MAX), j < ZA_FFT_COOP_MAX / 2
-  __shared__ int tw_ready;                         // (LDS is not initialised: the magic value marks a staged table)
+  double* const tw = za_fft_tw;
   const bool mine = ok && n <= ZA_FFT_COOP_MAX;
   const uint64_t active = __ballot(1);
   uint64_t todo = __ballot(mine);
   const int lane = (int)(threadIdx.x & 63);
   const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
   const int rank = __popcll(active & below), nact = __popcll(active);
-  // LDS survives between workgroups, so the marker alone could be a leftover: two table entries are checked with it
-  const int twk = ZA_FFT_COOP_MAX / 2 - 1, twq = ZA_FFT_MAX / ZA_FFT_COOP_MAX;
-  if (todo && (op == ZA_COOP_FFT || op == ZA_COOP_IFFT) &&
-      !(tw_ready == 0x5a17ab1e && tw[2] == za_fft_cos[twq] && tw[2 * twk + 1] == za_fft_sin[twk * twq])) {
+  if (todo && (op == ZA_COOP_FFT || op == ZA_COOP_IFFT) && za_fft_tw_ready != 1) {
     // twiddles of the largest cooperative size, staged once per workgroup launch (the HBM table is 1 us away per read)
     for (int j = rank; j < ZA_FFT_COOP_MAX / 2; j += nact) {
       tw[2 * j] = za_fft_cos[j * (ZA_FFT_MAX / ZA_FFT_COOP_MAX)];
       tw[2 * j + 1] = za_fft_sin[j * (ZA_FFT_MAX / ZA_FFT_COOP_MAX)];
     }
     __builtin_amdgcn_wave_barrier();
-    if (rank == 0) tw_ready = 0x5a17ab1e;
+    if (rank == 0) za_fft_tw_ready = 1;
     __builtin_amdgcn_wave_barrier();
   }
   while (todo) {
