@@ -12,19 +12,23 @@ pytestmark = pytest.mark.gpu
 
 DDT_CASES = ["DDT_default", "DDT_far_extreme", "DDT_near_eco_direct", "DDT_diffuse_ragged"]
 # the fast kernel runs NW wavefronts per instance (picked from the batch size); ZAB_DDT_NW pins it so every variant is covered
-FAST_VARIANTS = ["fast1", "fast2", "fast4", "fast8"]
+FAST_VARIANTS = ["fast1", "fast2", "fast4", "fast8", "fast1p", "fast2p", "fast1d"]   # p / d: pin the ring addressing mode
 
 
 @pytest.fixture(autouse=True)
 def _unpin_nw(monkeypatch):
     monkeypatch.delenv("ZAB_DDT_NW", raising=False)
+    monkeypatch.delenv("ZAB_DDT_RING", raising=False)
 
 
 def _paths(zabatch, monkeypatch):
     """(name, path) pairs; selecting one pins the wave count through the environment."""
     def select(name):
         if name.startswith("fast"):
-            monkeypatch.setenv("ZAB_DDT_NW", name[4:])
+            monkeypatch.setenv("ZAB_DDT_NW", name[4])
+            monkeypatch.delenv("ZAB_DDT_RING", raising=False)
+            if name[5:]:          # power-of-two ring with masked offsets / doubled ring without wrap
+                monkeypatch.setenv("ZAB_DDT_RING", {"p": "pow2", "d": "dbl"}[name[5:]])
             return zabatch.ZAB_PATH_FAST
         return zabatch.ZAB_PATH_GENERIC
     return select

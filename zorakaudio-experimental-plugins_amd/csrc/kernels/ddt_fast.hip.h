@@ -29,6 +29,8 @@
 // frame included), within the scan's rounding for the filter states -- tests/test_ddt_gpu.py compares both paths.
 #pragma once
 
+#include <string.h>
+
 #include <map>
 #include <mutex>
 #include <type_traits>
@@ -143,8 +145,8 @@ struct DdtChunk {  // per-lane registers that live across the two workgroup barr
 };
 
 // Phase A: read the chunk's audio, publish M to the shared ring (and the f64 L/R rings of mem[] when they survive).
-template <bool PARTIAL>
-__device__ __forceinline__ void ddt_phase_a(const DdtCtx& C, DdtChunk& K, int lane, int64_t f0, const float4& p0, const float4& p1) {
+template <bool PARTIAL, bool DBL>
+__device__ __forceinline__ void ddt_phase_a(const DdtCtx& C, DdtChunk& K, int lane, int64_t f0, int nb, const float4& p0, const float4& p1) {
   const int64_t t0 = f0 + DDT_KF * lane;
   if (!PARTIAL && C.vec_ok) {                              // prefetched one iteration ahead (ddt_prefetch)
     K.x0[0] = p0.x; K.x0[1] = p0.y; K.x0[2] = p0.z; K.x0[3] = p0.w;
@@ -162,14 +164,22 @@ __device__ __forceinline__ void ddt_phase_a(const DdtCtx& C, DdtChunk& K, int la
       K.x1[k] = ok ? C.in1[t0 + k] : 0.0f;
     }
   }
-  const int nb = (int)((C.wofs0 + f0) & 0x3fffffff);      // uniform; W divides 2^30 so low bits suffice
+  // nb = ring position of the chunk's first frame (uniform)
 #pragma unroll
   for (int k = 0; k < DDT_KF; ++k) {
     const double M = 0.5 * ((double)K.x0[k] + (double)K.x1[k]);   // mono (:445) == ring value 0.5*(L+R) (:467)
     if (!PARTIAL || t0 + k >= 0) {
-      const int slot = (nb + DDT_KF * lane + k) & (C.W - 1);
-      C.ring[slot] = M;
-      if (slot < DDT_CHUNK) C.ring[C.W + slot] = M;
+      if (DBL) {                                           // doubled ring: [0,W) | [W,2W) | copy of the first 256 slots
+        int slot = nb + DDT_KF * lane + k;
+        slot = slot >= C.W ? slot - C.W : slot;
+        C.ring[slot] = M;
+        C.ring[C.W + slot] = M;
+        if (slot < DDT_CHUNK) C.ring[2 * C.W + slot] = M;
+      } else {                                             // power-of-two ring + copy of the first 256 slots
+        const int slot = (nb + DDT_KF * lane + k) & (C.W - 1);
+        C.ring[slot] = M;
+        if (slot < DDT_CHUNK) C.ring[C.W + slot] = M;
+      }
     }
   }
   if (f0 + DDT_CHUNK > C.frames - DDT_RING) {             // :441-442, only slots that survive the launch
@@ -197,10 +207,13 @@ __device__ __forceinline__ DdtTap ddt_tap_get(const DdtTapRegs& R, int i) {
   t.gR = ddt_readlane(R.gR, i);
   return t;
 }
+// DBL: `ringb` already points at frame (nb + lane) of the SECOND copy of a doubled ring, so `- delay` never leaves the
+// allocation and needs no wrap; otherwise the byte offset is wrapped with the power-of-two mask.
+template <bool DBL>
 __device__ __forceinline__ void ddt_tap_fetch(const char* ringb, int lane8nb, int m8, const DdtTap& tp, double (&l)[DDT_KF],
                                               double (&r)[DDT_KF]) {
-  const char* pl = ringb + ((lane8nb - tp.dL8) & m8);
-  const char* pr = ringb + ((lane8nb - tp.dR8) & m8);
+  const char* pl = DBL ? ringb - tp.dL8 : ringb + ((lane8nb - tp.dL8) & m8);
+  const char* pr = DBL ? ringb - tp.dR8 : ringb + ((lane8nb - tp.dR8) & m8);
 #pragma unroll
   for (int k = 0; k < DDT_KF; ++k) {
     l[k] = *reinterpret_cast<const double*>(pl + 512 * k);
@@ -215,28 +228,29 @@ __device__ __forceinline__ void ddt_tap_acc(const DdtTap& tp, const double (&l)[
     acc[1][k] = __builtin_fma(tp.gR, r[k], acc[1][k]);
   }
 }
+template <bool DBL>
 __device__ __forceinline__ void ddt_tap_run(const DdtCtx& C, const DdtTapRegs& R, const char* ringb, int lane8nb, int i0, int i1,
                                             double (&acc)[2][DDT_KF]) {
   if (i0 >= i1) return;
   const int last = i1 - 1;
   double al[DDT_KF], ar[DDT_KF], bl[DDT_KF], br[DDT_KF];
   DdtTap ta = ddt_tap_get(R, i0), tb;
-  ddt_tap_fetch(ringb, lane8nb, C.m8, ta, al, ar);
+  ddt_tap_fetch<DBL>(ringb, lane8nb, C.m8, ta, al, ar);
   int i = i0;
   for (; i + 1 < i1; i += 2) {                             // pairs; the fetch past the end re-reads the last tap
     tb = ddt_tap_get(R, i + 1);
-    ddt_tap_fetch(ringb, lane8nb, C.m8, tb, bl, br);
+    ddt_tap_fetch<DBL>(ringb, lane8nb, C.m8, tb, bl, br);
     ddt_tap_acc(ta, al, ar, acc);
     ta = ddt_tap_get(R, i + 2 < last ? i + 2 : last);
-    ddt_tap_fetch(ringb, lane8nb, C.m8, ta, al, ar);
+    ddt_tap_fetch<DBL>(ringb, lane8nb, C.m8, ta, al, ar);
     ddt_tap_acc(tb, bl, br, acc);
   }
   if (i < i1) ddt_tap_acc(ta, al, ar, acc);                // odd count: the last tap is already in (ta, al, ar)
 }
 
 // Phase B: taps (:459-484), transpose, in-lane recurrences + scans. Leaves y (zero-state responses) and G in K.
-template <bool PARTIAL>
-__device__ __forceinline__ void ddt_phase_b(const DdtCtx& C, const DdtTapRegs& R, DdtChunk& K, int lane, int64_t f0, const double (&carry)[6], bool head,
+template <bool PARTIAL, bool DBL>
+__device__ __forceinline__ void ddt_phase_b(const DdtCtx& C, const DdtTapRegs& R, DdtChunk& K, int lane, int64_t f0, int nb, const double (&carry)[6], bool head,
                                             const double (&cb1)[3], const double (&cb2)[3], bool want_last) {
   int first_lane = 0, first_k = 0;
   if (PARTIAL) {
@@ -244,10 +258,10 @@ __device__ __forceinline__ void ddt_phase_b(const DdtCtx& C, const DdtTapRegs& R
     first_lane = firstv / DDT_KF;
     first_k = firstv % DDT_KF;
   }
-  const int nb = (int)((C.wofs0 + f0) & 0x3fffffff);
   {
-    const char* ringb = reinterpret_cast<const char*>(C.ring);
-    const int lane8nb = (8 * lane + 8 * nb) & C.m8;       // byte address of frame (nb + lane) in the ring
+    // DBL: pointer to frame (nb + lane) in the second copy; else ring base + wrapped byte offset of frame (nb + lane)
+    const char* ringb = reinterpret_cast<const char*>(DBL ? C.ring + C.W + nb + lane : C.ring);
+    const int lane8nb = DBL ? 0 : ((8 * lane + 8 * nb) & C.m8);
     double sE[2][DDT_KF], sL[2][DDT_KF];
 #pragma unroll
     for (int k = 0; k < DDT_KF; ++k) sE[0][k] = sE[1][k] = sL[0][k] = sL[1][k] = 0.0;
@@ -267,9 +281,9 @@ __device__ __forceinline__ void ddt_phase_b(const DdtCtx& C, const DdtTapRegs& R
       }                                                                                                \
       __builtin_amdgcn_wave_barrier();                                                                 \
     }
-    ddt_tap_run(C, R, ringb, lane8nb, 0, C.nE, sE);
+    ddt_tap_run<DBL>(C, R, ringb, lane8nb, 0, C.nE, sE);
     DDT_TRANSPOSE(sE, 2)
-    ddt_tap_run(C, R, ringb, lane8nb, C.nE, C.nT, sL);
+    ddt_tap_run<DBL>(C, R, ringb, lane8nb, C.nE, C.nT, sL);
     DDT_TRANSPOSE(sL, 4)
 #undef DDT_TRANSPOSE
   }
@@ -371,11 +385,13 @@ __device__ __forceinline__ void ddt_phase_c(const DdtCtx& C, DdtChunk& K, int la
   }
 }
 
-template <int NW>
+__device__ __forceinline__ int ddt_pos(int64_t n, int W) { int r = (int)(n % W); return r < 0 ? r + W : r; }
+
+template <int NW, bool DBL>
 __device__ __forceinline__ void ddt_fast_body(const ZabBatch& b, const ZabAudio& a, int W) {
   extern __shared__ double ddt_lds[];
-  double* ring = ddt_lds;                                  // [W + 256]: circular history + mirror of its first 256 slots
-  double* Tall = ddt_lds + W + DDT_CHUNK;                  // [NW][2][256] per-wave transpose areas
+  double* ring = ddt_lds;                                  // [W + 256] (power-of-two W) or [2 W + 256] (doubled), see ddt_geometry
+  double* Tall = ddt_lds + (DBL ? 2 * W : W) + DDT_CHUNK;  // [NW][2][256] per-wave transpose areas
   double* gend = Tall + NW * 2 * DDT_CHUNK;                // [NW][6] chunk-end responses (zero incoming state)
   double* mred = Tall;                                     // [NW][7] meter partials, after the last chunk (aliases Tall)
   DdtTap* taps = (DdtTap*)Tall;                            // [DDT_MAXTAPS] staging only (aliases Tall): early taps, then late
@@ -477,10 +493,17 @@ __device__ __forceinline__ void ddt_fast_body(const ZabBatch& b, const ZabAudio&
   for (int j = tid; j < H; j += NW * 64) {
     const int64_t n = C.wofs0 - H + j;
     const int64_t ri = n & C.bufmask;
-    const int slot = (int)(n & (W - 1));
     const double mv = 0.5 * (Mem[C.rL + ri] + Mem[C.rR + ri]);
-    ring[slot] = mv;
-    if (slot < DDT_CHUNK) ring[W + slot] = mv;
+    if (DBL) {
+      const int slot = ddt_pos(n, W);
+      ring[slot] = mv;
+      ring[W + slot] = mv;
+      if (slot < DDT_CHUNK) ring[2 * W + slot] = mv;
+    } else {
+      const int slot = (int)(n & (W - 1));
+      ring[slot] = mv;
+      if (slot < DDT_CHUNK) ring[W + slot] = mv;
+    }
   }
   __syncthreads();
   C.nE = scratch[2];
@@ -499,6 +522,7 @@ __device__ __forceinline__ void ddt_fast_body(const ZabBatch& b, const ZabAudio&
   const int64_t niter = (nchunks + NW - 1) / NW;
   DdtChunk K;
   int64_t my_last_chunk = -1;
+  int pos = DBL ? ddt_pos(C.wofs0 + f_first + (int64_t)DDT_CHUNK * wave, W) : 0;
   // The HBM read of a wave's next chunk is issued a whole iteration ahead of its use.
   float4 pf0 = make_float4(0.f, 0.f, 0.f, 0.f), pf1 = pf0;
   auto prefetch = [&](const int64_t c) __attribute__((always_inline)) {
@@ -517,11 +541,14 @@ __device__ __forceinline__ void ddt_fast_body(const ZabBatch& b, const ZabAudio&
     const int64_t f0 = f_first + DDT_CHUNK * c;
     const bool want_last = active && c == nchunks - 1;
     const bool head = (wave == 0);                         // wave 0 owns the head of this iteration's carry chain
-    if (active) ddt_phase_a<PART>(C, K, lane, f0, pf0, pf1);
+    // ring position of the chunk's first frame: tracked incrementally for the doubled ring (W is not a power of two)
+    const int nb = DBL ? pos : (int)((C.wofs0 + f0) & (W - 1));
+    if (DBL) { pos += NW * DDT_CHUNK; pos = pos >= W ? pos - W : pos; }
+    if (active) ddt_phase_a<PART, DBL>(C, K, lane, f0, nb, pf0, pf1);
     prefetch(c + NW);                                      // this wave's next chunk: in flight across phases B and C
     __syncthreads();                                       // ring holds every frame of this iteration
     if (active) {
-      ddt_phase_b<PART>(C, R, K, lane, f0, carry, head, cb1, cb2, want_last);
+      ddt_phase_b<PART, DBL>(C, R, K, lane, f0, nb, carry, head, cb1, cb2, want_last);
       if (lane == 63) {
 #pragma unroll
         for (int s = 0; s < 6; ++s) gend[wave * 6 + s] = K.G[s];
@@ -600,7 +627,8 @@ __device__ __forceinline__ void ddt_fast_body(const ZabBatch& b, const ZabAudio&
     V[ZA_VAR_i] = (double)tapN;
     if (tapN > 0) {
       const int dLl = scratch[0], dRl = scratch[1];
-      const int cl = (int)((nlast - dLl) & (W - 1)), cr = (int)((nlast - dRl) & (W - 1));
+      const int cl = DBL ? ddt_pos(nlast - dLl, W) : (int)((nlast - dLl) & (W - 1));
+      const int cr = DBL ? ddt_pos(nlast - dRl, W) : (int)((nlast - dRl) & (W - 1));
       V[ZA_VAR_idxL] = (double)(int32_t)((nlast - dLl) & C.bufmask);
       V[ZA_VAR_idxR] = (double)(int32_t)((nlast - dRl) & C.bufmask);
       V[ZA_VAR_xL] = ring[cl];                                        // the LDS ring still holds frame - delay
@@ -615,10 +643,17 @@ __device__ __forceinline__ void ddt_fast_body(const ZabBatch& b, const ZabAudio&
   }
 }
 
-extern "C" __global__ void __launch_bounds__(64, 2) zab_ddt_fast(ZabBatch b, ZabAudio a, int W) { ddt_fast_body<1>(b, a, W); }
-extern "C" __global__ void __launch_bounds__(128, 2) zab_ddt_fast_nw2(ZabBatch b, ZabAudio a, int W) { ddt_fast_body<2>(b, a, W); }
-extern "C" __global__ void __launch_bounds__(256, 2) zab_ddt_fast_nw4(ZabBatch b, ZabAudio a, int W) { ddt_fast_body<4>(b, a, W); }
-extern "C" __global__ void __launch_bounds__(512, 2) zab_ddt_fast_nw8(ZabBatch b, ZabAudio a, int W) { ddt_fast_body<8>(b, a, W); }
+// _nwK: K wavefronts per instance. W < 0 selects the doubled ring of length -W (any multiple of 256), W > 0 the
+// power-of-two ring of length W (long delays that do not fit twice in LDS).
+#define DDT_KERNEL(name, NW)                                                                             \
+  extern "C" __global__ void __launch_bounds__(64 * NW, 2) name(ZabBatch b, ZabAudio a, int W) {         \
+    if (W < 0) ddt_fast_body<NW, true>(b, a, -W); else ddt_fast_body<NW, false>(b, a, W);                \
+  }
+DDT_KERNEL(zab_ddt_fast, 1)
+DDT_KERNEL(zab_ddt_fast_nw2, 2)
+DDT_KERNEL(zab_ddt_fast_nw4, 4)
+DDT_KERNEL(zab_ddt_fast_nw8, 8)
+#undef DDT_KERNEL
 
 // ---- plan: max tap delay over the batch (decides the LDS ring length) -----------------------------------------------
 __device__ int ddt_plan_word[2];
@@ -672,18 +707,29 @@ static int ddt_pick_nw(int n_inst) {
   if (const char* e = getenv("ZAB_DDT_NW")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) nw = v; }
   return nw;
 }
-static size_t ddt_lds_bytes(int W, int nw) {
-  return (size_t)(W + DDT_CHUNK + nw * 2 * DDT_CHUNK + nw * 6) * sizeof(double) + 3 * sizeof(DdtPole) + 16;
+static size_t ddt_lds_bytes(int W, int nw, bool dbl) {
+  return (size_t)((dbl ? 2 * W : W) + DDT_CHUNK + nw * 2 * DDT_CHUNK + nw * 6) * sizeof(double) + 3 * sizeof(DdtPole) + 16;
 }
-// ring length (power of two) and waves per instance; W == 0: not applicable (generic kernel takes over)
+// Ring geometry and waves per instance. The ring must hold Dmax + NW*256 + 1 frames. Preferred: a DOUBLED ring of exactly
+// that length rounded up to 256 (returned as -W): `frame - delay` then needs no wrap at all in the tap phase. When twice
+// that does not fit in LDS: a power-of-two ring with masked offsets (returned as +W). 0: not applicable (generic kernel).
 static void ddt_geometry(const ZabBatch* b, int& W, int& nw) {
   const DdtPlan p = ddt_plan(b);
   W = 0; nw = 1;
   if (!p.ok) return;
+  const size_t cap = 160 * 1024 - 512, cu = 160 * 1024;
+  const char* force = getenv("ZAB_DDT_RING");              // "dbl" / "pow2": tests pin the addressing mode
   for (nw = ddt_pick_nw(b->n_inst); nw >= 1; nw >>= 1) {
+    const int need = p.dmax + nw * DDT_CHUNK + 1;
+    const int wd = (need + DDT_CHUNK - 1) / DDT_CHUNK * DDT_CHUNK;
     int w = 1024;
-    while (w < p.dmax + nw * DDT_CHUNK + 1) w <<= 1;
-    if (w <= 16384 && ddt_lds_bytes(w, nw) <= 160 * 1024 - 512) { W = w; return; }
+    while (w < need) w <<= 1;
+    const size_t ld = ddt_lds_bytes(wd, nw, true), lp = ddt_lds_bytes(w, nw, false);
+    const bool fd = ld <= cap && !(force && !strcmp(force, "pow2")), fp = w <= 16384 && lp <= cap && !(force && !strcmp(force, "dbl"));
+    // the register budget allows 8 wavefronts per CU; an LDS footprint that admits fewer costs more than the wrap does
+    const bool full_d = fd && (cu / ld) * nw >= 8, full_p = fp && (cu / lp) * nw >= 8;
+    if (full_d || (fd && !full_p)) { W = -wd; return; }
+    if (fp) { W = w; return; }
   }
   nw = 1;
 }
@@ -693,14 +739,14 @@ static int32_t za_fast_applies(const ZabBatch* b, const ZabAudio* a) {
   if (a->frames <= 0) return 0;
   int W, nw;
   ddt_geometry(b, W, nw);
-  return W > 0 ? 1 : 0;
+  return W != 0 ? 1 : 0;
 }
 
 static hipError_t za_launch_fast(const ZabBatch* b, const ZabAudio* a, hipStream_t st) {
   int W, nw;
   ddt_geometry(b, W, nw);
-  if (W <= 0) return hipErrorInvalidValue;
-  const size_t lds = ddt_lds_bytes(W, nw);
+  if (W == 0) return hipErrorInvalidValue;
+  const size_t lds = ddt_lds_bytes(W < 0 ? -W : W, nw, W < 0);
   static std::once_flag once;
   std::call_once(once, [] {
     const int cap = 160 * 1024 - 512;
