@@ -13,7 +13,9 @@ RCCL is used only for the barrier and the max-over-ranks of the timed region.
 
 One JSON line on rank 0 (see README/DESIGN for the field definitions), including
   roofline     -- dominant kernel's algorithmic HBM bytes / its mean duration (HIP events on the engine stream)
-  cpu_baseline -- the reference's own WDL/EEL2 VM (oracle/_ref) timed on this box's host cores on a bounded sample.
+  cpu_baseline -- the CPU port of the same path (oracle/port.py, g++ -O2 scalar f64; kind "port") timed on this box's host
+                  cores on a bounded sample. (The reference's EEL2 VM needs the leaf's script text, which does not travel
+                  to the GPU box; its speed is recorded in DESIGN.md.)
 """
 from __future__ import annotations
 
