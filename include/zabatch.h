@@ -148,6 +148,12 @@ int zab_gmem_read(zab_engine* e, int64_t start, int64_t n, double* dst);
 int zab_gmem_write(zab_engine* e, int64_t start, int64_t n, const double* src);
 int zab_gmem_seq(zab_engine* e, int64_t page, uint64_t* out);
 
+/* File slots (leaves that call file_open / file_riff / file_avail / file_mem / file_var ...; reference: the processor's
+ * runtime file handles, src/JSFXJuceProcessor.cpp:4893-5215). The host decodes whatever is assigned to a slot into a flat
+ * array of doubles (interleaved audio items) and hands it over; every instance of the engine sees the same slots through
+ * its own handles and cursors. items == NULL unassigns the slot (file_open returns -1, as for an empty slot). */
+int zab_file_slot_set(zab_engine* e, int32_t slot, int32_t channels, double sample_rate, const double* items, int64_t n_items);
+
 /* Sample pool (leaves that call sample_read* / sample_export_mem): one immutable generation per upload, entries are
  * 1-based sample ids in array order (DspJsfxSamplePoolEntry / Generation, src/DspJsfxSamplePool.h:55-79). audio is the
  * packed float32 arena, each entry interleaved by channel starting at offset_items. Decode/resample is host work. */

@@ -29,6 +29,11 @@ struct ZaPort {
   std::vector<ZaPoolEntry> pent;
   ZaPoolView pview;
 #endif
+#ifdef ZA_FILE_H_INCLUDED
+  ZaFileView fview;
+  std::vector<double> fitems[ZA_FILE_SLOTS];
+  int64_t fhw[ZA_FH_WORDS];
+#endif
   int alias[64];
 };
 
@@ -46,6 +51,13 @@ ZaPort* port_create(double srate, int64_t mem_cap) {
   p->s.mt_stride = 1;
   p->s.srate = srate;
   p->s.instance_id = 1;
+#ifdef ZA_FILE_H_INCLUDED
+  memset(&p->fview, 0, sizeof p->fview);
+  memset(p->fhw, 0, sizeof p->fhw);
+  p->s.files = &p->fview;
+  p->s.fh = p->fhw;
+  p->s.fh_stride = 1;
+#endif
 #ifdef ZA_FFT_MAX
   za_fft_table_init();
   p->fft.assign(2 * ZA_FFT_MAX, 0.0);
@@ -136,6 +148,14 @@ void port_pool_upload(ZaPort* p, int n, const int64_t* ent4, const float* peak_r
                                      peak_rms[2 * i], peak_rms[2 * i + 1], 0};
   p->pview = ZaPoolView{p->paudio.data(), (uint64_t)items, p->pent.data(), (uint32_t)n, 1};
   p->s.pool = &p->pview;
+}
+#endif
+#ifdef ZA_FILE_H_INCLUDED
+void port_file_slot_set(ZaPort* p, int slot, int channels, double srate, const double* items, int64_t n) {
+  if (slot < 0 || slot >= ZA_FILE_SLOTS) return;
+  if (!items) { p->fview.slot[slot] = ZaFileSlot{nullptr, 0, 0, 0, 0.0}; return; }
+  p->fitems[slot].assign(items, items + n);
+  p->fview.slot[slot] = ZaFileSlot{p->fitems[slot].data(), n, channels, 1, srate};
 }
 #endif
 int64_t port_mem_high(ZaPort* p) { return p->s.mem_high; }

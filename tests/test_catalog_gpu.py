@@ -115,13 +115,12 @@ def test_dot_device_vs_port():
         assert np.abs(mem[i] - p.mem(0, 57344)).max() <= SCALAR_EPS, i
 
 
-HOST_ASSISTED = ["IPCProbeA", "IPCProbeB", "GesturePad", "3DPannerManager", "PsychoConvolver", "CMD", "Contour",
-                 "TextureXY", "3DPanner", "Texture"]
+HOST_ASSISTED = ["IPCProbeA", "IPCProbeB", "3DPannerManager", "CMD", "3DPanner"]     # msg bus / comm
 
 
 @pytest.mark.parametrize("leaf", HOST_ASSISTED)
 def test_host_assisted_leaves_build_and_are_refused_loudly(leaf):
-    """Leaves whose default path calls host services (msg bus / file slots / MIDI: SURVEY §8f.3-4, not built yet) go through
+    """Leaves whose default path needs the message bus (not built) go through
     the translator and load, but the engine must not run them with stubbed host calls: the device latches
     ZA_ERR_UNSUPPORTED and the C ABI returns ZAB_E_UNSUPPORTED."""
     import zabatch
@@ -135,3 +134,53 @@ def test_host_assisted_leaves_build_and_are_refused_loudly(leaf):
             e.prepare()
             e.process_host(np.zeros((3, e.nch, 64), np.float32), block=64)
         assert ei.value.code in (-5, -4), ei.value          # unsupported (or arena too small before getting there)
+
+
+FILE_LEAVES = ["PsychoConvolver", "Contour", "TextureXY", "Texture"]
+
+
+@pytest.mark.parametrize("loaded", [False, True])
+@pytest.mark.parametrize("leaf", FILE_LEAVES)
+def test_file_slot_leaves_device_vs_port(leaf, loaded):
+    """Leaves that load audio through file_open(0) / file_riff / file_mem (impulse responses, textures). The host side of
+    the reference decodes the file; here the decoded items are handed over with zab_file_slot_set. Checked device vs CPU port
+    (no VM fixture: the reference's shadow VM has no file slots here), with the slot empty (file_open -> -1, the state of a
+    freshly inserted plugin) and with a short stereo noise burst assigned to slot 0."""
+    import zabatch
+    from oracle import port
+    from zajit import noise
+    if not zabatch.module_path(leaf).exists() or not port.port_path(leaf).exists():
+        pytest.skip(f"{leaf} not built")
+    meta = zabatch.leaf_meta(leaf)
+    nch = int(meta["nch"])
+    n, frames, cap = 5, 2048, 1 << 25
+    ir = (noise.white_noise([321], 3000)[0].T * np.exp(-np.arange(3000) / 400.0)[:, None]).reshape(-1).astype(np.float64)   # interleaved L,R
+    x = np.zeros((n, nch, frames), np.float32)
+    x[:, :2] = noise.white_noise(range(n), frames)[:, :min(2, nch)]
+    with zabatch.Engine(leaf, n, mem_cap=cap) as e:
+        if loaded:
+            e.file_slot_set(0, ir, channels=2, sample_rate=48000.0)
+        e.set_sliders(meta["default_sliders"]); e.prepare()
+        y = e.process_host(x, block=512)
+        v = e.read_vars(); names = e.var_names()
+        high = int(e.mem_high().max())
+        mem = e.read_mem(0, min(high, 1 << 20), 0, 1)[0] if high else None
+    p = port.Port(leaf, 48000.0, mem_cap=cap)
+    if loaded:
+        p.file_slot_set(0, ir, 2, 48000.0)
+    p.set_sliders(meta["default_sliders"]); p.prepare()
+    for i in (0, n - 1):
+        q = p if i == 0 else None
+        if q is None:
+            q = port.Port(leaf, 48000.0, mem_cap=cap)
+            if loaded:
+                q.file_slot_set(0, ir, 2, 48000.0)
+            q.set_sliders(meta["default_sliders"]); q.prepare()
+        ref = q.process(x[i], 512)
+        assert np.abs(y[i].astype(np.float64) - ref).max() <= AUDIO_EPS, (leaf, loaded, i)
+        assert_state_close(names, v[i], q.vars(), what=f"{leaf} vars[{i}]")
+        if i == 0 and mem is not None:
+            assert int(q.mem_high) == high
+            assert np.abs(mem - q.mem(0, len(mem))).max() <= SCALAR_EPS
+    if loaded and leaf == "PsychoConvolver":
+        assert np.abs(y).max() > 1.0          # the loaded impulse response is really convolved in

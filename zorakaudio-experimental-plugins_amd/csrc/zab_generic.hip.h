@@ -70,6 +70,9 @@ __device__ __forceinline__ void za_state_bind(ZaS& s, const ZabBatch& b, int ins
   s.fft_stride = b.fft_se;
   s.fft_cap = b.fft ? b.fft_cap : 0;
   s.gmem_attached = b.gmem_att ? b.gmem_att[inst] : 0;
+  s.files = (const ZaFileView*)b.files;
+  s.fh = b.fh ? b.fh + (int64_t)inst * b.fh_si : nullptr;
+  s.fh_stride = b.fh_se;
 }
 
 __device__ __forceinline__ void za_state_load(ZaS& s, const ZabBatch& b, int inst) {

@@ -6,7 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define ZAB_MODULE_ABI 9
+#define ZAB_MODULE_ABI 10
 
 enum { ZAB_FLAG_SLIDER_DIRTY = 1u, ZAB_FLAG_PREPARED = 2u };
 
@@ -38,6 +38,8 @@ struct ZabBatch {
   double* fft;    int64_t fft_se, fft_si, fft_cap;   // FFT builtin scratch (null / 0 when unused)
   uint32_t* gmem_att;                          // per-instance "gmem attached" flag [n_pad] (null when unused)
   uint64_t epoch;                              // bumped by the runtime whenever host calls may have changed state
+  const void* files;                           // ZaFileView* (device) or null
+  int64_t* fh;    int64_t fh_se, fh_si;        // per-instance file handle words [ZA_FH_WORDS] (null when unused)
   int32_t ipw;                                 // instances per wavefront of the lane-per-instance kernels (1..64, power of
                                                // two): instance i runs in lane i % ipw of workgroup i / ipw
 };
@@ -61,6 +63,7 @@ struct ZabModule {
   int64_t fft_scratch_doubles;       // per-instance scratch the runtime must provide (0: leaf has no FFT builtins)
   int32_t uses_gmem;                 // runtime must provide a gmem segment; 2 = instances start attached (options:gmem=)
   int32_t uses_pool;                 // leaf reads the sample pool (zab_pool_upload provides it)
+  int32_t uses_files;                // leaf calls file_*(): runtime provides slots + per-instance handle words
   // generic (translator-generated) kernels
   hipError_t (*launch_prepare)(const ZabBatch*, hipStream_t);
   hipError_t (*launch_process)(const ZabBatch*, const ZabAudio*, hipStream_t);

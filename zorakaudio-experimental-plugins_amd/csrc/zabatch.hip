@@ -78,6 +78,11 @@ __global__ void zab_k_scatter(T* base, int64_t se, int64_t n, const T* staging) 
 
 }  // namespace
 
+// mirrors ZaFileSlot / ZaFileView of csrc/zart_file.h (the runtime does not include the device headers)
+struct ZabFileSlotDev { const double* items; int64_t n_items; int32_t channels; int32_t assigned; double srate; };
+struct ZabFileViewDev { ZabFileSlotDev slot[16]; };
+enum { kFileHandleWords = 26 };
+
 struct zab_engine {
   void* dl = nullptr;
   const ZabModule* mod = nullptr;
@@ -96,6 +101,8 @@ struct zab_engine {
   unsigned long long *gmem_cells = nullptr, *gmem_page_seq = nullptr, *gmem_global_seq = nullptr;
   uint64_t gmem_cell_count = 0;
   uint32_t pool_generation = 0;
+  ZabFileViewDev* d_files = nullptr;      // file slot table (device) + its host copy
+  ZabFileViewDev h_files{};
   void* state_stage = nullptr;      // device staging for zab_state_upload/download
   int64_t state_stage_bytes = 0;
   float* stage_in = nullptr;
@@ -224,12 +231,14 @@ int zab_create(const char* module, const zab_config* cfg, zab_engine** out) {
     b.mem_se = 1; b.mem_si = b.mem_cap;
     b.mt_se = 1; b.mt_si = 624;
     b.fft_se = 1; b.fft_si = m->fft_scratch_doubles;
+    b.fh_se = 1; b.fh_si = kFileHandleWords;
   } else {
     b.var_se = P; b.var_si = 1;
     b.sl_se = P; b.sl_si = 1;
     b.mem_se = P; b.mem_si = 1;
     b.mt_se = P; b.mt_si = 1;
     b.fft_se = P; b.fft_si = 1;
+    b.fh_se = P; b.fh_si = 1;
   }
   b.fft_cap = m->fft_scratch_doubles;
   if ((rc = e->alloc(&b.vars, (size_t)P * m->nvars)) || (rc = e->alloc(&b.sliders, (size_t)P * 64)) ||
@@ -240,10 +249,12 @@ int zab_create(const char* module, const zab_config* cfg, zab_engine** out) {
       (rc = e->alloc(&b.pend, (size_t)P * 3)) || (rc = e->alloc(&b.vis_mask, (size_t)P)) ||
       (rc = e->alloc(&b.vis_init, (size_t)P)) ||
       (m->fft_scratch_doubles > 0 && (rc = e->alloc(&b.fft, (size_t)P * m->fft_scratch_doubles))) ||
-      (m->uses_gmem && (rc = setup_gmem(e)))) {
+      (m->uses_gmem && (rc = setup_gmem(e))) ||
+      (m->uses_files && ((rc = e->alloc(&e->d_files, 1)) || (rc = e->alloc(&b.fh, (size_t)P * kFileHandleWords))))) {
     zab_destroy(e);
     return rc;
   }
+  b.files = e->d_files;                    // zero-filled: every slot unassigned until zab_file_slot_set
   if ((he = hipStreamSynchronize(e->stream)) != hipSuccess) {
     rc = fail(ZAB_E_HIP, "state clear failed: %s", hipGetErrorString(he));
     zab_destroy(e);
@@ -546,6 +557,28 @@ int zab_pool_upload(zab_engine* e, int32_t n_entries, const zab_pool_entry* entr
   HIP_TRY(hipMemcpyAsync(d_view, &v, sizeof v, hipMemcpyHostToDevice, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   e->b.pool = d_view;          // earlier generations stay allocated until zab_destroy (readers may still hold them)
+  e->b.epoch++;
+  return ZAB_OK;
+}
+
+int zab_file_slot_set(zab_engine* e, int32_t slot, int32_t channels, double sample_rate, const double* items, int64_t n_items) {
+  if (!e || slot < 0 || slot >= 16 || n_items < 0 || (n_items && !items) || channels < 0)
+    return fail(ZAB_E_ARG, "zab_file_slot_set: bad argument");
+  if (!e->mod->uses_files) return fail(ZAB_E_STATE, "zab_file_slot_set: leaf %s has no file_*() calls", e->mod->name);
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  ZabFileSlotDev& f = e->h_files.slot[slot];
+  if (!items) {                            // unassign (file_open fails again); data of open handles stays allocated
+    f = ZabFileSlotDev{};
+  } else {
+    double* d = nullptr;
+    int rc = e->alloc(&d, (size_t)(n_items ? n_items : 1));
+    if (rc) return rc;
+    if (n_items) HIP_TRY(hipMemcpyAsync(d, items, sizeof(double) * (size_t)n_items, hipMemcpyHostToDevice, e->stream));
+    f = ZabFileSlotDev{d, n_items, channels, 1, sample_rate};
+  }
+  HIP_TRY(hipMemcpyAsync(e->d_files, &e->h_files, sizeof e->h_files, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
   e->b.epoch++;
   return ZAB_OK;
 }

@@ -46,6 +46,7 @@ enum : uint32_t {
 
 struct ZaGmemView;   // zart_gmem.h
 struct ZaPoolView;   // zart_pool.h
+struct ZaFileView;   // zart_file.h
 
 template <int NV>
 struct ZaState {
@@ -75,6 +76,9 @@ struct ZaState {
   double* fft;           // FFT builtin scratch (natural-order work area), element a at fft[a * fft_stride]
   int64_t fft_stride;
   int64_t fft_cap;       // doubles available (0 when the leaf has no FFT builtins)
+  const ZaFileView* files; // file slots of the engine (zart_file.h); null when the leaf has no file builtins
+  int64_t* fh;           // this instance's file handle words, word k at fh[k * fh_stride]
+  int64_t fh_stride;
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -50,7 +50,7 @@ ABI_SYMBOLS = [
     "zab_var_index", "zab_set_sliders", "zab_get_sliders", "zab_prepare", "zab_process", "zab_sync", "zab_read_vars",
     "zab_read_mem", "zab_write_mem", "zab_read_mem_high", "zab_device_alloc", "zab_device_free", "zab_device_upload",
     "zab_device_download", "zab_device_noise", "zab_last_timing", "zab_timing_history", "zab_stream",
-    "zab_used_fast_path", "zab_last_kernel_name", "zab_state_upload", "zab_state_download", "zab_run_section", "zab_gmem_read", "zab_gmem_write", "zab_gmem_seq", "zab_pool_upload",
+    "zab_used_fast_path", "zab_last_kernel_name", "zab_state_upload", "zab_state_download", "zab_run_section", "zab_gmem_read", "zab_gmem_write", "zab_gmem_seq", "zab_pool_upload", "zab_file_slot_set",
 ]
 
 _lib = None
@@ -101,6 +101,7 @@ def load_runtime():
     L.zab_gmem_write.argtypes = [vp, i64, i64, C.POINTER(d)]
     L.zab_gmem_seq.argtypes = [vp, i64, C.POINTER(C.c_uint64)]
     L.zab_pool_upload.argtypes = [vp, i32, C.POINTER(zab_pool_entry), C.POINTER(C.c_float), i64]
+    L.zab_file_slot_set.argtypes = [vp, i32, i32, C.c_double, C.POINTER(C.c_double), i64]
     _lib = L
     return L
 
@@ -304,6 +305,14 @@ class Engine:
         audio = np.concatenate(chunks) if chunks else np.zeros(0, np.float32)
         arr = (zab_pool_entry * max(1, len(ents)))(*ents)
         self._chk(self.L.zab_pool_upload(self.h, len(ents), arr, audio.ctypes.data_as(C.POINTER(C.c_float)), audio.size))
+
+    def file_slot_set(self, slot: int, items, channels: int = 1, sample_rate: float = 48000.0):
+        """Assign decoded file data (interleaved doubles) to a file slot; items=None unassigns it."""
+        if items is None:
+            self._chk(self.L.zab_file_slot_set(self.h, int(slot), 0, C.c_double(0.0), None, 0))
+            return
+        a = np.ascontiguousarray(items, dtype=np.float64)
+        self._chk(self.L.zab_file_slot_set(self.h, int(slot), int(channels), C.c_double(float(sample_rate)), _dp(a), a.size))
 
     def mem_high(self, first=0, count=None) -> np.ndarray:
         cnt = self.n - first if count is None else count

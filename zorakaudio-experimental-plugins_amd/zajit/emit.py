@@ -30,10 +30,13 @@ HOST_ONLY = {"instance_uid", "instance_set_name", "instance_get_name", "track_na
              "comm_join", "msg_subscribe", "msg_unsubscribe", "msg_advertise", "msg_send", "msg_sendto",
              "msg_avail", "msg_kind", "msg_recv", "msg_send_buf", "msg_sendto_buf", "msg_recv_buf", "msg_length",
              "msg_dropped", "msg_clear", "msg_peer_count", "msg_peer_id", "msg_peer_name", "msg_peer_uid",
-             "msg_peer_caps", "msg_peer_alive", "midirecv", "midirecv_buf", "midirecv_str", "midisend",
-             "midisend_buf", "midisend_str", "midisyx", "file_open", "file_open_multi", "file_close", "file_rewind",
-             "file_seek", "file_avail", "file_text", "file_mem", "file_multi_count", "file_multi_select", "file_var",
-             "file_riff", "sample_name", "sample_preview_read", "sample_preview_bins"}
+             "msg_peer_caps", "msg_peer_alive", "sample_name", "sample_preview_read", "sample_preview_bins"}
+# file_*() over host-provided file slots (csrc/zart_file.h)
+FILE_CALLS = {"file_open", "file_open_multi", "file_close", "file_rewind", "file_seek", "file_avail", "file_text", "file_mem",
+              "file_multi_count", "file_multi_select", "file_var", "file_riff"}
+# MIDI: the batch engine has no MIDI ports. With an empty input queue the reference's midirecv*() return 0 and leave their
+# outputs untouched (src/JSFXJuceProcessor.cpp:2239-2333); with no output queue midisend*() return 0 (:2335-2420).
+MIDI_CALLS = {"midirecv", "midirecv_buf", "midirecv_str", "midisend", "midisend_buf", "midisend_str", "midisyx"}
 GMEM_CALLS = {"gmem_attach", "gmem_attach_size", "gmem_size", "gmem_get", "gmem_put", "gmem_fill", "gmem_zero",
               "gmem_copy", "gmem_seq", "gmem_page"}
 POOL_READ_CALLS = {"sample_pool_from_slot", "sample_pool_set_mode", "sample_pool_set_budget_mb", "sample_pool_commit",
@@ -361,6 +364,25 @@ class Emitter:
             pre, args = self.ordered([a for a in n.args])
             body = " ".join(f"(void)({a});" for a in args)
             return f"({{ {pre} {body} za_unsupported(s); }})"
+        if fn in MIDI_CALLS:
+            self.features.add("midi")
+            vals = [a for a in n.args if not (fn.startswith("midirecv") and isinstance(a, (S.Var, S.Index)))]
+            pre, args = self.ordered(vals)                    # value arguments are still evaluated (side effects)
+            return f"({{ {pre} {' '.join(f'(void)({a});' for a in args)} 0.0; }})"
+        if fn in FILE_CALLS:
+            self.features.add("file")
+            if fn == "file_riff":
+                self.nargs(n, 3)
+                pre, args = self.ordered(n.args[:1])
+                return self.wrap(pre, f"za_file_riff(s, {args[0]}, {self.out_ptr(n.args[1], fn)}, {self.out_ptr(n.args[2], fn)})")
+            if fn == "file_var":
+                self.nargs(n, 2)
+                pre, args = self.ordered(n.args[:1])
+                return self.wrap(pre, f"za_file_var(s, {args[0]}, {self.out_ptr(n.args[1], fn)})")
+            if fn in ("file_open", "file_open_multi") and len(n.args) == 1:
+                pre, args = self.ordered(n.args)
+                return self.wrap(pre, f"za_{fn}(s, {args[0]}, 0.0)")
+            return self.call_rt(n, "za_" + fn)
         if fn == "__memtop":
             self.nargs(n, 0)
             return c_double(float(self.p.memtop))
