@@ -1,0 +1,23 @@
+import sys; sys.path[:0]=["zorakaudio-experimental-plugins_amd","."]
+import zabatch, numpy as np
+for n, size, K in ((2048, 4096, 4), (2048, 1024, 4), (256, 4096, 4)):
+    with zabatch.Engine("fx_fftbench", n, mem_cap=1<<17) as e:
+        row = np.zeros(64); row[0]=size; row[1]=K; row[2]=15
+        e.set_sliders(row); e.prepare()
+        nch = e.nch; frames = 64
+        nb = n*nch*frames*4
+        di, do = e.device_alloc(nb), e.device_alloc(nb)
+        e.device_noise(di, frames)
+        for _ in range(2): e.process_device(di, do, frames, block=64); e.sync()
+        ms,_ = e.last_timing()
+        flops = 2*5*size*np.log2(size)
+        print(f"size={size} buffers={n} K={K}: {ms:.2f} ms -> {ms/K*1e3:.1f} us per round trip of the batch, {n*K*flops/ms/1e6:.1f} GFLOP/s, {n*K*4*2*size*16/ms/1e6:.1f} GB/s (4 ops x r+w)", flush=True)
+for leaf, n, frames in (("fx_stft4k", 1024, 16384), ("fx_stft", 1024, 16384), ("DOT", 1024, 16384), ("PsychoConvolver", 1024, 16384)):
+    with zabatch.Engine(leaf, n, mem_cap=(1<<22) if leaf=="PsychoConvolver" else 0) as e:
+        e.set_sliders(zabatch.leaf_meta(leaf)["default_sliders"]); e.prepare()
+        nb = n*2*frames*4
+        di, do = e.device_alloc(nb), e.device_alloc(nb)
+        e.device_noise(di, frames)
+        for _ in range(2): e.process_device(di, do, frames); e.sync()
+        ms,_ = e.last_timing()
+        print(f"{leaf} N={n} frames={frames}: {ms:.1f} ms  {n*2*frames/ms/1e3:.1f} Msamples/s  rt x{frames/48000/(ms/1e3):.2f}", flush=True)

@@ -70,6 +70,7 @@ __device__ __forceinline__ void za_state_bind(ZaS& s, const ZabBatch& b, int ins
   s.fft_stride = b.fft_se;
   s.fft_cap = b.fft ? b.fft_cap : 0;
   s.gmem_attached = b.gmem_att ? b.gmem_att[inst] : 0;
+  s.replica = 0;
   s.files = (const ZaFileView*)b.files;
   s.fh = b.fh ? b.fh + (int64_t)inst * b.fh_si : nullptr;
   s.fh_stride = b.fh_se;
@@ -152,11 +153,24 @@ extern "C" __global__ void __launch_bounds__(64) ZA_KERNEL(process)(ZabBatch b, 
   const int lane = threadIdx.x;
   const int ipw = b.ipw;
   const int inst0 = blockIdx.x * ipw;
+#if ZA_USES_FFT && !ZA_USES_GMEM
+  // REPLICA LANES: a thin wavefront (ipw < 64) runs every instance on 64 / ipw lanes at once -- identical state, identical
+  // control flow, identical (hence harmless) stores. Nothing is gained for the serial code, but every lane now reaches the
+  // FFT builtins, whose wave-cooperative form (zart_fft.h) spreads ONE instance's transform over all of them.
+  const int row = lane % ipw;
+  const bool primary = lane < ipw;
+  const int inst = inst0 + row;
+  const bool active = inst < b.n_inst;
+#else
+  const int row = lane;
+  const bool primary = true;
   const int inst = inst0 + lane;
   const bool active = lane < ipw && inst < b.n_inst;
+#endif
   ZaS s;
   if (active) {
     za_state_load(s, b, inst);
+    s.replica = primary ? 0u : 1u;
     if (b.flags[inst] & ZAB_FLAG_SLIDER_DIRTY) {      // processBlock: sliders changed -> jsfx_slider (:3545-3547)
       za_alias_sync(s);
       za_section_slider(s);
@@ -195,11 +209,11 @@ extern "C" __global__ void __launch_bounds__(64) ZA_KERNEL(process)(ZabBatch b, 
       __syncthreads();
       if (active) {
         for (int t = 0; t < tn; ++t) {
-#define ZA_X(ch) s.spl[ch] = (double)tile[ch][lane][t];
+#define ZA_X(ch) s.spl[ch] = (double)tile[ch][row][t];
           ZA_FOR_CH(ZA_X)
 #undef ZA_X
           za_section_sample(s);
-#define ZA_X(ch) tile[ch][lane][t] = (float)s.spl[ch];
+#define ZA_X(ch) tile[ch][row][t] = (float)s.spl[ch];
           ZA_FOR_CH(ZA_X)
 #undef ZA_X
         }
@@ -215,7 +229,7 @@ extern "C" __global__ void __launch_bounds__(64) ZA_KERNEL(process)(ZabBatch b, 
 #endif
     if (active) s.pend_change = s.pend_automate = s.pend_automate_end = 0;   // consumeDspSliderChanges (:3745)
   }
-  if (active) za_state_store(s, b, inst);
+  if (active && primary) za_state_store(s, b, inst);
 }
 
 // processBlock prologue for the hand-written kernels: instances whose sliders changed run @slider first (:3545-3547).

@@ -206,7 +206,12 @@ int zab_create(const char* module, const zab_config* cfg, zab_engine** out) {
     // Measured on the catalog at 1024 instances (profiles/README.md): thinning pays for leaves with many channels (tile
     // staging is NCH x ipw loads per frame: NeuroCV 18 ch 200 -> 87 ms, RED 6 ch 74 -> 39 ms) and is neutral to slightly
     // negative for 2..4-channel leaves, so it is applied from 6 channels up.
-    int ipw = m->nch >= 6 ? 16 : 64;
+    // Leaves with FFT builtins on the audio path (prefer_instance_major == 2) run 8 instances per wavefront, each on 8
+    // replica lanes (zab_generic.hip.h): the cooperative transforms (zart_fft.h) then queue 8 requests per wave instead
+    // of 64 and the chip runs 8x the wavefronts. Measured at 1024-2048 instances (ipw 64 / 16 / 8 / 4 / 1): FFT round trip
+    // 11.4 / 2.9 / 1.45 / 1.45 / 1.46 ms, STFT fixture 443 / 276 / 248 / 232 / 780 ms, DOT 642 / 600 / 593 / 593 / 2200 ms --
+    // below ~4 the serial parts pay for 64x the memory instructions chip-wide.
+    int ipw = m->prefer_instance_major == 2 ? 8 : (m->nch >= 6 ? 16 : 64);
     while (ipw < 64 && (int64_t)cfg->n_instances > 2048ll * ipw) ipw <<= 1;
     if (const char* f = getenv("ZAB_IPW")) { const int v = atoi(f); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) ipw = v; }
     b.ipw = ipw;

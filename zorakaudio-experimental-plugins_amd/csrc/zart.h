@@ -76,6 +76,7 @@ struct ZaState {
   double* fft;           // FFT builtin scratch (natural-order work area), element a at fft[a * fft_stride]
   int64_t fft_stride;
   int64_t fft_cap;       // doubles available (0 when the leaf has no FFT builtins)
+  uint32_t replica;      // this lane duplicates another lane's instance (zab_generic.hip.h): it must not raise requests of its own
   const ZaFileView* files; // file slots of the engine (zart_file.h); null when the leaf has no file builtins
   int64_t* fh;           // this instance's file handle words, word k at fh[k * fh_stride]
   int64_t fh_stride;
@@ -140,7 +141,7 @@ ZA_FN void za_note_store(S& s, int64_t end) {
 template <class S>
 ZA_FN double za_st(S& s, int64_t a, double v) {
   za_note_store(s, a + 1);
-  if (a < s.mem_cap) s.mem[a * s.mem_stride] = v;
+  if (a < s.mem_cap && !s.replica) s.mem[a * s.mem_stride] = v;   // (replica lanes would store the same value again)
   return v;
 }
 

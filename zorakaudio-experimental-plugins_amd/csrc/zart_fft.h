@@ -137,7 +137,8 @@ template <class S>
 __device__ __noinline__ bool za_fft_coop(S& s, bool ok, int64_t base, int n, int op) {
   __shared__ double buf[2 * ZA_FFT_COOP_MAX];
   double* const tw = za_fft_tw;
-  const bool mine = ok && n <= ZA_FFT_COOP_MAX;
+  const bool coop = ok && n <= ZA_FFT_COOP_MAX;
+  const bool mine = coop && !s.replica;            // replica lanes help with their primary's request, they add none
   const uint64_t active = __ballot(1);
   uint64_t todo = __ballot(mine);
   const int lane = (int)(threadIdx.x & 63);
@@ -243,7 +244,7 @@ __device__ __noinline__ bool za_fft_coop(S& s, bool ok, int64_t base, int n, int
     __builtin_amdgcn_wave_barrier();
 #undef ZA_G
   }
-  return mine;
+  return coop;
 }
 #define ZA_FFT_TRY_COOP(op) if (za_fft_coop(s, ok, base, (int)n, op)) return 0.0
 #else
