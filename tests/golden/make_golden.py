@@ -47,6 +47,10 @@ CASES = [
     ("TSEQ", "default", {}, 2048, 512),
     ("fx_stft", "default", {0: 0.4}, 4096, 512),      # repo-authored fixture leaf (tests/fixtures/stft.jsfx)
     ("fx_stft4k", "default", {0: -0.3}, 12288, 512),  # the same at BASELINE config C3's size: 4096-point, hop 1024
+    # random programs over the constructs the AOT lowering and the EEL2 VM agree on (tests/fixtures/make_fuzz.py)
+    ("fx_fuzz0", "default", {0: 3.0}, 600, 128), ("fx_fuzz1", "default", {0: 7.5}, 600, 128),
+    ("fx_fuzz2", "default", {0: 0.0}, 600, 128), ("fx_fuzz3", "default", {0: 10.0}, 600, 128),
+    ("fx_fuzz4", "default", {0: 2.5}, 600, 128), ("fx_fuzz5", "default", {0: 5.0}, 600, 128),
     # DOT is deliberately absent: its `topo == 1 ? K=4 : (...)` chain (DOT.jsfx:372) parses differently in EEL2
     # (unparenthesised assignment inside ?: -> K stays 0) and in the reference's AOT parser (K = 2), so the reference's
     # own shadow VM disagrees with its compiled path on this leaf; DOT is checked device-vs-port instead.
