@@ -103,3 +103,31 @@ def test_api_edges_empty_input_oversize_block_and_call_order():
     with pytest.raises(zabatch.ZabError) as ei:
         zabatch.Engine("NoSuchLeaf", 1)
     assert ei.value.code == -2
+
+
+@pytest.mark.parametrize("leaf", ["DDT", "SOMA", "ClickBeGoneSG"])
+def test_checkpoint_resume_continues_bit_identically(leaf, tmp_path):
+    """the single-instance state exchange doubles as a checkpoint. Run, checkpoint (through an .npz file),
+    keep running; a fresh engine restored from the checkpoint must continue with exactly the same output and end state.
+    SOMA covers rand() state and a grown arena, DDT the hand-written kernel, ClickBeGoneSG a Faust leaf."""
+    import zabatch
+    from zajit import noise
+    meta = zabatch.leaf_meta(leaf)
+    n, frames = 5, 1500
+    cap = 1 << 20 if leaf == "SOMA" else 0
+    x = noise.white_noise(range(n), 2 * frames)
+    rows = np.tile(np.array(meta["default_sliders"], dtype=np.float64), (n, 1))
+    rows[:, 0] += np.arange(n)                                   # distinct first slider per instance
+    with zabatch.Engine(leaf, n, mem_cap=cap) as e:
+        e.set_sliders(rows); e.prepare()
+        e.process_host(x[:, :, :frames], block=512)
+        ck = e.checkpoint()
+        np.savez(tmp_path / "ck.npz", **ck)
+        want = e.process_host(x[:, :, frames:], block=512)
+        want_vars = e.read_vars()
+    ck = dict(np.load(tmp_path / "ck.npz"))
+    with zabatch.Engine(leaf, n, mem_cap=cap) as e2:
+        e2.restore(ck)
+        got = e2.process_host(x[:, :, frames:], block=512)
+        assert np.array_equal(got, want)
+        assert np.array_equal(e2.read_vars(), want_vars)

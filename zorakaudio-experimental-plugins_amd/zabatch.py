@@ -32,6 +32,13 @@ class zab_config(C.Structure):
                 ("path", C.c_int32), ("mem_cap", C.c_int64), ("first_instance_id", C.c_uint64)]
 
 
+class zab_host_state(C.Structure):      # include/zabatch.h
+    _fields_ = [("spl", C.POINTER(C.c_double)), ("sliders", C.POINTER(C.c_double)), ("vars", C.POINTER(C.c_double)),
+                ("mem", C.POINTER(C.c_double)), ("mem_n", C.c_int64), ("pending_masks", C.POINTER(C.c_int64)),
+                ("rand_mt", C.POINTER(C.c_uint32)), ("rand_index", C.POINTER(C.c_uint32)),
+                ("slider_visible_mask", C.POINTER(C.c_int64)), ("slider_visibility_init", C.POINTER(C.c_int32))]
+
+
 class zab_pool_entry(C.Structure):
     _fields_ = [("offset_items", C.c_int64), ("frames", C.c_int32), ("sample_rate", C.c_int32), ("channels", C.c_int32),
                 ("peak", C.c_float), ("rms", C.c_float)]
@@ -97,6 +104,9 @@ def load_runtime():
     L.zab_used_fast_path.argtypes = [vp]
     L.zab_last_kernel_name.argtypes = [vp]
     L.zab_last_kernel_name.restype = C.c_char_p
+    L.zab_state_upload.argtypes = [vp, i32, C.POINTER(zab_host_state)]
+    L.zab_state_download.argtypes = [vp, i32, C.POINTER(zab_host_state)]
+    L.zab_run_section.argtypes = [vp, i32, i32]
     L.zab_gmem_read.argtypes = [vp, i64, i64, C.POINTER(d)]
     L.zab_gmem_write.argtypes = [vp, i64, i64, C.POINTER(d)]
     L.zab_gmem_seq.argtypes = [vp, i64, C.POINTER(C.c_uint64)]
@@ -144,6 +154,7 @@ class Engine:
         self.info = info
         self.nch = info.n_channels
         self.nvars = info.nvars
+        self.mem_cap = int(info.mem_cap)
         self._owned = []
 
     def _chk(self, rc):
@@ -313,6 +324,53 @@ class Engine:
             return
         a = np.ascontiguousarray(items, dtype=np.float64)
         self._chk(self.L.zab_file_slot_set(self.h, int(slot), int(channels), C.c_double(float(sample_rate)), _dp(a), a.size))
+
+    # -- checkpoint / resume (the state exchange format doubles as the engine's checkpoint) -------------------
+    def _host_state(self, arrs):
+        h = zab_host_state()
+        P = C.POINTER
+        h.spl = arrs["spl"].ctypes.data_as(P(C.c_double)); h.sliders = arrs["sliders"].ctypes.data_as(P(C.c_double))
+        h.vars = arrs["vars"].ctypes.data_as(P(C.c_double))
+        if arrs["mem"].size:
+            h.mem = arrs["mem"].ctypes.data_as(P(C.c_double))
+        h.mem_n = arrs["mem"].size
+        h.pending_masks = arrs["masks"].ctypes.data_as(P(C.c_int64))
+        h.rand_mt = arrs["mt"].ctypes.data_as(P(C.c_uint32)); h.rand_index = arrs["mti"].ctypes.data_as(P(C.c_uint32))
+        h.slider_visible_mask = arrs["vis"].ctypes.data_as(P(C.c_int64))
+        h.slider_visibility_init = arrs["visi"].ctypes.data_as(P(C.c_int32))
+        return h
+
+    def checkpoint(self) -> dict:
+        """Everything zab_process depends on, per instance, as numpy arrays: spl / sliders / vars, mem[] up to the write
+        high-water mark (sparse: untouched tails are not stored), pending slider masks, MT19937 state, visibility. The
+        shared gmem segment, sample pool and file slots belong to the host and are not part of it."""
+        n, nv = self.n, max(1, self.nvars)
+        high = self.mem_high()
+        out = {"leaf": np.array(self.leaf), "srate": np.array(self.srate), "spl": np.zeros((n, 64)), "sliders": np.zeros((n, 64)),
+               "vars": np.zeros((n, nv)), "masks": np.zeros((n, 3), np.int64), "mt": np.zeros((n, 624), np.uint32),
+               "mti": np.zeros(n, np.uint32), "vis": np.zeros(n, np.int64), "visi": np.zeros(n, np.int32),
+               "mem_high": high.astype(np.int64)}
+        mems = []
+        for i in range(n):
+            a = {k: out[k][i:i + 1].reshape(-1) if out[k].ndim > 1 else out[k][i:i + 1] for k in ("spl", "sliders", "vars", "masks", "mt", "mti", "vis", "visi")}
+            a["mem"] = np.zeros(int(min(high[i], self.mem_cap)))
+            h = self._host_state(a)
+            self._chk(self.L.zab_state_download(self.h, i, C.byref(h)))
+            mems.append(a["mem"])
+        out["mem_offsets"] = np.concatenate([[0], np.cumsum([m.size for m in mems])]).astype(np.int64)
+        out["mem_data"] = np.concatenate(mems) if mems else np.zeros(0)
+        return out
+
+    def restore(self, ck: dict):
+        """Load a checkpoint() into this engine (same leaf, same instance count); the next zab_process continues from it."""
+        if str(ck["leaf"]) != self.leaf or ck["vars"].shape[0] != self.n:
+            raise ZabError(-1, "checkpoint does not match this engine (leaf / instance count)")
+        off = ck["mem_offsets"]
+        for i in range(self.n):
+            a = {k: np.ascontiguousarray(ck[k][i:i + 1].reshape(-1) if ck[k].ndim > 1 else ck[k][i:i + 1]) for k in ("spl", "sliders", "vars", "masks", "mt", "mti", "vis", "visi")}
+            a["mem"] = np.ascontiguousarray(ck["mem_data"][off[i]:off[i + 1]])
+            h = self._host_state(a)
+            self._chk(self.L.zab_state_upload(self.h, i, C.byref(h)))
 
     def mem_high(self, first=0, count=None) -> np.ndarray:
         cnt = self.n - first if count is None else count
