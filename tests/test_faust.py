@@ -82,7 +82,7 @@ def test_modtilt_zero_tilt_is_identity_and_blocks_do_not_matter():
 
 
 VARIANTS = [("ClickBeGoneSG", "generic"), ("ClickBeGoneSG", "wave1"), ("ClickBeGoneSG", "wave4"),
-            ("ModTilt", "generic"), ("GTS", "generic"), ("VAR", "generic"), ("RED", "generic"),
+            ("ModTilt", "generic"), ("ModTilt", "wave"), ("GTS", "generic"), ("VAR", "generic"), ("RED", "generic"), ("RED", "wave"),
             ("ClickBeGoneSG", "generic64"), ("ModTilt", "generic64"), ("RED", "generic64")]   # 64 instances per wavefront
 
 
@@ -116,7 +116,8 @@ def test_gpu_matches_restatement(leaf, variant, monkeypatch):
     if variant == "generic64":
         monkeypatch.setenv("ZAB_IPW", "64")
     if variant.startswith("wave"):
-        monkeypatch.setenv("ZAB_CBG_G", variant[4:])
+        if variant[4:]:
+            monkeypatch.setenv("ZAB_CBG_G", variant[4:])
         path = zabatch.ZAB_PATH_FAST
     n, frames = 70, 3000                                  # two workgroups, ragged tile tail
     x = _input(leaf, list(range(40, 40 + n)), frames)
