@@ -82,7 +82,7 @@ def test_modtilt_zero_tilt_is_identity_and_blocks_do_not_matter():
 
 
 VARIANTS = [("ClickBeGoneSG", "generic"), ("ClickBeGoneSG", "wave1"), ("ClickBeGoneSG", "wave4"),
-            ("ModTilt", "generic"), ("ModTilt", "wave"), ("GTS", "generic"), ("VAR", "generic"), ("RED", "generic"), ("RED", "wave"),
+            ("ModTilt", "generic"), ("ModTilt", "wave"), ("GTS", "generic"), ("VAR", "generic"), ("VAR", "wave"), ("RED", "generic"), ("RED", "wave"),
             ("ClickBeGoneSG", "generic64"), ("ModTilt", "generic64"), ("RED", "generic64")]   # 64 instances per wavefront
 
 
