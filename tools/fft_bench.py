@@ -1,4 +1,7 @@
-import sys; sys.path[:0]=["zorakaudio-experimental-plugins_amd","."]
+"""FFT builtin throughput (BASELINE config C3 ii) and the STFT / FFT-using leaves: python tools/fft_bench.py  (GPU box)"""
+import sys; from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path[:0] = [str(ROOT / "zorakaudio-experimental-plugins_amd"), str(ROOT)]
 import zabatch, numpy as np
 for n, size, K in ((2048, 4096, 4), (2048, 1024, 4), (256, 4096, 4)):
     with zabatch.Engine("fx_fftbench", n, mem_cap=1<<17) as e:

@@ -1,6 +1,6 @@
-"""rebuild a leaf module and dump the device asm of one kernel: python scratch/asm.py DDT zab_ddt_fast /tmp/k1.s"""
+"""rebuild a leaf module and dump the device asm of one kernel: python tools/kernel_asm.py DDT zab_ddt_fast /tmp/k1.s"""
 import sys, subprocess
-sys.path.insert(0, 'zorakaudio-experimental-plugins_amd')
+sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parent.parent / 'zorakaudio-experimental-plugins_amd'))
 from zajit import build
 from pathlib import Path
 leaf, kern, out = sys.argv[1], sys.argv[2], sys.argv[3]

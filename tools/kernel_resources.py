@@ -1,6 +1,6 @@
-"""Print register / scratch / occupancy of a leaf module's kernels: python scratch/kres.py DDT [filter]"""
+"""Print register / scratch / occupancy of a leaf module's kernels: python tools/kernel_resources.py DDT [filter]"""
 import sys, re, subprocess
-sys.path.insert(0, 'zorakaudio-experimental-plugins_amd')
+sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parent.parent / 'zorakaudio-experimental-plugins_amd'))
 from zajit import build
 leaf = sys.argv[1]; filt = sys.argv[2] if len(sys.argv) > 2 else ''
 cmd = [build.HIPCC] + build.HIP_FLAGS + ["-I", str(build.CSRC), "-Rpass-analysis=kernel-resource-usage", "-o", "/tmp/kres_t.so",

@@ -1,4 +1,4 @@
-"""quick bench: python scratch/qb.py N FRAMES [label] -> one short line (value, kernel_ms, frac)"""
+"""quick bench: python tools/quick_bench.py N FRAMES [label] -> one short line (value, kernel_ms, frac)"""
 import json, subprocess, sys
 n, fr = sys.argv[1], sys.argv[2]
 lab = sys.argv[3] if len(sys.argv) > 3 else ""
