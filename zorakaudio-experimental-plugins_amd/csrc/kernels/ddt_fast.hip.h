@@ -8,12 +8,17 @@
 //     One WORKGROUP PER INSTANCE made of NW wavefronts (NW = 1, 2, 4 or 8, chosen so that the batch fills the chip);
 //     each wavefront takes one 256-frame chunk per iteration, each lane 4 consecutive frames of it.
 //   * The mono delay history M[n] = 0.5*(L[n]+R[n]) (the only thing the taps read: :467-468) lives in one LDS ring
-//     shared by the workgroup (plain circular layout plus a 256-slot mirror of its head behind its tail).
+//     shared by the workgroup. Two addressing modes (ddt_geometry): a DOUBLED ring of Dmax + NW*256 + 1 frames (rounded to
+//     256) stored twice back to back, so `frame - delay` never wraps in the tap phase; or, when twice the history does
+//     not fit beside 8 resident waves per CU, a power-of-two ring with masked byte offsets. Either has a copy of its
+//     first 256 slots behind its end for the strided reads.
 //   * Tap phase: lane l takes frames {l, 64+l, 128+l, 192+l} of its chunk, so the gather `frame - delay` of a wave reads
 //     64 consecutive ring slots per k (conflict-free for every delay) and the four k differ by a constant 512 bytes:
-//     one masked address per (tap, channel), the rest are ds_read immediates. Tap parameters are wave-uniform LDS
-//     broadcasts, staged as two lists (early taps, late taps, each in source order). The four sums then move to the
-//     "4 consecutive frames per lane" layout through a per-wave LDS transpose.
+//     one address per (tap, channel), the rest are ds_read immediates. Tap parameters live in registers -- lane j keeps
+//     staged tap j (early taps first, then late taps, each in source order) -- and are broadcast with v_readlane; the
+//     eight ring reads of a tap are issued one tap ahead of their FMAs. The four sums then move to the "4 consecutive
+//     frames per lane" layout through a per-wave LDS transpose.
+//   * The HBM read of a wave's next chunk is issued a whole iteration ahead of its use.
 //   * The six filter recurrences y[n] = (1-a) x[n] + a y[n-1]: 4 serial steps inside the lane, a weighted 64-lane scan
 //     of the lane aggregates with coefficient a^4 done with DPP (row_shr 1/2/4/8, row_bcast15, row_bcast31 -- no LDS
 //     crossbar traffic, no lane masks), a chunk-to-chunk carry chain across the NW waves through 6 doubles of LDS per
@@ -23,7 +28,7 @@
 //     weighted partial sums and reduced once, at the end.
 //   * HBM traffic per frame: 8 B in + 8 B out (float4 per lane per channel, 1 KiB per wave instruction); the f64
 //     rings in mem[] are written only for the last 16384 frames of a launch (older slots would be overwritten).
-//     vars[] / tap tables are touched once per launch. Measured with FETCH_SIZE/WRITE_SIZE: 1.0002x these bytes.
+//     vars[] / tap tables are touched once per launch. Measured with FETCH_SIZE/WRITE_SIZE: 1.0004x these bytes.
 //
 // State contract: on exit vars[] and mem[] hold what the serial path would hold (all @sample temporaries of the last
 // frame included), within the scan's rounding for the filter states -- tests/test_ddt_gpu.py compares both paths.
