@@ -140,6 +140,7 @@ struct DdtCtx {
   double* SPL;
   int bufmask, W, m8, nE, nT, mon;
   double col, one_m_col, directGain, wetp, dryp, out_gain;
+  double dgc, dgm, mixd, mixw;   // folded products: directGain*(1-col), directGain*col*0.5, dryp*out_gain, wetp*out_gain
   bool vec_ok;
 };
 
@@ -295,10 +296,11 @@ __device__ __forceinline__ void ddt_phase_b(const DdtCtx& C, const DdtTapRegs& R
   // direct path (:444-451)
 #pragma unroll
   for (int k = 0; k < DDT_KF; ++k) {
+    // dIn = directGain * (x*(1-col) + mono*col) (:447-451) with the constant products folded (re-association, ~1e-16)
     const double x0 = (double)K.x0[k], x1 = (double)K.x1[k];
-    const double mc = (0.5 * (x0 + x1)) * C.col;
-    K.y[0][k] = C.directGain * __builtin_fma(x0, C.one_m_col, mc);
-    K.y[1][k] = C.directGain * __builtin_fma(x1, C.one_m_col, mc);
+    const double mc = (x0 + x1) * C.dgm;
+    K.y[0][k] = __builtin_fma(x0, C.dgc, mc);
+    K.y[1][k] = __builtin_fma(x1, C.dgc, mc);
   }
   if (want_last && lane == 63) {                           // the launch's final frame: leave its temporaries in vars[]
     const int q = DDT_KF - 1;
@@ -306,7 +308,8 @@ __device__ __forceinline__ void ddt_phase_b(const DdtCtx& C, const DdtTapRegs& R
     double* V = C.V;
     V[ZA_VAR_mono] = M;
     V[ZA_VAR_srcL] = __builtin_fma(x0, C.one_m_col, M * C.col); V[ZA_VAR_srcR] = __builtin_fma(x1, C.one_m_col, M * C.col);
-    V[ZA_VAR_dInL] = K.y[0][q]; V[ZA_VAR_dInR] = K.y[1][q];
+    V[ZA_VAR_dInL] = C.directGain * __builtin_fma(x0, C.one_m_col, M * C.col);
+    V[ZA_VAR_dInR] = C.directGain * __builtin_fma(x1, C.one_m_col, M * C.col);
     V[ZA_VAR_sumEL] = K.y[2][q]; V[ZA_VAR_sumER] = K.y[3][q]; V[ZA_VAR_sumLL] = K.y[4][q]; V[ZA_VAR_sumLR] = K.y[5][q];
   }
   // one-poles (:453-454, 486-490): local responses + wave scans
@@ -341,8 +344,8 @@ __device__ __forceinline__ void ddt_phase_c(const DdtCtx& C, DdtChunk& K, int la
     else if (C.mon == 1) { oL = dirZL; oR = dirZR; }
     else if (C.mon == 2) { oL = dL; oR = dR; }
     else { oL = yL; oR = yR; }
-    double s0 = __builtin_fma(C.dryp, x0, C.wetp * oL) * C.out_gain;
-    double s1 = __builtin_fma(C.dryp, x1, C.wetp * oR) * C.out_gain;
+    double s0 = __builtin_fma(C.mixd, x0, C.mixw * oL);      // (dryp*x + wetp*o) * out_gain (:500-503), gains folded
+    double s1 = __builtin_fma(C.mixd, x1, C.mixw * oR);
     s0 = s0 > 8.0 ? 8.0 : (s0 < -8.0 ? -8.0 : s0);
     s1 = s1 > 8.0 ? 8.0 : (s1 < -8.0 ? -8.0 : s1);
     o0[k] = (float)s0; o1[k] = (float)s1;
@@ -440,6 +443,8 @@ __device__ __forceinline__ void ddt_fast_body(const ZabBatch& b, const ZabAudio&
   const double distN = (tt * tt) * (3.0 - 2.0 * tt);
   C.col = pow(distN, 0.8);
   C.one_m_col = 1.0 - C.col;
+  C.dgc = C.directGain * C.one_m_col; C.dgm = C.directGain * C.col * 0.5;
+  C.mixd = C.dryp * C.out_gain; C.mixw = C.wetp * C.out_gain;
   C.mon = za_i32(slider8);
 
   const double poles[3] = {V[ZA_VAR_a_dir], V[ZA_VAR_a_early], V[ZA_VAR_a_late]};
