@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(64) zf_cbg_wave(ZabBatch b, ZabAudio a) {
       xs[g][0][lane] = hl; xs[g][1][lane] = hr;
     }
   }
-  __syncthreads();
+  zf_wave_sync();
 
   // the HBM read of chunk k+1 is issued before chunk k is processed (registers), so its latency hides behind the phases
   float nxL[G], nxR[G];
@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(64) zf_cbg_wave(ZabBatch b, ZabAudio a) {
       if (g < ng) { xs[g][0][32 + lane] = nxL[g]; xs[g][1][32 + lane] = nxR[g]; }
     }
     fetch(t0 + 64);
-    __syncthreads();
+    zf_wave_sync();
     // ---- B: feed-forward, lane = frame: predictors, error norms, HPF input ---------------------------------------------
     for (int g = 0; g < ng; ++g) {
       const L::Ctl c = ctls[g];
@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(64) zf_cbg_wave(ZabBatch b, ZabAudio a) {
       us[g][0][lane] = aL(0) - aL(1);
       us[g][1][lane] = aR(0) - aR(1);
     }
-    __syncthreads();
+    zf_wave_sync();
     // ---- C: recursion 1, lane = instance -------------------------------------------------------------------------------
     if (lane < ng) {
       if (tn == 64) {                                                 // full chunk: straight-line code, LDS reads up front
@@ -111,10 +111,10 @@ __global__ void __launch_bounds__(64) zf_cbg_wave(ZabBatch b, ZabAudio a) {
         }
       }
     }
-    __syncthreads();
+    zf_wave_sync();
     // ---- D: feed-forward: trigger --------------------------------------------------------------------------------------
     for (int g = 0; g < ng; ++g) th[g][lane] = L::trigger(ctls[g], eb[g][0][lane], eb[g][1][lane], pp[g][4][lane]);
-    __syncthreads();
+    zf_wave_sync();
     // ---- E: recursion 2, lane = instance -------------------------------------------------------------------------------
     if (lane < ng) {
       if (tn == 64) {
@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(64) zf_cbg_wave(ZabBatch b, ZabAudio a) {
         for (int n = 0; n < tn; ++n) th[lane][n] = L::hold_step(st, myc, th[lane][n]);
       }
     }
-    __syncthreads();
+    zf_wave_sync();
     // ---- F: feed-forward: mix and store; roll the history rows ----------------------------------------------------------
     for (int g = 0; g < ng; ++g) {
       const L::Ctl c = ctls[g];
@@ -140,10 +140,10 @@ __global__ void __launch_bounds__(64) zf_cbg_wave(ZabBatch b, ZabAudio a) {
       // frames tn-32 .. tn-1 of the extended row become the next chunk's (or the next launch's) history
       float keepL = 0.f, keepR = 0.f;
       if (lane < 32) { keepL = xs[g][0][tn + lane]; keepR = xs[g][1][tn + lane]; }
-      __syncthreads();
+      zf_wave_sync();
       if (lane < 32) { xs[g][0][lane] = keepL; xs[g][1][lane] = keepR; }
     }
-    __syncthreads();
+    zf_wave_sync();
   }
 
   // ---- launch epilogue ----------------------------------------------------------------------------------------------------

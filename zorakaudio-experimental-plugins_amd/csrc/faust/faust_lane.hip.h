@@ -21,6 +21,11 @@
 
 #define ZF_FN __device__ __forceinline__
 
+// Phase boundary inside a SINGLE-WAVE workgroup (the wave kernels): a wave's LDS accesses execute in order, so other lanes'
+// LDS writes are visible once the compiler is kept from reordering; __syncthreads() would also drain the HBM prefetch of
+// the next chunk and the output stores (s_waitcnt vmcnt(0)) at every phase boundary.
+ZF_FN void zf_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 // control-rate transcendental functions: evaluated in f64 and rounded once (the CPU restatement does the same), so the
 // coefficients on both sides are the same floats
 ZF_FN float zf_exp(float x) { return (float)exp((double)x); }
@@ -81,7 +86,7 @@ __global__ void __launch_bounds__(64) zf_process(ZabBatch b, ZabAudio a) {
         if (idx < ipw * L::NCH * TT) tile[ch][row][t] = xv[u];
       }
     }
-    __syncthreads();
+    zf_wave_sync();
     if (active) {
       for (int t = 0; t < tn; ++t) {
         float x[L::NCH];
@@ -92,13 +97,13 @@ __global__ void __launch_bounds__(64) zf_process(ZabBatch b, ZabAudio a) {
         for (int ch = 0; ch < L::NCH; ++ch) tile[ch][lane][t] = x[ch];
       }
     }
-    __syncthreads();
+    zf_wave_sync();
     for (int idx = lane; idx < ipw * L::NCH * TT; idx += 64) {
       const int t = idx % TT, rc = idx / TT, ch = rc % L::NCH, row = rc / L::NCH;
       if (t < tn && inst0 + row < b.n_inst)
         a.out[((int64_t)(inst0 + row) * L::NCH + ch) * a.frame_stride + t0 + t] = tile[ch][row][t];
     }
-    __syncthreads();
+    zf_wave_sync();
   }
   if (active) {
 #pragma unroll

@@ -22,7 +22,7 @@ __device__ __forceinline__ void zf_serial64(float* row, int lane, int tn, F step
       for (int n = 0; n < tn; ++n) row[n] = step(row[n]);
     }
   }
-  __syncthreads();
+  zf_wave_sync();
 }
 
 // K independent recursions of the SAME shape at once: lane k (k < K) runs `step(k, x) -> y` over rows[k][0 .. tn) in place.
@@ -41,5 +41,5 @@ __device__ __forceinline__ void zf_serial64_rows(float (*rows)[64], int lane, in
       for (int n = 0; n < tn; ++n) row[n] = step(lane, row[n]);
     }
   }
-  __syncthreads();
+  zf_wave_sync();
 }

@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(64) zf_gts_wave(ZabBatch b, ZabAudio a) {
   const float* in0 = a.in + (int64_t)inst * 2 * a.frame_stride;
   float* out0 = a.out + (int64_t)inst * 2 * a.frame_stride;
   float nx0 = lane < a.frames ? in0[lane] : 0.0f, nx1 = lane < a.frames ? in0[a.frame_stride + lane] : 0.0f;
-  __syncthreads();
+  zf_wave_sync();
 
   for (int64_t t0 = 0; t0 < a.frames; t0 += 64) {
     const int tn = (int)((a.frames - t0 < 64) ? (a.frames - t0) : 64);
@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(64) zf_gts_wave(ZabBatch b, ZabAudio a) {
         sm[lane][n] = y;
       }
     }
-    __syncthreads();
+    zf_wave_sync();
     // ---- lane = frame ----------------------------------------------------------------------------------------------
     const float sigmaMs = sm[0][lane], attackDB = sm[1][lane], sustainDB = sm[2][lane], mix = sm[3][lane], outGain = sm[4][lane];
     const float sigmaSamples = zf_max(0.25f, sigmaMs * SR * 0.001f);    // :69-70
@@ -103,10 +103,10 @@ __global__ void __launch_bounds__(64) zf_gts_wave(ZabBatch b, ZabAudio a) {
     float keep[2][4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) { keep[0][q] = xs[0][tn + lane + 64 * q]; keep[1][q] = xs[1][tn + lane + 64 * q]; }
-    __syncthreads();
+    zf_wave_sync();
 #pragma unroll
     for (int q = 0; q < 4; ++q) { xs[0][lane + 64 * q] = keep[0][q]; xs[1][lane + 64 * q] = keep[1][q]; }
-    __syncthreads();
+    zf_wave_sync();
   }
   if (lane < 5) b.vars[(L::S_SM + lane) * b.var_se + inst * b.var_si] = (double)y;
   for (int d = 1 + lane; d <= L::HIST; d += 64) {

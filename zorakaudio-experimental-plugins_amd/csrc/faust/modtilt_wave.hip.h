@@ -33,16 +33,16 @@ __global__ void __launch_bounds__(64) zf_modtilt_wave(ZabBatch b, ZabAudio a) {
     }
     const float x = 0.5f * (xL + xR);                                    // :52
     work[lane] = x * x;                                                  // :55
-    __syncthreads();
+    zf_wave_sync();
     zf_serial64(work, lane, tn, [&](float v) { return L::onepole(c.a_env, v, st[L::S_ENV2]); });    // env2 (:56)
     const float e = sqrtf(zf_max(work[lane], 0.0f));                     // :57
     env[lane] = e; base[lane] = e;
-    __syncthreads();
+    zf_wave_sync();
     zf_serial64(base, lane, tn, [&](float v) { return L::onepole(c.a_base, v, st[L::S_BASE]); });   // base (:60)
     const float bs = base[lane];
     const float m = e - bs;                                              // :63
     mm[lane] = m; lp[lane] = m;
-    __syncthreads();
+    zf_wave_sync();
     zf_serial64(lp, lane, tn, [&](float v) { return L::onepole(c.a_piv, v, st[L::S_LP]); });        // pivot LPF (:66)
     {
       const float l = lp[lane];
@@ -55,12 +55,12 @@ __global__ void __launch_bounds__(64) zf_modtilt_wave(ZabBatch b, ZabAudio a) {
       const float r0c = zf_min(zf_max(r0, 0.67f), 1.5f);                 // :83
       work[lane] = r0c - 1.0f;
     }
-    __syncthreads();
+    zf_wave_sync();
     zf_serial64(work, lane, tn, [&](float v) { return L::onepole(0.05f, v, st[L::S_RS]); });        // ratio smoother (:86)
     const float r_s = 1.0f + work[lane];
-    __syncthreads();                                                     // (work is reused below)
+    zf_wave_sync();                                                     // (work is reused below)
     work[lane] = 20.0f * zf_log10(zf_max(r_s, 1e-12f));                  // :90
-    __syncthreads();
+    zf_wave_sync();
     zf_serial64(work, lane, tn, [&](float v) { return L::onepole(c.a_trim, v, st[L::S_MEAN]); });   // auto-trim (:91)
     const float trim = zf_pow(10.0f, (0.0f - work[lane]) / 20.0f);       // :92
     const float yL = xL * r_s, yR = xR * r_s;                            // :95-99
@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(64) zf_modtilt_wave(ZabBatch b, ZabAudio a) {
       out0[t0 + lane] = (xL * (1.0f - c.mix) + yL * c.mix) * trim;
       out0[a.frame_stride + t0 + lane] = (xR * (1.0f - c.mix) + yR * c.mix) * trim;
     }
-    __syncthreads();
+    zf_wave_sync();
   }
   if (lane == 0) {
 #pragma unroll

@@ -37,34 +37,34 @@ __global__ void __launch_bounds__(64) zf_red_wave(ZabBatch b, ZabAudio a) {
     const float wetL = x[0], wetR = x[1], refL = x[4], refR = x[5];
     r2[0][lane] = 0.5f * (wetL * wetL + wetR * wetR);                                   // wet_p, ref_p (:66-67)
     r2[1][lane] = 0.5f * (refL * refL + refR * refR);
-    __syncthreads();
+    zf_wave_sync();
     // group 1: wet_env2 (lane 0), ref_env2 (lane 1)                                       :70-71
     zf_serial64_rows<2>(r2, lane, tn, [&](int, float v) { return L::smooth(c.pole_rms, v, g1); });
     const float Ey = zf_max(sqrtf(zf_max(r2[0][lane], 0.0f)), c.floor_lin), Ex = zf_max(sqrtf(zf_max(r2[1][lane], 0.0f)), c.floor_lin);
     const float dryA = (float)(Ex > c.dry_on_lin), offA = (float)(Ex <= c.ref_off_lin);   // :76-77
     r1[lane] = offA;
-    __syncthreads();
+    zf_wave_sync();
     zf_serial64(r1, lane, tn, [&](float v) { return L::smooth(c.pole_grace, v, st[L::S_OFF]); });    // group 2: offA_s (:81)
     const float tail_w = (1.0f - offA) + offA * L::smoothstep01(r1[lane]);                // :82
     const float rdB = 20.0f * zf_log10(zf_max((Ey + eps) / (Ex + eps), 1e-30f));          // :85
     const float over = rdB - c.thr_db;
     const float over_eff = (over <= 0.0f) ? 0.0f : over * L::smoothstep01(L::clampf(over / c.knee, 0.0f, 1.0f));
     const float tgt0 = (over_eff > 0.0f) ? zf_min(c.maxduck_dB, over_eff * c.ratio) : 0.0f;          // :95-96
-    __syncthreads();
+    zf_wave_sync();
     r2[0][lane] = tgt0 * tail_w;                                                          // tgt1
     r2[1][lane] = dryA;
-    __syncthreads();
+    zf_wave_sync();
     // group 3: tgt_db (lane 0, pole_tgt), dryA_s (lane 1, 10 ms pole)                      :99,105
     zf_serial64_rows<2>(r2, lane, tn, [&](int, float v) { return L::smooth(pole3, v, g3); });
     const float tgt_db = r2[0][lane], dryA_s = r2[1][lane];
     r1[lane] = tgt_db;
-    __syncthreads();
+    zf_wave_sync();
     zf_serial64(r1, lane, tn, [&](float v) { return L::smooth(c.pole_hold, v, st[L::S_HOLD]); });    // group 4: hold (:110)
     const float tgt_hold = zf_max(tgt_db, r1[lane]);
     const float tgt_pin = (1.0f - dryA) * tgt_hold + dryA * tgt_db;
-    __syncthreads();
+    zf_wave_sync();
     r2[0][lane] = fabsf(tgt_pin); r2[1][lane] = fabsf(tgt_pin);
-    __syncthreads();
+    zf_wave_sync();
     // group 5: gr_norm (lane 0, release), gr_fast (lane 1, release with reference present)   :118-119
     zf_serial64_rows<2>(r2, lane, tn, [&](int, float v) { return L::ar(c.catt, rel5, v, g5); });
     const float gr_db = (1.0f - dryA_s) * r2[0][lane] + dryA_s * r2[1][lane];             // :122
@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(64) zf_red_wave(ZabBatch b, ZabAudio a) {
 #pragma unroll
       for (int ch = 2; ch < 6; ++ch) out0[ch * a.frame_stride + t0 + lane] = x[ch];      // pass-through channels
     }
-    __syncthreads();
+    zf_wave_sync();
   }
   // lane 0 holds the states it advanced alone and those of the paired groups' first member; lane 1 the second members
 #define ZF_PUT(K, v) b.vars[(K) * b.var_se + inst * b.var_si] = (double)(v)

@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(64) zf_var_wave(ZabBatch b, ZabAudio a) {
   const float eps = 1e-12f;
   const float one_m_ds = 1.0f - c.detSmooth_a, one_m_lv = 1.0f - c.hfLvl_a;
   float nxL = lane < a.frames ? in0[lane] : 0.0f, nxR = lane < a.frames ? in0[a.frame_stride + lane] : 0.0f;
-  __syncthreads();
+  zf_wave_sync();
   for (int64_t t0 = 0; t0 < a.frames; t0 += 64) {
     const int tn = (int)((a.frames - t0 < 64) ? (a.frames - t0) : 64);
     const float xL = nxL, xR = nxR;
@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(64) zf_var_wave(ZabBatch b, ZabAudio a) {
     xin[0][lane] = xL; xin[1][lane] = xR;
     const uint32_t ri = rnd * jumpA + 12345u * jumpS;                                  // this frame's LCG state
     nzr[lane] = (float)(int32_t)ri / 2147483647.0f;
-    __syncthreads();
+    zf_wave_sync();
     rnd = (uint32_t)__shfl((int)ri, tn - 1, 64);                                       // state after the chunk's last frame
     // ---- S1: per-channel chains on lanes 0 / 1 -----------------------------------------------------------------------------
     if (lane < 2) {
@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(64) zf_var_wave(ZabBatch b, ZabAudio a) {
         detr[lane][n] = det; sm2r[lane][n] = sm2; hfr[lane][n] = hf;
       }
     }
-    __syncthreads();
+    zf_wave_sync();
     // ---- M2: curvature of the smoothed detector, detector level, per frame -------------------------------------------------
     float curv[2];
 #pragma unroll
@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(64) zf_var_wave(ZabBatch b, ZabAudio a) {
     }
     hfabs[lane] = 0.5f * (fabsf(detr[0][lane]) + fabsf(detr[1][lane]));                // :129
     curvn[lane] = 0.5f * (curv[0] + curv[1]);
-    __syncthreads();
+    zf_wave_sync();
     if (lane < 2) {                                                                    // x', x'' for the next chunk
       const float d1 = sm2r[lane][tn - 1];
       const float d2 = tn >= 2 ? sm2r[lane][tn - 2] : dly[lane][0];
@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(64) zf_var_wave(ZabBatch b, ZabAudio a) {
         airr[n] = L::tf22t(airz, c.air, nzr[n]);                                       // :177-178
       }
     }
-    __syncthreads();
+    zf_wave_sync();
     // ---- M3: trigger, gains, mix, per frame -----------------------------------------------------------------------------------
     {
       const float amount = amr[lane], sens = ser[lane];
@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(64) zf_var_wave(ZabBatch b, ZabAudio a) {
         out0[a.frame_stride + t0 + lane] = (xR + hfr[1][lane] * (g - 1.0f) + air * airGain) * 1.0f;
       }
     }
-    __syncthreads();
+    zf_wave_sync();
   }
 #define ZF_PUT(K, v) b.vars[(K) * b.var_se + inst * b.var_si] = (double)(v)
   if (lane < 2) {

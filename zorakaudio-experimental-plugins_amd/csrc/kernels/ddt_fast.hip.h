@@ -83,6 +83,11 @@ __device__ __forceinline__ double ddt_dpp(double v) {
 #define DDT_ROW_BCAST15 0x142
 #define DDT_ROW_BCAST31 0x143
 
+// Workgroup barrier of the chunk loop: LDS traffic must have landed (lgkmcnt), but the HBM prefetch of the next chunk and
+// the output stores must stay in flight -- __syncthreads() would drain them too (s_waitcnt vmcnt(0)) and put a full memory
+// latency back into every iteration.
+__device__ __forceinline__ void ddt_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ double ddt_clamp(double x, double a, double b) { return x < a ? a : (x > b ? b : x); }
 __device__ __forceinline__ double ddt_ipow(double base, int64_t e) {   // base^e, e >= 0, square-and-multiply
   double r = 1.0;
@@ -556,7 +561,7 @@ __device__ __forceinline__ void ddt_fast_body(const ZabBatch& b, const ZabAudio&
     if (DBL) { pos += NW * DDT_CHUNK; pos = pos >= W ? pos - W : pos; }
     if (active) ddt_phase_a<PART, DBL>(C, K, lane, f0, nb, pf0, pf1);
     prefetch(c + NW);                                      // this wave's next chunk: in flight across phases B and C
-    __syncthreads();                                       // ring holds every frame of this iteration
+    ddt_barrier();                                         // ring holds every frame of this iteration
     if (active) {
       ddt_phase_b<PART, DBL>(C, R, K, lane, f0, nb, carry, head, cb1, cb2, want_last);
       if (lane == 63) {
@@ -565,7 +570,7 @@ __device__ __forceinline__ void ddt_fast_body(const ZabBatch& b, const ZabAudio&
       }
       my_last_chunk = c;
     }
-    __syncthreads();                                       // chunk-end responses published; taps of this iteration done
+    ddt_barrier();                                         // chunk-end responses published; taps of this iteration done
     // carry chain: state entering wave w's chunk = a^256 * (state entering w-1) + response of w-1; wave 0 injected `carry`
     double cw[6] = {0, 0, 0, 0, 0, 0};
     {

@@ -37,6 +37,10 @@
 
 typedef ZaState<ZA_NV> ZaS;
 
+// Phase boundary inside a single-wave workgroup: a wave's LDS accesses execute in order, so only the compiler has to be
+// kept from reordering them; __syncthreads() would also wait for the tile's output stores to reach memory (vmcnt(0)).
+__device__ __forceinline__ void za_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 #ifndef ZA_KERNEL_ENTRY
 #define ZA_KERNEL_ENTRY() (void)0      /* leaves with FFT builtins reset their LDS twiddle flag here (zart_fft.h) */
 #endif
@@ -206,7 +210,7 @@ extern "C" __global__ void __launch_bounds__(64) ZA_KERNEL(process)(ZabBatch b, 
           if (idx < ipw * ZA_NCH * ZA_TT) tile[ch][row][t] = xv[u];
         }
       }
-      __syncthreads();
+      za_wave_sync();
       if (active) {
         for (int t = 0; t < tn; ++t) {
 #define ZA_X(ch) s.spl[ch] = (double)tile[ch][row][t];
@@ -218,13 +222,13 @@ extern "C" __global__ void __launch_bounds__(64) ZA_KERNEL(process)(ZabBatch b, 
 #undef ZA_X
         }
       }
-      __syncthreads();
+      za_wave_sync();
       for (int idx = lane; idx < ipw * ZA_NCH * ZA_TT; idx += 64) {
         const int t = idx % ZA_TT, rc = idx / ZA_TT, ch = rc % ZA_NCH, row = rc / ZA_NCH;
         if (t < tn && inst0 + row < b.n_inst)
           a.out[((int64_t)(inst0 + row) * ZA_NCH + ch) * a.frame_stride + pos + t0 + t] = tile[ch][row][t];
       }
-      __syncthreads();
+      za_wave_sync();
     }
 #endif
     if (active) s.pend_change = s.pend_automate = s.pend_automate_end = 0;   // consumeDspSliderChanges (:3745)
