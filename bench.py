@@ -198,6 +198,21 @@ def main() -> int:
                          "kernel": kernel_name, "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": alg, "bytes_per_frame": alg / (n_inst * frames)},
         }
+        try:    # what a plain device copy reaches on this box (SURVEY §8d asks for it beside the spec peak)
+            src = torch.empty(1 << 28, dtype=torch.float32, device="cuda")        # 1 GiB
+            dst = torch.empty_like(src)
+            dst.copy_(src); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                dst.copy_(src)
+            e1.record(); torch.cuda.synchronize()
+            copy_gbs = 5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            line["roofline"]["device_copy_gbs"] = copy_gbs
+            line["roofline"]["frac_of_device_copy"] = achieved / copy_gbs
+            del src, dst
+        except Exception:
+            pass
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
