@@ -115,7 +115,7 @@ def test_dot_device_vs_port():
         assert np.abs(mem[i] - p.mem(0, 57344)).max() <= SCALAR_EPS, i
 
 
-HOST_ASSISTED = ["IPCProbeA", "IPCProbeB", "3DPannerManager", "CMD", "3DPanner"]     # msg bus / comm
+HOST_ASSISTED = ["IPCProbeA", "IPCProbeB", "3DPannerManager", "3DPanner"]     # message bus
 
 
 @pytest.mark.parametrize("leaf", HOST_ASSISTED)
@@ -184,3 +184,32 @@ def test_file_slot_leaves_device_vs_port(leaf, loaded):
             assert np.abs(mem - q.mem(0, len(mem))).max() <= SCALAR_EPS
     if loaded and leaf == "PsychoConvolver":
         assert np.abs(y).max() > 1.0          # the loaded impulse response is really convolved in
+
+
+def test_cmd_bus_leaf_device_vs_port():
+    """Spectral/CMD talks over gmem only (comm_join / instance_set_name succeed: an engine is one domain with one segment).
+    One instance on the device against the CPU port: audio, vars, mem and the cells it wrote to the shared segment."""
+    import zabatch
+    from oracle import port
+    from zajit import noise
+    if not zabatch.module_path("CMD").exists() or not port.port_path("CMD").exists():
+        pytest.skip("CMD not built")
+    meta = zabatch.leaf_meta("CMD")
+    frames = 2048
+    x = noise.white_noise([3], frames)
+    with zabatch.Engine("CMD", 1, mem_cap=1 << 20) as e:
+        e.set_sliders(meta["default_sliders"]); e.prepare()
+        y = e.process_host(x, block=512)
+        v = e.read_vars(); names = e.var_names()
+        cells = e.gmem_read(0, 1 << 16)
+        high = int(e.mem_high()[0])
+        mem = e.read_mem(0, high)[0]
+    p = port.Port("CMD", 48000.0, mem_cap=1 << 20)
+    p.set_sliders(meta["default_sliders"]); p.prepare()
+    ref = p.process(x[0], 512)
+    assert np.abs(y[0].astype(np.float64) - ref).max() <= AUDIO_EPS
+    assert_state_close(names, v[0], p.vars(), what="CMD vars")
+    assert int(p.mem_high) == high and np.abs(mem - p.mem(0, high)).max() <= SCALAR_EPS
+    want = p.gmem_read(0, 1 << 16)
+    assert np.array_equal(cells != 0, want != 0) and np.count_nonzero(cells) > 0        # same cells written
+    assert np.abs(cells - want).max() <= SCALAR_EPS * max(1.0, np.abs(want).max())

@@ -25,15 +25,20 @@ PURE_MATH2 = {"pow": "pow", "atan2": "atan2"}
 NOOP_CALLS = {"sprintf", "printf", "strcpy", "strcat", "strcmp", "strlen", "str_getchar", "str_setchar",
               "str_insert", "str_delete", "str_mid", "strncpy", "file_read", "file_write", "file_string"}
 # builtins that need a host (MIDI, files, strings, messaging): reaching one on the device latches ZA_ERR_UNSUPPORTED.
-HOST_ONLY = {"instance_uid", "instance_set_name", "instance_get_name", "track_name", "host_track_name",
-             "track_name_available", "host_track_name_available", "track_name_seq", "host_track_name_seq",
-             "comm_join", "msg_subscribe", "msg_unsubscribe", "msg_advertise", "msg_send", "msg_sendto",
+HOST_ONLY = {"msg_subscribe", "msg_unsubscribe", "msg_advertise", "msg_send", "msg_sendto",
              "msg_avail", "msg_kind", "msg_recv", "msg_send_buf", "msg_sendto_buf", "msg_recv_buf", "msg_length",
              "msg_dropped", "msg_clear", "msg_peer_count", "msg_peer_id", "msg_peer_name", "msg_peer_uid",
              "msg_peer_caps", "msg_peer_alive", "sample_name", "sample_preview_read", "sample_preview_bins"}
 # file_*() over host-provided file slots (csrc/zart_file.h)
 FILE_CALLS = {"file_open", "file_open_multi", "file_close", "file_rewind", "file_seek", "file_avail", "file_text", "file_mem",
               "file_multi_count", "file_multi_select", "file_var", "file_riff"}
+# Identity / host-context builtins with a fixed answer in a batch engine (reference: src/DspJsfxRuntimeBuiltins.cpp:67-140):
+#   there is no DAW track, so the track-name queries answer "none" (0), as the reference does for an empty name;
+#   an engine is one communication domain with one gmem segment, so comm_join() / instance_set_name() succeed (1);
+#   strings are opaque handles on the device, so instance_uid() / instance_get_name() cannot fill one and return 0.
+HOST_CONST = {"track_name": 0, "host_track_name": 0, "track_name_available": 0, "host_track_name_available": 0,
+              "track_name_seq": 0, "host_track_name_seq": 0, "comm_join": 1, "instance_set_name": 1, "instance_uid": 0,
+              "instance_get_name": 0}
 # MIDI: the batch engine has no MIDI ports. With an empty input queue the reference's midirecv*() return 0 and leave their
 # outputs untouched (src/JSFXJuceProcessor.cpp:2239-2333); with no output queue midisend*() return 0 (:2335-2420).
 MIDI_CALLS = {"midirecv", "midirecv_buf", "midirecv_str", "midisend", "midisend_buf", "midisend_str", "midisyx"}
@@ -364,6 +369,11 @@ class Emitter:
             pre, args = self.ordered([a for a in n.args])
             body = " ".join(f"(void)({a});" for a in args)
             return f"({{ {pre} {body} za_unsupported(s); }})"
+        if fn in HOST_CONST:
+            self.features.add("hostconst")
+            vals = [a for a in n.args if not isinstance(a, (S.Var, S.Index)) or fn in ("comm_join", "instance_set_name")]
+            pre, args = self.ordered(vals)
+            return f"({{ {pre} {' '.join(f'(void)({a});' for a in args)} {float(HOST_CONST[fn])}; }})"
         if fn in MIDI_CALLS:
             self.features.add("midi")
             vals = [a for a in n.args if not (fn.startswith("midirecv") and isinstance(a, (S.Var, S.Index)))]
