@@ -29,6 +29,12 @@ struct ZaPort {
   std::vector<ZaPoolEntry> pent;
   ZaPoolView pview;
 #endif
+#ifdef ZA_MSG_H_INCLUDED
+  ZaBusView bview;                       // a bus with this one instance on it
+  std::vector<ZaMsg> mring, moutbox, minbox;
+  uint64_t mseq, mdomain, mlast, mch_hash[ZA_MSG_CHANNELS], mch_caps[ZA_MSG_CHANNELS], mch_dropped[ZA_MSG_CHANNELS];
+  uint32_t mch_flags[ZA_MSG_CHANNELS], mout_count, min_count;
+#endif
 #ifdef ZA_FILE_H_INCLUDED
   ZaFileView fview;
   std::vector<double> fitems[ZA_FILE_SLOTS];
@@ -51,6 +57,16 @@ ZaPort* port_create(double srate, int64_t mem_cap) {
   p->s.mt_stride = 1;
   p->s.srate = srate;
   p->s.instance_id = 1;
+#ifdef ZA_MSG_H_INCLUDED
+  p->mring.assign(ZA_MSG_RING, ZaMsg{}); p->moutbox.assign(ZA_MSG_OUTBOX, ZaMsg{}); p->minbox.assign(ZA_MSG_INBOX, ZaMsg{});
+  p->mseq = 0; p->mdomain = ZA_MSG_DEFAULT_DOMAIN; p->mlast = 0; p->mout_count = 0; p->min_count = 0;
+  memset(p->mch_hash, 0, sizeof p->mch_hash); memset(p->mch_caps, 0, sizeof p->mch_caps);
+  memset(p->mch_dropped, 0, sizeof p->mch_dropped); memset(p->mch_flags, 0, sizeof p->mch_flags);
+  p->bview = ZaBusView{p->mring.data(), &p->mseq, &p->mdomain, p->mch_hash, p->mch_flags, p->mch_caps, p->mch_dropped, &p->mlast,
+                       p->moutbox.data(), &p->mout_count, p->minbox.data(), &p->min_count, 1u, 0u, 1ull};
+  p->s.bus = &p->bview;
+  p->s.inst_index = 0;
+#endif
 #ifdef ZA_FILE_H_INCLUDED
   memset(&p->fview, 0, sizeof p->fview);
   memset(p->fhw, 0, sizeof p->fhw);
@@ -103,6 +119,9 @@ void port_process(ZaPort* p, const float* in, float* out, int nCh, int64_t frame
     int n = (int)((frames - pos < block) ? frames - pos : block);
     s.samplesblock = (double)n;
     s.block_size = n;
+#ifdef ZA_MSG_H_INCLUDED
+    za_msg_begin_block(s);
+#endif
     za_section_block(s);
     if (s.pend_change | s.pend_automate | s.pend_automate_end) za_section_slider(s);
 #if ZA_HAS_SAMPLE
@@ -113,6 +132,9 @@ void port_process(ZaPort* p, const float* in, float* out, int nCh, int64_t frame
     }
 #endif
     s.pend_change = s.pend_automate = s.pend_automate_end = 0;
+#ifdef ZA_MSG_H_INCLUDED
+    za_msg_flush_all(&p->bview);
+#endif
   }
 }
 

@@ -115,25 +115,56 @@ def test_dot_device_vs_port():
         assert np.abs(mem[i] - p.mem(0, 57344)).max() <= SCALAR_EPS, i
 
 
-HOST_ASSISTED = ["IPCProbeA", "IPCProbeB", "3DPannerManager", "3DPanner"]     # message bus
+BUS_LEAVES = ["IPCProbeA", "IPCProbeB", "3DPannerManager", "3DPanner"]     # scalar message bus
 
 
-@pytest.mark.parametrize("leaf", HOST_ASSISTED)
-def test_host_assisted_leaves_build_and_are_refused_loudly(leaf):
-    """Leaves whose default path needs the message bus (not built) go through
-    the translator and load, but the engine must not run them with stubbed host calls: the device latches
-    ZA_ERR_UNSUPPORTED and the C ABI returns ZAB_E_UNSUPPORTED."""
+@pytest.mark.parametrize("leaf", BUS_LEAVES)
+def test_bus_leaves_single_instance_device_vs_port(leaf):
+    """The reference's leaves that talk over the message bus, one instance per engine (every send finds no peer and is counted
+    as dropped, peer queries see only the instance itself), device vs CPU port; tests/test_msg_bus.py covers several instances."""
     import zabatch
-    if not zabatch.module_path(leaf).exists():
-        pytest.skip(f"module for {leaf} not built")
+    from oracle import port
+    from zajit import noise
+    if not zabatch.module_path(leaf).exists() or not port.port_path(leaf).exists():
+        pytest.skip(f"{leaf} not built")
     meta = zabatch.leaf_meta(leaf)
+    assert "msg" in meta["features"] and not any(f.startswith("host:") for f in meta["features"])
+    nch, frames, cap = int(meta["nch"]), 1536, 1 << 16
+    x = np.zeros((1, nch, frames), np.float32)
+    x[:, :2] = noise.white_noise([5], frames)[:, :min(2, nch)]
+    with zabatch.Engine(leaf, 1, mem_cap=cap, max_block=256) as e:
+        e.set_sliders(meta["default_sliders"]); e.prepare()
+        y = e.process_host(x, block=256)
+        v = e.read_vars(); names = e.var_names()
+    p = port.Port(leaf, 48000.0, mem_cap=cap)
+    p.set_sliders(meta["default_sliders"]); p.prepare()
+    ref = p.process(x[0], 256)
+    assert np.abs(y[0].astype(np.float64) - ref).max() <= AUDIO_EPS
+    assert_state_close(names, v[0], p.vars(), what=f"{leaf} vars")
+
+
+def test_bus_rejects_more_instances_than_it_holds():
+    import zabatch
+    if not zabatch.module_path("IPCProbeA").exists():
+        pytest.skip("IPCProbeA not built")
+    with pytest.raises(zabatch.ZabError) as ei:
+        zabatch.Engine("IPCProbeA", 257)
+    assert ei.value.code == -1, ei.value
+
+
+def test_host_only_builtins_are_refused_loudly():
+    """Builtins that need the host itself (buffer messages, peer names, sample previews) go through the translator and load,
+    but the engine must not run them with stubbed host calls: the device latches ZA_ERR_UNSUPPORTED and the C ABI returns
+    ZAB_E_UNSUPPORTED."""
+    import zabatch
+    meta = zabatch.leaf_meta("fx_hostonly")
     assert any(f.startswith("host:") for f in meta["features"])
-    with zabatch.Engine(leaf, 3, mem_cap=1 << 16) as e:
+    with zabatch.Engine("fx_hostonly", 3, mem_cap=1 << 16) as e:
         e.set_sliders(meta["default_sliders"])
         with pytest.raises(zabatch.ZabError) as ei:
             e.prepare()
             e.process_host(np.zeros((3, e.nch, 64), np.float32), block=64)
-        assert ei.value.code in (-5, -4), ei.value          # unsupported (or arena too small before getting there)
+        assert ei.value.code == -5, ei.value
 
 
 FILE_LEAVES = ["PsychoConvolver", "Contour", "TextureXY", "Texture"]

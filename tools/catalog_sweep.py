@@ -2,7 +2,7 @@
 
     python tools/catalog_sweep.py [--instances 1024] [--frames 48000] [--out profiles/r01_catalog_sweep.json]
 
-Leaves whose script reaches a host-only builtin (msg bus, file slots, MIDI) are reported as "host-assisted": the engine
+Leaves whose script reaches a host-only builtin (buffer messages, peer names) are reported as "host-assisted": the engine
 refuses them loudly (ZAB_E_UNSUPPORTED) instead of running them with stubbed host calls. Timing is the engine's own HIP
 events around the launches of one zab_process call (inputs resident in HBM), warm-up call discarded.
 """
@@ -35,6 +35,8 @@ def main() -> int:
         meta = zabatch.leaf_meta(leaf)
         nch = int(meta["nch"])
         row = {"leaf": leaf, "kind": meta.get("kind", "jsfx"), "nch": nch, "instances": args.instances, "frames": args.frames}
+        if "msg" in meta.get("features", []):  # one engine = one message bus = one session's worth of plugins
+            row["instances"] = min(args.instances, 256)
         run_one(zabatch, args, leaf, meta, nch, row, 0)
         m = re.search(r"needed >= (\d+)", row.get("status", ""))
         if m:                                  # fixed arena too small for this leaf: size it from the device's report

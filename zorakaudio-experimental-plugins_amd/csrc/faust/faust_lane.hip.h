@@ -124,12 +124,12 @@ template <class L> static hipError_t zf_launch_slider(const ZabBatch*, hipStream
 
 #define ZF_DEFINE_MODULE(L, KEY)                                                                                        \
   static const ZabModule zf_module = {                                                                                  \
-      ZAB_MODULE_ABI, KEY, L::NSTATE, L::NCH, L::NCH, L::NCH, 1, 0, 0, 1, 0, 64, L::names, 0, 0, 0, 0,                     \
-      zf_launch_prepare<L>, zf_launch_process<L>, zf_launch_slider<L>, nullptr, nullptr, nullptr, "zf_process", nullptr};     \
+      ZAB_MODULE_ABI, KEY, L::NSTATE, L::NCH, L::NCH, L::NCH, 1, 0, 0, 1, 0, 64, L::names, 0, 0, 0, 0, 0,                     \
+      zf_launch_prepare<L>, zf_launch_process<L>, zf_launch_slider<L>, nullptr, nullptr, nullptr, "zf_process", nullptr, nullptr};     \
   extern "C" const ZabModule* zab_module_get(void) { return &zf_module; }
 // the same with a hand-written leaf kernel as the fast path
 #define ZF_DEFINE_MODULE_FAST(L, KEY, APPLIES, LAUNCH, NAME)                                                            \
   static const ZabModule zf_module = {                                                                                  \
-      ZAB_MODULE_ABI, KEY, L::NSTATE, L::NCH, L::NCH, L::NCH, 1, 0, 0, 1, 0, 64, L::names, 0, 0, 0, 0,                     \
-      zf_launch_prepare<L>, zf_launch_process<L>, zf_launch_slider<L>, APPLIES, LAUNCH, NAME, "zf_process", nullptr};            \
+      ZAB_MODULE_ABI, KEY, L::NSTATE, L::NCH, L::NCH, L::NCH, 1, 0, 0, 1, 0, 64, L::names, 0, 0, 0, 0, 0,                     \
+      zf_launch_prepare<L>, zf_launch_process<L>, zf_launch_slider<L>, APPLIES, LAUNCH, NAME, "zf_process", nullptr, nullptr};            \
   extern "C" const ZabModule* zab_module_get(void) { return &zf_module; }

@@ -142,8 +142,8 @@ static const char* const* zf_gts_names() {
 }
 #define ZF_DEFINE_GTS_MODULE(KEY)                                                                                        \
   extern "C" const ZabModule* zab_module_get(void) {                                                                    \
-    static const ZabModule m = {ZAB_MODULE_ABI, KEY, ZfGts::NSTATE, 2, 2, 2, 1, 0, 0, 1, 0, 64, zf_gts_names(), 0, 0, 0, 0, \
+    static const ZabModule m = {ZAB_MODULE_ABI, KEY, ZfGts::NSTATE, 2, 2, 2, 1, 0, 0, 1, 0, 64, zf_gts_names(), 0, 0, 0, 0, 0, \
                                 zf_gts_launch_prepare, zf_gts_launch_process, zf_gts_launch_slider, nullptr, nullptr,   \
-                                nullptr, ZF_GTS_KERNEL_NAME, nullptr};                                                  \
+                                nullptr, ZF_GTS_KERNEL_NAME, nullptr, nullptr};                                                  \
     return &m;                                                                                                          \
   }

@@ -75,6 +75,8 @@ __device__ __forceinline__ void za_state_bind(ZaS& s, const ZabBatch& b, int ins
   s.fft_cap = b.fft ? b.fft_cap : 0;
   s.gmem_attached = b.gmem_att ? b.gmem_att[inst] : 0;
   s.replica = 0;
+  s.bus = (const ZaBusView*)b.bus;
+  s.inst_index = (uint32_t)inst;
   s.files = (const ZaFileView*)b.files;
   s.fh = b.fh ? b.fh + (int64_t)inst * b.fh_si : nullptr;
   s.fh_stride = b.fh_se;
@@ -186,6 +188,9 @@ extern "C" __global__ void __launch_bounds__(64) ZA_KERNEL(process)(ZabBatch b, 
     if (active) {
       s.samplesblock = (double)n;
       s.block_size = n;
+#if ZA_USES_MSG
+      za_msg_begin_block(s);        // DspJsfxRuntime::beginBlock: this block's ready inbox
+#endif
       za_section_block(s);
       if (s.pend_change | s.pend_automate | s.pend_automate_end) za_section_slider(s);
     }
@@ -273,6 +278,15 @@ static hipError_t za_launch_section(const ZabBatch* b, int which, double samples
   hipLaunchKernelGGL(ZA_KERNEL(section), dim3((b->n_inst + b->ipw - 1) / b->ipw), dim3(64), 0, st, *b, which, samplesblock);
   return hipGetLastError();
 }
+
+#if ZA_USES_MSG
+// DspJsfxRuntime::endBlock of every instance, in instance order (one thread: the ring order must be deterministic)
+extern "C" __global__ void ZA_KERNEL(msgflush)(ZabBatch b) { za_msg_flush_all((const ZaBusView*)b.bus); }
+static hipError_t za_launch_msg_flush(const ZabBatch* b, hipStream_t st) {
+  hipLaunchKernelGGL(ZA_KERNEL(msgflush), dim3(1), dim3(1), 0, st, *b);
+  return hipGetLastError();
+}
+#endif
 
 static hipError_t za_launch_slider(const ZabBatch* b, hipStream_t st) {
   hipLaunchKernelGGL(ZA_KERNEL(slider), dim3((b->n_inst + b->ipw - 1) / b->ipw), dim3(64), 0, st, *b);

@@ -6,7 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define ZAB_MODULE_ABI 10
+#define ZAB_MODULE_ABI 11
 
 enum { ZAB_FLAG_SLIDER_DIRTY = 1u, ZAB_FLAG_PREPARED = 2u };
 
@@ -40,6 +40,7 @@ struct ZabBatch {
   uint64_t epoch;                              // bumped by the runtime whenever host calls may have changed state
   const void* files;                           // ZaFileView* (device) or null
   int64_t* fh;    int64_t fh_se, fh_si;        // per-instance file handle words [ZA_FH_WORDS] (null when unused)
+  const void* bus;                             // ZaBusView* (device) or null
   int32_t ipw;                                 // instances per wavefront of the lane-per-instance kernels (1..64, power of
                                                // two): instance i runs in lane i % ipw of workgroup i / ipw
 };
@@ -64,6 +65,8 @@ struct ZabModule {
   int32_t uses_gmem;                 // runtime must provide a gmem segment; 2 = instances start attached (options:gmem=)
   int32_t uses_pool;                 // leaf reads the sample pool (zab_pool_upload provides it)
   int32_t uses_files;                // leaf calls file_*(): runtime provides slots + per-instance handle words
+  int32_t uses_msg;                  // leaf calls msg_*(): runtime provides the bus, runs host block by host block and
+                                     // calls launch_msg_flush after each (at most 256 instances per engine)
   // generic (translator-generated) kernels
   hipError_t (*launch_prepare)(const ZabBatch*, hipStream_t);
   hipError_t (*launch_process)(const ZabBatch*, const ZabAudio*, hipStream_t);
@@ -76,6 +79,7 @@ struct ZabModule {
   const char* generic_kernel_name;
   // one raw section (0 init, 1 slider, 2 block, 3 sample) on every instance; null for leaves without sections (Faust)
   hipError_t (*launch_section)(const ZabBatch*, int which, double samplesblock, hipStream_t);
+  hipError_t (*launch_msg_flush)(const ZabBatch*, hipStream_t);   // end of a host block: every outbox to the bus ring
 };
 
 extern "C" const ZabModule* zab_module_get(void);

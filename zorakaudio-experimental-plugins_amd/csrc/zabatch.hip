@@ -82,6 +82,15 @@ __global__ void zab_k_scatter(T* base, int64_t se, int64_t n, const T* staging) 
 struct ZabFileSlotDev { const double* items; int64_t n_items; int32_t channels; int32_t assigned; double srate; };
 struct ZabFileViewDev { ZabFileSlotDev slot[16]; };
 enum { kFileHandleWords = 26 };
+// mirrors ZaMsg / ZaBusView of csrc/zart_msg.h
+struct ZabMsgDev { uint64_t seq, chan, src, target; double tag, a, b, c, d; uint32_t kind, pad; };
+struct ZabBusViewDev {
+  ZabMsgDev* ring; uint64_t* global_seq; uint64_t* domain; uint64_t* ch_hash; uint32_t* ch_flags; uint64_t* ch_caps;
+  uint64_t* ch_dropped; uint64_t* last_read; ZabMsgDev* outbox; uint32_t* out_count; ZabMsgDev* inbox; uint32_t* in_count;
+  uint32_t n_inst, pad; uint64_t first_id;
+};
+enum { kMsgRing = 4096, kMsgChannels = 24, kMsgOutbox = 1024, kMsgInbox = 1024, kMsgMaxInstances = 256 };
+static const uint64_t kMsgDefaultDomain = 0x9ae16a3b2f90404full;
 
 struct zab_engine {
   void* dl = nullptr;
@@ -101,6 +110,8 @@ struct zab_engine {
   unsigned long long *gmem_cells = nullptr, *gmem_page_seq = nullptr, *gmem_global_seq = nullptr;
   uint64_t gmem_cell_count = 0;
   uint32_t pool_generation = 0;
+  ZabBusViewDev* d_bus = nullptr;         // message bus view (device) + host copy of the pointers
+  ZabBusViewDev h_bus{};
   ZabFileViewDev* d_files = nullptr;      // file slot table (device) + its host copy
   ZabFileViewDev h_files{};
   void* state_stage = nullptr;      // device staging for zab_state_upload/download
@@ -138,6 +149,43 @@ static int setup_gmem(zab_engine* e) {
   e->b.gmem = dv;
   e->gmem_cells = v.cells; e->gmem_page_seq = v.page_seq; e->gmem_global_seq = v.global_seq; e->gmem_cell_count = cells;
   return ZAB_OK;
+}
+
+// message bus of an engine whose leaf calls msg_*(): every instance registered in the default domain, nothing subscribed
+static int reset_bus(zab_engine* e) {
+  const ZabBusViewDev& v = e->h_bus;
+  const size_t n = (size_t)e->b.n_pad;
+  HIP_TRY(hipMemsetAsync(v.ring, 0, sizeof(ZabMsgDev) * kMsgRing, e->stream));
+  HIP_TRY(hipMemsetAsync(v.global_seq, 0, 8, e->stream));
+  HIP_TRY(hipMemsetAsync(v.ch_hash, 0, 8 * n * kMsgChannels, e->stream));
+  HIP_TRY(hipMemsetAsync(v.ch_flags, 0, 4 * n * kMsgChannels, e->stream));
+  HIP_TRY(hipMemsetAsync(v.ch_caps, 0, 8 * n * kMsgChannels, e->stream));
+  HIP_TRY(hipMemsetAsync(v.ch_dropped, 0, 8 * n * kMsgChannels, e->stream));
+  HIP_TRY(hipMemsetAsync(v.last_read, 0, 8 * n, e->stream));
+  HIP_TRY(hipMemsetAsync(v.out_count, 0, 4 * n, e->stream));
+  HIP_TRY(hipMemsetAsync(v.in_count, 0, 4 * n, e->stream));
+  std::vector<uint64_t> dom(n, kMsgDefaultDomain);
+  HIP_TRY(hipMemcpyAsync(v.domain, dom.data(), 8 * n, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return ZAB_OK;
+}
+static int setup_bus(zab_engine* e) {
+  if (e->b.n_inst > kMsgMaxInstances)
+    return fail(ZAB_E_ARG, "%s exchanges messages: at most %d instances per engine (the reference's per-domain instance table)",
+                e->mod->name, (int)kMsgMaxInstances);
+  ZabBusViewDev& v = e->h_bus;
+  const size_t n = (size_t)e->b.n_pad;
+  int rc;
+  if ((rc = e->alloc(&v.ring, kMsgRing)) || (rc = e->alloc(&v.global_seq, 1)) || (rc = e->alloc(&v.domain, n)) ||
+      (rc = e->alloc(&v.ch_hash, n * kMsgChannels)) || (rc = e->alloc(&v.ch_flags, n * kMsgChannels)) ||
+      (rc = e->alloc(&v.ch_caps, n * kMsgChannels)) || (rc = e->alloc(&v.ch_dropped, n * kMsgChannels)) ||
+      (rc = e->alloc(&v.last_read, n)) || (rc = e->alloc(&v.outbox, n * kMsgOutbox)) || (rc = e->alloc(&v.out_count, n)) ||
+      (rc = e->alloc(&v.inbox, n * kMsgInbox)) || (rc = e->alloc(&v.in_count, n)) || (rc = e->alloc(&e->d_bus, 1)))
+    return rc;
+  v.n_inst = (uint32_t)e->b.n_inst; v.pad = 0; v.first_id = e->b.first_id;
+  if (hipMemcpyAsync(e->d_bus, &v, sizeof v, hipMemcpyHostToDevice, e->stream) != hipSuccess) return fail(ZAB_E_HIP, "bus view upload failed");
+  e->b.bus = e->d_bus;
+  return reset_bus(e);
 }
 
 static hipError_t create_events(zab_engine* e) {
@@ -255,7 +303,8 @@ int zab_create(const char* module, const zab_config* cfg, zab_engine** out) {
       (rc = e->alloc(&b.vis_init, (size_t)P)) ||
       (m->fft_scratch_doubles > 0 && (rc = e->alloc(&b.fft, (size_t)P * m->fft_scratch_doubles))) ||
       (m->uses_gmem && (rc = setup_gmem(e))) ||
-      (m->uses_files && ((rc = e->alloc(&e->d_files, 1)) || (rc = e->alloc(&b.fh, (size_t)P * kFileHandleWords))))) {
+      (m->uses_files && ((rc = e->alloc(&e->d_files, 1)) || (rc = e->alloc(&b.fh, (size_t)P * kFileHandleWords)))) ||
+      (m->uses_msg && (rc = setup_bus(e)))) {
     zab_destroy(e);
     return rc;
   }
@@ -395,6 +444,7 @@ static int check_device_errors(zab_engine* e, const char* where) {
 int zab_prepare(zab_engine* e) {
   if (!e) return fail(ZAB_E_ARG, "zab_prepare: null engine");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  if (e->mod->uses_msg) { int rb = reset_bus(e); if (rb) return rb; }     // DspJsfxRuntime::reset + fresh registrations
   hipError_t he = e->mod->launch_prepare(&e->b, e->stream);
   if (he != hipSuccess) return fail(ZAB_E_HIP, "prepare launch failed: %s", hipGetErrorString(he));
   HIP_TRY(hipStreamSynchronize(e->stream));
@@ -443,11 +493,27 @@ int zab_process(zab_engine* e, const void* in, void* out, int64_t frames, int64_
     return fail(ZAB_E_ARG, "ZAB_PATH_FAST requested but %s's hand-written kernel does not apply to this configuration", e->mod->name);
   const int slot = (int)(e->n_process % zab_engine::kTimingSlots);
   HIP_TRY(hipEventRecord(e->ev0[slot], e->stream));
-  hipError_t he = fast ? e->mod->launch_fast(&e->b, &a, e->stream) : e->mod->launch_process(&e->b, &a, e->stream);
+  hipError_t he = hipSuccess;
+  if (e->mod->uses_msg && e->mod->launch_msg_flush) {
+    // message leaves: one launch per host block, every outbox flushed to the bus in between (block k's messages are
+    // block k + 1's inbox; csrc/zart_msg.h)
+    e->launches = 0;
+    for (int64_t pos = 0; pos < frames && he == hipSuccess; pos += block) {
+      ZabAudio ab = a;
+      ab.in = a.in ? a.in + pos : nullptr;
+      ab.out = a.out ? a.out + pos : nullptr;
+      ab.frames = (frames - pos < block) ? (frames - pos) : block;
+      he = e->mod->launch_process(&e->b, &ab, e->stream);
+      if (he == hipSuccess) he = e->mod->launch_msg_flush(&e->b, e->stream);
+      e->launches += 2;
+    }
+  } else {
+    he = fast ? e->mod->launch_fast(&e->b, &a, e->stream) : e->mod->launch_process(&e->b, &a, e->stream);
+  }
   if (he != hipSuccess) return fail(ZAB_E_HIP, "process launch failed: %s", hipGetErrorString(he));
   HIP_TRY(hipEventRecord(e->ev1[slot], e->stream));
   e->n_process++;
-  e->timing_valid = true; e->launches = 1; e->used_fast = fast;
+  e->timing_valid = true; if (!(e->mod->uses_msg && e->mod->launch_msg_flush)) e->launches = 1; e->used_fast = fast;
   if (placement == ZAB_BUF_HOST) {
     if (bytes) HIP_TRY(hipMemcpyAsync(out, e->stage_out, bytes, hipMemcpyDeviceToHost, e->stream));
     return zab_sync(e);

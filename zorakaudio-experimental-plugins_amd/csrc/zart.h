@@ -47,6 +47,7 @@ enum : uint32_t {
 struct ZaGmemView;   // zart_gmem.h
 struct ZaPoolView;   // zart_pool.h
 struct ZaFileView;   // zart_file.h
+struct ZaBusView;    // zart_msg.h
 
 template <int NV>
 struct ZaState {
@@ -77,6 +78,8 @@ struct ZaState {
   int64_t fft_stride;
   int64_t fft_cap;       // doubles available (0 when the leaf has no FFT builtins)
   uint32_t replica;      // this lane duplicates another lane's instance (zab_generic.hip.h): it must not raise requests of its own
+  const ZaBusView* bus;  // message bus of the engine (zart_msg.h); null when the leaf has no msg_*() calls
+  uint32_t inst_index;   // this instance's row in the bus tables (instance_id - first id of the engine)
   const ZaFileView* files; // file slots of the engine (zart_file.h); null when the leaf has no file builtins
   int64_t* fh;           // this instance's file handle words, word k at fh[k * fh_stride]
   int64_t fh_stride;

@@ -1,0 +1,290 @@
+// zart_msg.h -- block-resolved message bus between the instances of one engine, for generated section code.
+//
+// Restates the observable behaviour of the reference's per-instance runtime + shared-memory bus for scalar messages:
+//   comm_join(domain) ............ leaves the old domain (inbox and read cursor reset), joins the new one; 0 selects the default
+//                                  domain .................................................. src/DspJsfxRuntime.cpp:234-247
+//   msg_subscribe / unsubscribe / advertise(channel, caps): per-instance channel table (24 entries) ... :291-313,
+//                                  src/DspJsfxMessageBus.cpp:19-21
+//   msg_send / msg_sendto ........ appended to the instance's outbox (1024 per block, else dropped[channel]++) ... :315-372
+//   end of block ................. outbox flushed to the domain's ring (4096 slots) in order; a broadcast with no OTHER active
+//                                  instance of the domain subscribed to its channel (a direct message with no active target)
+//                                  is dropped and counted ............................ DspJsfxMessageBus.cpp:529-607
+//   start of block ............... ring entries newer than the instance's read cursor that target it (direct: target == id;
+//                                  broadcast: source != id and channel subscribed) are moved to its ready inbox; a receiver
+//                                  that lagged past the ring counts one drop per subscription ............. :609-677
+//   msg_recv / avail / kind / clear / dropped / length ........................ DspJsfxRuntime.cpp:409-478
+//   msg_peer_count / peer_id / peer_caps / peer_alive over the domain's instances (self included) ... MessageBus.cpp:713-790
+// The reference delivers what a sender flushed at the end of ITS block to whoever starts a block afterwards; instances run
+// on unrelated threads, so the order inside one host block is unspecified there. Here every instance of the engine runs
+// host block k, then all outboxes are flushed in instance order, then block k + 1 starts: a message sent in block k is
+// received in block k + 1. Buffer messages (msg_*_buf) and the string-valued peer queries stay host-only.
+#pragma once
+#define ZA_MSG_H_INCLUDED 1
+
+#include "zart.h"
+
+#define ZA_MSG_RING 4096
+#define ZA_MSG_CHANNELS 24
+#define ZA_MSG_OUTBOX 1024
+#define ZA_MSG_INBOX 1024
+#define ZA_MSG_MAX_INSTANCES 256
+#define ZA_MSG_DEFAULT_DOMAIN 0x9ae16a3b2f90404full
+
+struct ZaMsg {
+  uint64_t seq, chan, src, target;
+  double tag, a, b, c, d;
+  uint32_t kind;       // 0 none / consumed, 1 scalar
+  uint32_t pad;
+};
+struct ZaBusView {
+  ZaMsg* ring;                 // [ZA_MSG_RING]
+  uint64_t* global_seq;        // [1]
+  uint64_t* domain;            // [n]
+  uint64_t* ch_hash;           // [n][ZA_MSG_CHANNELS]
+  uint32_t* ch_flags;          // [n][ZA_MSG_CHANNELS] bit 0 subscribed, bit 1 advertised, bit 2 slot in use
+  uint64_t* ch_caps;           // [n][ZA_MSG_CHANNELS]
+  uint64_t* ch_dropped;        // [n][ZA_MSG_CHANNELS]
+  uint64_t* last_read;         // [n]
+  ZaMsg* outbox;               // [n][ZA_MSG_OUTBOX]
+  uint32_t* out_count;         // [n]
+  ZaMsg* inbox;                // [n][ZA_MSG_INBOX]  (kind 0 = consumed)
+  uint32_t* in_count;          // [n]
+  uint32_t n_inst;
+  uint32_t pad;
+  uint64_t first_id;
+};
+
+// channel / domain identity of a string handle: the handle value itself (one script per engine: equal names are equal handles)
+ZA_FN uint64_t za_msg_key(double h) { const int64_t v = za_f2i64(h + (h < 0 ? -0.5 : 0.5)); return (uint64_t)v; }
+
+template <class S> ZA_FN int za_msg_slot(S& s, uint64_t chan, bool create) {
+  const ZaBusView* B = s.bus;
+  const int64_t base = (int64_t)s.inst_index * ZA_MSG_CHANNELS;
+  int free_k = -1;
+  for (int k = 0; k < ZA_MSG_CHANNELS; ++k) {
+    const uint32_t f = B->ch_flags[base + k];
+    if ((f & 4u) && B->ch_hash[base + k] == chan) return k;
+    if (!(f & 4u) && free_k < 0) free_k = k;
+  }
+  if (!create || free_k < 0) return -1;
+  B->ch_hash[base + free_k] = chan;
+  B->ch_flags[base + free_k] = 4u;
+  B->ch_caps[base + free_k] = 0;
+  B->ch_dropped[base + free_k] = 0;
+  return free_k;
+}
+template <class S> ZA_FN void za_msg_drop(S& s, uint64_t chan) {
+  const int k = za_msg_slot(s, chan, true);
+  if (k >= 0) s.bus->ch_dropped[(int64_t)s.inst_index * ZA_MSG_CHANNELS + k] += 1u;
+}
+
+template <class S> ZA_NOINLINE double za_comm_join(S& s, double domainH) {
+  if (!s.bus) return 0.0;
+  uint64_t d = za_msg_key(domainH);
+  if (d == 0) d = ZA_MSG_DEFAULT_DOMAIN;
+  if (s.bus->domain[s.inst_index] != d) {            // joinDomain: inboxes cleared, read cursor reset
+    s.bus->in_count[s.inst_index] = 0;
+    s.bus->last_read[s.inst_index] = 0;
+  }
+  s.bus->domain[s.inst_index] = d;
+  return 1.0;
+}
+template <class S> ZA_NOINLINE double za_msg_subscribe(S& s, double chanH) {
+  if (!s.bus) return 0.0;
+  const int k = za_msg_slot(s, za_msg_key(chanH), true);
+  if (k >= 0) s.bus->ch_flags[(int64_t)s.inst_index * ZA_MSG_CHANNELS + k] |= 1u;
+  return 1.0;
+}
+template <class S> ZA_NOINLINE double za_msg_unsubscribe(S& s, double chanH) {
+  if (!s.bus) return 0.0;
+  const int k = za_msg_slot(s, za_msg_key(chanH), false);
+  if (k >= 0) s.bus->ch_flags[(int64_t)s.inst_index * ZA_MSG_CHANNELS + k] &= ~1u;
+  return 1.0;
+}
+template <class S> ZA_NOINLINE double za_msg_advertise(S& s, double chanH, double capsD) {
+  if (!s.bus) return 0.0;
+  const int64_t ci = za_f2i64(capsD + (capsD < 0 ? -0.5 : 0.5));
+  const uint64_t caps = ci < 0 ? 0 : (uint64_t)ci;
+  const int k = za_msg_slot(s, za_msg_key(chanH), caps != 0);
+  if (k >= 0) {
+    const int64_t at = (int64_t)s.inst_index * ZA_MSG_CHANNELS + k;
+    s.bus->ch_caps[at] = caps;
+    if (caps) s.bus->ch_flags[at] |= 2u; else s.bus->ch_flags[at] &= ~2u;
+  }
+  return 1.0;
+}
+template <class S> ZA_NOINLINE double za_msg_queue(S& s, uint64_t target, bool direct, double chanH, double tag, double a, double b,
+                                                  double c, double d) {
+  if (!s.bus) return 0.0;
+  const uint64_t chan = za_msg_key(chanH);
+  const uint32_t n = s.bus->out_count[s.inst_index];
+  if (n >= ZA_MSG_OUTBOX) { za_msg_drop(s, chan); return 0.0; }
+  ZaMsg& m = s.bus->outbox[(int64_t)s.inst_index * ZA_MSG_OUTBOX + n];
+  m.seq = 0; m.chan = chan; m.src = s.instance_id; m.target = direct ? target : 0;
+  m.tag = tag; m.a = a; m.b = b; m.c = c; m.d = d; m.kind = 1; m.pad = direct ? 1u : 0u;
+  s.bus->out_count[s.inst_index] = n + 1;
+  return 1.0;
+}
+template <class S> ZA_FN double za_msg_send(S& s, double chanH, double tag, double a, double b, double c, double d) {
+  return za_msg_queue(s, 0, false, chanH, tag, a, b, c, d);
+}
+template <class S> ZA_FN double za_msg_sendto(S& s, double targetD, double chanH, double tag, double a, double b, double c, double d) {
+  const int64_t t = za_f2i64(targetD + 0.5);
+  return za_msg_queue(s, t < 0 ? 0 : (uint64_t)t, true, chanH, tag, a, b, c, d);
+}
+// first unconsumed inbox entry of a channel, or -1
+template <class S> ZA_FN int64_t za_msg_front(S& s, uint64_t chan) {
+  const int64_t base = (int64_t)s.inst_index * ZA_MSG_INBOX;
+  const uint32_t n = s.bus->in_count[s.inst_index];
+  for (uint32_t i = 0; i < n; ++i)
+    if (s.bus->inbox[base + i].kind != 0 && s.bus->inbox[base + i].chan == chan) return base + i;
+  return -1;
+}
+template <class S> ZA_NOINLINE double za_msg_recv(S& s, double chanH, double* src, double* tag, double* a, double* b, double* c, double* d) {
+  if (!s.bus) return 0.0;
+  const int64_t at = za_msg_front(s, za_msg_key(chanH));
+  if (at < 0) return 0.0;
+  ZaMsg& m = s.bus->inbox[at];
+  *src = (double)m.src; *tag = m.tag; *a = m.a; *b = m.b; *c = m.c; *d = m.d;
+  m.kind = 0;
+  return 1.0;
+}
+template <class S> ZA_NOINLINE double za_msg_avail(S& s, double chanH) {
+  if (!s.bus) return 0.0;
+  const uint64_t chan = za_msg_key(chanH);
+  const int64_t base = (int64_t)s.inst_index * ZA_MSG_INBOX;
+  int cnt = 0;
+  for (uint32_t i = 0; i < s.bus->in_count[s.inst_index]; ++i) cnt += (s.bus->inbox[base + i].kind != 0 && s.bus->inbox[base + i].chan == chan);
+  return (double)cnt;
+}
+template <class S> ZA_FN double za_msg_kind(S& s, double chanH) {
+  if (!s.bus) return 0.0;
+  return za_msg_front(s, za_msg_key(chanH)) >= 0 ? 1.0 : 0.0;
+}
+template <class S> ZA_NOINLINE double za_msg_clear(S& s, double chanH) {
+  if (!s.bus) return 0.0;
+  const uint64_t chan = za_msg_key(chanH);
+  const int64_t base = (int64_t)s.inst_index * ZA_MSG_INBOX;
+  int cnt = 0;
+  for (uint32_t i = 0; i < s.bus->in_count[s.inst_index]; ++i)
+    if (s.bus->inbox[base + i].kind != 0 && s.bus->inbox[base + i].chan == chan) { s.bus->inbox[base + i].kind = 0; ++cnt; }
+  return (double)cnt;
+}
+template <class S> ZA_FN double za_msg_dropped(S& s, double chanH) {
+  if (!s.bus) return 0.0;
+  const int k = za_msg_slot(s, za_msg_key(chanH), false);
+  return k >= 0 ? (double)s.bus->ch_dropped[(int64_t)s.inst_index * ZA_MSG_CHANNELS + k] : 0.0;
+}
+template <class S> ZA_FN double za_msg_length(S& s) { (void)s; return 0.0; }      // scalar messages carry no buffer
+
+ZA_FN bool za_msg_matches(const ZaBusView* B, uint32_t j, uint64_t chan, int role) {   // channelMatches
+  const bool wantSub = role == 1 || role == 3 || role <= 0, wantPub = role == 2 || role == 3 || role <= 0;
+  const int64_t base = (int64_t)j * ZA_MSG_CHANNELS;
+  for (int k = 0; k < ZA_MSG_CHANNELS; ++k) {
+    const uint32_t f = B->ch_flags[base + k];
+    if ((f & 4u) && B->ch_hash[base + k] == chan) return (wantSub && (f & 1u)) || (wantPub && (f & 2u));
+  }
+  return false;
+}
+template <class S> ZA_NOINLINE double za_msg_peer_count(S& s, double chanH, double roleD) {
+  if (!s.bus) return 0.0;
+  const uint64_t chan = za_msg_key(chanH), dom = s.bus->domain[s.inst_index];
+  const int role = (int)za_f2i64(roleD + (roleD < 0 ? -0.5 : 0.5));
+  int cnt = 0;
+  for (uint32_t j = 0; j < s.bus->n_inst; ++j) cnt += (s.bus->domain[j] == dom && za_msg_matches(s.bus, j, chan, role));
+  return (double)cnt;
+}
+template <class S> ZA_NOINLINE double za_msg_peer_id(S& s, double chanH, double roleD, double indexD) {
+  if (!s.bus) return 0.0;
+  const uint64_t chan = za_msg_key(chanH), dom = s.bus->domain[s.inst_index];
+  const int role = (int)za_f2i64(roleD + (roleD < 0 ? -0.5 : 0.5));
+  const int64_t want = za_f2i64(indexD + (indexD < 0 ? -0.5 : 0.5));
+  if (want < 0) return 0.0;
+  int64_t cnt = 0;
+  for (uint32_t j = 0; j < s.bus->n_inst; ++j)
+    if (s.bus->domain[j] == dom && za_msg_matches(s.bus, j, chan, role)) { if (cnt == want) return (double)(s.bus->first_id + j); ++cnt; }
+  return 0.0;
+}
+template <class S> ZA_FN int64_t za_msg_peer_index(S& s, double idD) {
+  const int64_t id = za_f2i64(idD + 0.5) - (int64_t)s.bus->first_id;
+  return (id >= 0 && id < (int64_t)s.bus->n_inst) ? id : -1;
+}
+template <class S> ZA_NOINLINE double za_msg_peer_caps(S& s, double idD) {     // merged caps of the peer's advertisements
+  if (!s.bus) return 0.0;
+  const int64_t j = za_msg_peer_index(s, idD);
+  if (j < 0) return 0.0;
+  uint64_t caps = 0;
+  for (int k = 0; k < ZA_MSG_CHANNELS; ++k)
+    if (s.bus->ch_flags[j * ZA_MSG_CHANNELS + k] & 2u) caps |= s.bus->ch_caps[j * ZA_MSG_CHANNELS + k];
+  return (double)caps;
+}
+template <class S> ZA_FN double za_msg_peer_alive(S& s, double idD) { return (s.bus && za_msg_peer_index(s, idD) >= 0) ? 1.0 : 0.0; }
+
+// beginBlock: collect what the ring holds for this instance (DspJsfxMessageBus::collectInbox)
+template <class S> ZA_NOINLINE void za_msg_begin_block(S& s) {
+  const ZaBusView* B = s.bus;
+  if (!B) return;
+  const uint32_t me = s.inst_index;
+  const int64_t ibase = (int64_t)me * ZA_MSG_INBOX;
+  uint32_t n = 0;                                        // compact the ready inbox (drop consumed entries, keep order)
+  for (uint32_t i = 0; i < B->in_count[me]; ++i)
+    if (B->inbox[ibase + i].kind != 0) { if (n != i) B->inbox[ibase + n] = B->inbox[ibase + i]; ++n; }
+  const uint64_t newest = *B->global_seq, last = B->last_read[me];
+  if (newest > last) {
+    uint64_t first = last + 1;
+    if (newest > ZA_MSG_RING && first + ZA_MSG_RING <= newest) {     // lagged past the ring window
+      for (int k = 0; k < ZA_MSG_CHANNELS; ++k)
+        if ((B->ch_flags[(int64_t)me * ZA_MSG_CHANNELS + k] & 5u) == 5u) B->ch_dropped[(int64_t)me * ZA_MSG_CHANNELS + k] += 1u;
+      first = newest - ZA_MSG_RING + 1;
+    }
+    for (uint64_t q = first; q <= newest; ++q) {
+      const ZaMsg& m = B->ring[q % ZA_MSG_RING];
+      if (m.seq != q) continue;
+      bool mine;
+      if (m.target != 0) mine = m.target == s.instance_id;
+      else mine = m.src != s.instance_id && za_msg_matches(B, me, m.chan, 1);
+      if (!mine) continue;
+      if (n < ZA_MSG_INBOX) B->inbox[ibase + n++] = m;
+      else za_msg_drop(s, m.chan);
+    }
+    B->last_read[me] = newest;
+  }
+  B->in_count[me] = n;
+}
+
+// endBlock of every instance, in instance order (one thread): DspJsfxMessageBus::flushOutbox
+ZA_FN void za_msg_flush_all(const ZaBusView* B) {
+  for (uint32_t i = 0; i < B->n_inst; ++i) {
+    const uint32_t cnt = B->out_count[i];
+    const uint64_t dom = B->domain[i], me = B->first_id + i;
+    for (uint32_t k = 0; k < cnt; ++k) {
+      const ZaMsg& in = B->outbox[(int64_t)i * ZA_MSG_OUTBOX + k];
+      bool has_target = false;
+      if (in.pad) {                                      // direct
+        const int64_t j = (int64_t)in.target - (int64_t)B->first_id;
+        has_target = j >= 0 && j < (int64_t)B->n_inst && B->domain[j] == dom;
+      } else {
+        for (uint32_t j = 0; j < B->n_inst && !has_target; ++j)
+          has_target = j != i && B->domain[j] == dom && za_msg_matches(B, j, in.chan, 1);
+      }
+      if (!has_target) {                                 // dropped[channel]++ on the sender
+        const int64_t base = (int64_t)i * ZA_MSG_CHANNELS;
+        int slot = -1, free_k = -1;
+        for (int c = 0; c < ZA_MSG_CHANNELS; ++c) {
+          const uint32_t f = B->ch_flags[base + c];
+          if ((f & 4u) && B->ch_hash[base + c] == in.chan) { slot = c; break; }
+          if (!(f & 4u) && free_k < 0) free_k = c;
+        }
+        if (slot < 0 && free_k >= 0) { slot = free_k; B->ch_hash[base + slot] = in.chan; B->ch_flags[base + slot] = 4u; B->ch_caps[base + slot] = 0; B->ch_dropped[base + slot] = 0; }
+        if (slot >= 0) B->ch_dropped[base + slot] += 1u;
+        continue;
+      }
+      const uint64_t seq = ++*B->global_seq;
+      ZaMsg out = in;
+      out.seq = seq; out.src = me; out.pad = 0;
+      if (!in.pad) out.target = 0;
+      B->ring[seq % ZA_MSG_RING] = out;
+    }
+    B->out_count[i] = 0;
+  }
+}

@@ -76,6 +76,7 @@ def make_unit(prog: Program) -> Unit:
         "ZA_GMEM_AUTOATTACH": "1" if ("gmem" in em.features and prog.options.get("gmem")) else "0",
         "ZA_USES_POOL": "1" if "pool" in em.features else "0",
         "ZA_USES_FILE": "1" if "file" in em.features else "0",
+        "ZA_USES_MSG": "1" if "msg" in em.features else "0",
         "ZA_USES_FFT": "1" if "fft" in em.features else "0",
         "ZA_MEMTOP": f"{float(prog.memtop)!r}",
     }

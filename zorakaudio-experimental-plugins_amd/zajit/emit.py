@@ -25,10 +25,11 @@ PURE_MATH2 = {"pow": "pow", "atan2": "atan2"}
 NOOP_CALLS = {"sprintf", "printf", "strcpy", "strcat", "strcmp", "strlen", "str_getchar", "str_setchar",
               "str_insert", "str_delete", "str_mid", "strncpy", "file_read", "file_write", "file_string"}
 # builtins that need a host (MIDI, files, strings, messaging): reaching one on the device latches ZA_ERR_UNSUPPORTED.
-HOST_ONLY = {"msg_subscribe", "msg_unsubscribe", "msg_advertise", "msg_send", "msg_sendto",
-             "msg_avail", "msg_kind", "msg_recv", "msg_send_buf", "msg_sendto_buf", "msg_recv_buf", "msg_length",
-             "msg_dropped", "msg_clear", "msg_peer_count", "msg_peer_id", "msg_peer_name", "msg_peer_uid",
-             "msg_peer_caps", "msg_peer_alive", "sample_name", "sample_preview_read", "sample_preview_bins"}
+HOST_ONLY = {"msg_send_buf", "msg_sendto_buf", "msg_recv_buf", "msg_peer_name", "msg_peer_uid",
+             "sample_name", "sample_preview_read", "sample_preview_bins"}
+# scalar message bus between the instances of one engine (csrc/zart_msg.h)
+MSG_CALLS = {"msg_subscribe", "msg_unsubscribe", "msg_advertise", "msg_send", "msg_sendto", "msg_avail", "msg_kind", "msg_recv",
+             "msg_length", "msg_dropped", "msg_clear", "msg_peer_count", "msg_peer_id", "msg_peer_caps", "msg_peer_alive"}
 # file_*() over host-provided file slots (csrc/zart_file.h)
 FILE_CALLS = {"file_open", "file_open_multi", "file_close", "file_rewind", "file_seek", "file_avail", "file_text", "file_mem",
               "file_multi_count", "file_multi_select", "file_var", "file_riff"}
@@ -369,6 +370,14 @@ class Emitter:
             pre, args = self.ordered([a for a in n.args])
             body = " ".join(f"(void)({a});" for a in args)
             return f"({{ {pre} {body} za_unsupported(s); }})"
+        if fn in MSG_CALLS or (fn == "comm_join" and self.p.calls & MSG_CALLS):
+            self.features.add("msg")
+            if fn == "msg_recv":
+                self.nargs(n, 7)
+                pre, args = self.ordered(n.args[:1])
+                outs = ", ".join(self.out_ptr(a, fn) for a in n.args[1:])
+                return self.wrap(pre, f"za_msg_recv(s, {args[0]}, {outs})")
+            return self.call_rt(n, "za_" + fn)
         if fn in HOST_CONST:
             self.features.add("hostconst")
             vals = [a for a in n.args if not isinstance(a, (S.Var, S.Index)) or fn in ("comm_join", "instance_set_name")]
