@@ -244,3 +244,36 @@ def test_cmd_bus_leaf_device_vs_port():
     want = p.gmem_read(0, 1 << 16)
     assert np.array_equal(cells != 0, want != 0) and np.count_nonzero(cells) > 0        # same cells written
     assert np.abs(cells - want).max() <= SCALAR_EPS * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize("pooled", [False, True])
+def test_sample_leaf_device_vs_port(pooled):
+    """Generator/Sample, the catalog's largest script (4058 vars, 754 specialised functions: its user functions are real
+    calls on the device, zajit/codegen.py ZA_OUTLINE_FNS): sample pool, gmem, rand, FFT, slider_change builtins in one leaf.
+    No MIDI ports in a batch engine, so no note starts; the pool is queried every block all the same. Device vs CPU port."""
+    import zabatch
+    from oracle import port
+    from zajit import noise
+    if not zabatch.module_path("Sample").exists() or not port.port_path("Sample").exists():
+        pytest.skip("Sample not built")
+    meta = zabatch.leaf_meta("Sample")
+    n, frames, cap = 3, 2048, 1 << 19
+    x = noise.white_noise(range(n), frames)
+    rng = np.random.default_rng(3)
+    samples = [rng.standard_normal((3000, 2)).astype(np.float32) * 0.2, rng.standard_normal(1500).astype(np.float32) * 0.1]
+    with zabatch.Engine("Sample", n, mem_cap=cap) as e:
+        if pooled:
+            e.pool_upload(samples, [44100, 48000])
+        e.set_sliders(meta["default_sliders"]); e.prepare()
+        y = e.process_host(x, block=512)
+        v = e.read_vars(); names = e.var_names()
+        assert int(e.mem_high().max()) <= cap
+    for i in (0, n - 1):
+        p = port.Port("Sample", 48000.0, mem_cap=cap)
+        if pooled:
+            p.pool_upload(samples, [44100, 48000])
+        p.set_sliders(meta["default_sliders"]); p.prepare()
+        ref = p.process(x[i], 512)
+        assert np.abs(y[i].astype(np.float64) - ref).max() <= AUDIO_EPS, i
+        assert_state_close(names, v[i], p.vars(), what=f"Sample vars[{i}]")
+    assert np.abs(y).max() > 0

@@ -30,6 +30,11 @@
 #define ZA_FN static inline __attribute__((always_inline))
 #define ZA_NOINLINE static __attribute__((noinline))
 #endif
+#if defined(ZA_OUTLINE_FNS) && ZA_OUTLINE_FNS
+#define ZA_UFN ZA_NOINLINE     // user functions of a very large script: real calls (zajit/codegen.py)
+#else
+#define ZA_UFN ZA_FN
+#endif
 
 enum : uint32_t {
   ZA_ERR_MEM_OVERFLOW = 1u,   // a store addressed mem[] beyond the arena capacity

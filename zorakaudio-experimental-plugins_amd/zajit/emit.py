@@ -495,7 +495,7 @@ class Emitter:
         body = self.expr(f.body)
         self.scope.pop()
         params = "".join(f", double p_{c_ident(p)}" for p in f.params)
-        return f"template <class S> ZA_FN double fn_{c_ident(name)}(S& s{params}) {{ return {body}; }}"
+        return f"template <class S> ZA_UFN double fn_{c_ident(name)}(S& s{params}) {{ return {body}; }}"
 
     def section(self, sec: str) -> str:
         body = " ".join(self.stmt(st) for st in self.p.sections.get(sec, []))
@@ -507,7 +507,7 @@ class Emitter:
         for name in order:
             f = self.p.fns[name]
             params = "".join(f", double p_{c_ident(p)}" for p in f.params)
-            protos.append(f"template <class S> ZA_FN double fn_{c_ident(name)}(S& s{params});")
+            protos.append(f"template <class S> ZA_UFN double fn_{c_ident(name)}(S& s{params});")
         fns = [self.function(name, self.p.fns[name]) for name in order]
         secs = [self.section(sec) for sec in ("init", "slider", "block", "sample")]
         return "\n".join(protos + fns + secs) + "\n"
