@@ -183,6 +183,9 @@ int zab_used_fast_path(zab_engine* e); /* 1 if the most recent zab_process ran t
 /* Name of the kernel the most recent zab_process launched (as rocprofv3 --kernel-trace lists it; templated kernels by the
  * substring before the template arguments). Valid until the next zab_process on any engine of the same leaf. */
 const char* zab_last_kernel_name(zab_engine* e);
+/* Launch shape of the lane-per-instance kernels as of the most recent zab_process: instances per wavefront and the
+ * number of mem[] words per instance held in LDS for the length of a launch (0: the arena is read in place). */
+int zab_launch_shape(zab_engine* e, int32_t* instances_per_wave, int32_t* lds_mem_words);
 
 #ifdef __cplusplus
 }

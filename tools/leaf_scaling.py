@@ -29,7 +29,8 @@ def main():
             e.process_device(d_in, d_out, a.frames, block=a.block); e.sync()
             e.process_device(d_in, d_out, a.frames, block=a.block); e.sync()
             ms, _ = e.last_timing()
-            print(json.dumps({"leaf": a.leaf, "instances": n, "frames": a.frames, "ipw": a.ipw or "default", "kernel_ms": round(ms, 2),
+            ipw, lds_words = e.launch_shape()
+            print(json.dumps({"leaf": a.leaf, "instances": n, "frames": a.frames, "ipw": ipw, "lds_mem_words": lds_words, "kernel_ms": round(ms, 2),
                               "instance_seconds_per_s": round(n * a.frames / 48000.0 / (ms * 1e-3), 1)}), flush=True)
 
 

@@ -80,6 +80,7 @@ __device__ __forceinline__ void za_state_bind(ZaS& s, const ZabBatch& b, int ins
   s.files = (const ZaFileView*)b.files;
   s.fh = b.fh ? b.fh + (int64_t)inst * b.fh_si : nullptr;
   s.fh_stride = b.fh_se;
+  s.lm_words = s.lm_stride = s.lm_off = 0;
 }
 
 __device__ __forceinline__ void za_state_load(ZaS& s, const ZabBatch& b, int inst) {
@@ -177,6 +178,21 @@ extern "C" __global__ void __launch_bounds__(64) ZA_KERNEL(process)(ZabBatch b, 
   if (active) {
     za_state_load(s, b, inst);
     s.replica = primary ? 0u : 1u;
+#if ZA_USES_LMEM
+    if (b.lmem_words > 0) {         // LDS window over mem[0, lmem_words) (zart.h): load it, eight reads in flight
+      s.lm_stride = (uint32_t)ipw;
+      s.lm_off = (uint32_t)lane;
+      const uint32_t K = (uint32_t)b.lmem_words;      // multiple of 8 (runtime), <= mem_cap
+      for (uint32_t a0 = 0; a0 < K; a0 += 8) {
+        double w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[u] = s.mem[(int64_t)(a0 + u) * s.mem_stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) za_lmem[(a0 + u) * s.lm_stride + s.lm_off] = w[u];
+      }
+      s.lm_words = K;
+    }
+#endif
     if (b.flags[inst] & ZAB_FLAG_SLIDER_DIRTY) {      // processBlock: sliders changed -> jsfx_slider (:3545-3547)
       za_alias_sync(s);
       za_section_slider(s);
@@ -238,6 +254,12 @@ extern "C" __global__ void __launch_bounds__(64) ZA_KERNEL(process)(ZabBatch b, 
 #endif
     if (active) s.pend_change = s.pend_automate = s.pend_automate_end = 0;   // consumeDspSliderChanges (:3745)
   }
+#if ZA_USES_LMEM
+  if (active && s.lm_words) {       // write the stored part of the window back (words at or above mem_high never changed)
+    const int64_t top = s.mem_high < (int64_t)s.lm_words ? s.mem_high : (int64_t)s.lm_words;
+    for (int64_t a = 0; a < top; ++a) s.mem[a * s.mem_stride] = za_lmem[(uint32_t)a * s.lm_stride + s.lm_off];
+  }
+#endif
   if (active && primary) za_state_store(s, b, inst);
 }
 
@@ -301,6 +323,16 @@ static hipError_t za_launch_prepare(const ZabBatch* b, hipStream_t st) {
   return hipGetLastError();
 }
 static hipError_t za_launch_process(const ZabBatch* b, const ZabAudio* a, hipStream_t st) {
-  hipLaunchKernelGGL(ZA_KERNEL(process), dim3((b->n_inst + b->ipw - 1) / b->ipw), dim3(64), 0, st, *b, *a);
+  size_t lds = 0;
+#if ZA_USES_LMEM
+  lds = (size_t)b->lmem_words * (size_t)b->ipw * sizeof(double);
+  static size_t za_lds_allowed = 0;                 // dynamic LDS beyond the default limit has to be asked for once
+  if (lds > za_lds_allowed) {
+    const hipError_t e = hipFuncSetAttribute((const void*)ZA_KERNEL(process), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    za_lds_allowed = lds;
+  }
+#endif
+  hipLaunchKernelGGL(ZA_KERNEL(process), dim3((b->n_inst + b->ipw - 1) / b->ipw), dim3(64), lds, st, *b, *a);
   return hipGetLastError();
 }

@@ -6,7 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define ZAB_MODULE_ABI 11
+#define ZAB_MODULE_ABI 12
 
 enum { ZAB_FLAG_SLIDER_DIRTY = 1u, ZAB_FLAG_PREPARED = 2u };
 
@@ -43,6 +43,8 @@ struct ZabBatch {
   const void* bus;                             // ZaBusView* (device) or null
   int32_t ipw;                                 // instances per wavefront of the lane-per-instance kernels (1..64, power of
                                                // two): instance i runs in lane i % ipw of workgroup i / ipw
+  int32_t lmem_words;                          // process kernel keeps mem[0, lmem_words) of its instances in LDS (0 = off);
+                                               // chosen by the runtime after prepare from the instances' arena footprint
 };
 
 struct ZabAudio {
@@ -80,6 +82,7 @@ struct ZabModule {
   // one raw section (0 init, 1 slider, 2 block, 3 sample) on every instance; null for leaves without sections (Faust)
   hipError_t (*launch_section)(const ZabBatch*, int which, double samplesblock, hipStream_t);
   hipError_t (*launch_msg_flush)(const ZabBatch*, hipStream_t);   // end of a host block: every outbox to the bus ring
+  int32_t lmem_ok;                   // process kernel honours ZabBatch::lmem_words (leaf touches mem[] only through zart.h)
 };
 
 extern "C" const ZabModule* zab_module_get(void);

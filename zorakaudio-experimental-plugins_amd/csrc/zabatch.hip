@@ -104,6 +104,8 @@ struct zab_engine {
   bool prepared = false;
   bool sliders_dirty = false;
   bool timing_valid = false;
+  bool lmem_stale = true;    // LDS window of the generic process kernel to be (re)chosen before the next launch
+  int ipw0 = 64;             // instances per wavefront by policy; the LDS window may thin the waves further
   int launches = 0;
   bool used_fast = false;
   std::vector<void*> owned;
@@ -263,6 +265,7 @@ int zab_create(const char* module, const zab_config* cfg, zab_engine** out) {
     while (ipw < 64 && (int64_t)cfg->n_instances > 2048ll * ipw) ipw <<= 1;
     if (const char* f = getenv("ZAB_IPW")) { const int v = atoi(f); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) ipw = v; }
     b.ipw = ipw;
+    e->ipw0 = ipw;
   }
   if (const char* f = getenv("ZAB_FORCE_LAYOUT")) {     // experiments only: "im" / "il" overrides the module's preference
     if (!strcmp(f, "im")) b.instance_major = 1;
@@ -441,6 +444,37 @@ static int check_device_errors(zab_engine* e, const char* where) {
   return fail(ZAB_E_LOOP_CAP, "%s: %s exceeded the loop safety cap (instance %d)", where, e->mod->name, who);
 }
 
+// LDS window of the lane-per-instance process kernel (zart.h "LDS WINDOW"): when the arena footprint of every instance
+// fits, mem[0, K) lives in LDS for the length of a launch. K * ipw doubles per single-wave workgroup, next to the audio
+// tile; thinner waves (smaller ipw) buy a larger window per instance. Taken only when every wave of the batch is resident
+// at once (256 CUs x what 160 KB of LDS hold) -- a window that serialises the batch into rounds loses what it gains.
+static int choose_lmem(zab_engine* e) {
+  e->lmem_stale = false;
+  e->b.lmem_words = 0;
+  e->b.ipw = e->ipw0;
+  const char* off = getenv("ZAB_LMEM");
+  if (!e->mod->lmem_ok || (off && !strcmp(off, "0")) || e->b.n_inst <= 0) return ZAB_OK;
+  std::vector<int64_t> hi((size_t)e->b.n_inst);
+  HIP_TRY(hipMemcpyAsync(hi.data(), e->b.mem_high, hi.size() * sizeof(int64_t), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  int64_t top = 0;
+  for (int64_t h : hi) top = h > top ? h : top;
+  const int64_t K = (top + 7) & ~(int64_t)7;
+  if (top <= 0 || K > e->b.mem_cap) return ZAB_OK;
+  const int nch = e->mod->nch, tt = nch <= 4 ? 32 : nch <= 8 ? 16 : nch <= 16 ? 8 : nch <= 32 ? 4 : 2;    // ZA_TT
+  const int64_t tile = (int64_t)nch * 64 * (tt + 1) * 4, cu_lds = 160 * 1024, wg_max = 128 * 1024;
+  for (int ipw = e->ipw0; ipw >= 1; ipw >>= 1) {
+    const int64_t lds = K * ipw * 8 + tile;
+    if (lds > wg_max) continue;
+    const int64_t waves = (e->b.n_inst + ipw - 1) / ipw;
+    if (waves > 256 * (cu_lds / lds)) break;             // thinner waves only add more of them
+    e->b.ipw = ipw;
+    e->b.lmem_words = (int32_t)K;
+    break;
+  }
+  return ZAB_OK;
+}
+
 int zab_prepare(zab_engine* e) {
   if (!e) return fail(ZAB_E_ARG, "zab_prepare: null engine");
   HIP_TRY(hipSetDevice(e->cfg.device));
@@ -450,6 +484,7 @@ int zab_prepare(zab_engine* e) {
   HIP_TRY(hipStreamSynchronize(e->stream));
   e->prepared = true;
   e->sliders_dirty = false;
+  e->lmem_stale = true;
   e->b.epoch++;
   return check_device_errors(e, "zab_prepare");
 }
@@ -507,8 +542,16 @@ int zab_process(zab_engine* e, const void* in, void* out, int64_t frames, int64_
       if (he == hipSuccess) he = e->mod->launch_msg_flush(&e->b, e->stream);
       e->launches += 2;
     }
+  } else if (fast) {
+    he = e->mod->launch_fast(&e->b, &a, e->stream);
   } else {
-    he = fast ? e->mod->launch_fast(&e->b, &a, e->stream) : e->mod->launch_process(&e->b, &a, e->stream);
+    if (e->lmem_stale) { const int rc = choose_lmem(e); if (rc) return rc; }
+    he = e->mod->launch_process(&e->b, &a, e->stream);
+    if (he != hipSuccess && e->b.lmem_words) {          // the device refused that much LDS: run from the arena instead
+      (void)hipGetLastError();
+      e->b.lmem_words = 0; e->b.ipw = e->ipw0;
+      he = e->mod->launch_process(&e->b, &a, e->stream);
+    }
   }
   if (he != hipSuccess) return fail(ZAB_E_HIP, "process launch failed: %s", hipGetErrorString(he));
   HIP_TRY(hipEventRecord(e->ev1[slot], e->stream));
@@ -776,6 +819,7 @@ int zab_state_upload(zab_engine* e, int32_t inst, const zab_host_state* h) {
   if (h->slider_visibility_init) HIP_TRY(hipMemcpyAsync(b.vis_init + inst, h->slider_visibility_init, 4, hipMemcpyHostToDevice, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   e->b.epoch++;
+  e->lmem_stale = true;
   e->prepared = true;              // the host's state object is authoritative: it has run (or will run) the sections itself
   return ZAB_OK;
 }
@@ -816,6 +860,12 @@ int zab_run_section(zab_engine* e, int32_t section, int32_t samplesblock) {
 }
 
 int zab_used_fast_path(zab_engine* e) { return e && e->used_fast ? 1 : 0; }
+int zab_launch_shape(zab_engine* e, int32_t* instances_per_wave, int32_t* lds_mem_words) {
+  if (!e) return fail(ZAB_E_ARG, "zab_launch_shape: null engine");
+  if (instances_per_wave) *instances_per_wave = e->b.ipw;
+  if (lds_mem_words) *lds_mem_words = e->b.lmem_words;
+  return ZAB_OK;
+}
 const char* zab_last_kernel_name(zab_engine* e) {
   if (!e) return "";
   const char* n = e->used_fast ? e->mod->fast_kernel_name : e->mod->generic_kernel_name;

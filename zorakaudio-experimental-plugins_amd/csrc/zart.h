@@ -88,6 +88,9 @@ struct ZaState {
   const ZaFileView* files; // file slots of the engine (zart_file.h); null when the leaf has no file builtins
   int64_t* fh;           // this instance's file handle words, word k at fh[k * fh_stride]
   int64_t fh_stride;
+  uint32_t lm_words;     // LDS window over mem[0, lm_words) for the length of a launch (device only; 0 = none)
+  uint32_t lm_stride;    // word a of this lane at za_lmem[a * lm_stride + lm_off]
+  uint32_t lm_off;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -138,8 +141,25 @@ ZA_FN int64_t za_loopcount(double n) { int64_t c = za_f2i64(n); return c < 0 ? 0
 ZA_FN int64_t za_addr1(double x) { int64_t a = za_f2i64(x + 1.0e-5); return a < 0 ? 0 : a; }
 ZA_FN int64_t za_addr(double base, double idx) { return za_addr1(base + idx); }
 
+// LDS WINDOW (device, leaves whose only mem[] users are the functions of this section): a serial script is bound by the
+// latency of its dependent mem[] accesses -- ~1 us each from HBM/L2 against ~0.1 us from LDS. When every instance's
+// arena footprint after @init fits, the process kernel keeps mem[0, lm_words) of its instances in LDS for the whole
+// launch (zab_generic.hip.h loads it on entry and writes the stored part back on exit); addresses above it, and every
+// other kernel, use the arena in HBM. Addresses are >= 0 here (za_addr1 clamps).
+#if defined(__HIPCC__) && defined(ZA_USES_LMEM) && ZA_USES_LMEM
+extern __shared__ double za_lmem[];
+#define ZA_LM_HIT(s, a) ((uint64_t)(a) < (uint64_t)(s).lm_words)
+#define ZA_LM_REF(s, a) za_lmem[(uint32_t)(a) * (s).lm_stride + (s).lm_off]
+#else
+#define ZA_LM_HIT(s, a) false
+#define ZA_LM_REF(s, a) (s).sink
+#endif
+
 template <class S>
-ZA_FN double za_ld(S& s, int64_t a) { return a < s.mem_cap ? s.mem[a * s.mem_stride] : 0.0; }
+ZA_FN double za_ld(S& s, int64_t a) {
+  if (ZA_LM_HIT(s, a)) return ZA_LM_REF(s, a);
+  return a < s.mem_cap ? s.mem[a * s.mem_stride] : 0.0;
+}
 
 template <class S>
 ZA_FN void za_note_store(S& s, int64_t end) {
@@ -149,6 +169,7 @@ ZA_FN void za_note_store(S& s, int64_t end) {
 template <class S>
 ZA_FN double za_st(S& s, int64_t a, double v) {
   za_note_store(s, a + 1);
+  if (ZA_LM_HIT(s, a)) { ZA_LM_REF(s, a) = v; return v; }
   if (a < s.mem_cap && !s.replica) s.mem[a * s.mem_stride] = v;   // (replica lanes would store the same value again)
   return v;
 }
@@ -156,6 +177,7 @@ ZA_FN double za_st(S& s, int64_t a, double v) {
 template <class S>
 ZA_FN double* za_mem_ptr(S& s, int64_t a) {    // lvalue for builtins with output arguments
   za_note_store(s, a + 1);
+  if (ZA_LM_HIT(s, a)) return (double*)&ZA_LM_REF(s, a);
   return a < s.mem_cap ? &s.mem[a * s.mem_stride] : &s.sink;
 }
 
@@ -177,7 +199,9 @@ ZA_FN double za_memset(S& s, double dest, double value, double len) {
   if (n > 0) za_note_store(s, d + n);
   int64_t e = d + n;
   if (e > s.mem_cap) e = s.mem_cap;
-  for (int64_t i = d; i < e; ++i) s.mem[i * s.mem_stride] = value;
+  int64_t i = d;
+  for (; i < e && ZA_LM_HIT(s, i); ++i) ZA_LM_REF(s, i) = value;
+  for (; i < e; ++i) s.mem[i * s.mem_stride] = value;
   return dest;
 }
 
@@ -198,8 +222,11 @@ ZA_FN double za_memcpy(S& s, double destD, double srcD, double lenD) {
   }
   if (d + n > s.mem_high) s.mem_high = d + n;
   const int64_t st = s.mem_stride;
-  if (d <= r) for (int64_t i = 0; i < n; ++i) s.mem[(d + i) * st] = s.mem[(r + i) * st];
-  else for (int64_t i = n - 1; i >= 0; --i) s.mem[(d + i) * st] = s.mem[(r + i) * st];
+#define ZA_CP1(i) do { const double x_ = ZA_LM_HIT(s, r + (i)) ? ZA_LM_REF(s, r + (i)) : s.mem[(r + (i)) * st];                    \
+                       if (ZA_LM_HIT(s, d + (i))) ZA_LM_REF(s, d + (i)) = x_; else s.mem[(d + (i)) * st] = x_; } while (0)
+  if (d <= r) for (int64_t i = 0; i < n; ++i) ZA_CP1(i);
+  else for (int64_t i = n - 1; i >= 0; --i) ZA_CP1(i);
+#undef ZA_CP1
   return 0.0;
 }
 

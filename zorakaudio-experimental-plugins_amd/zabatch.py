@@ -57,7 +57,7 @@ ABI_SYMBOLS = [
     "zab_var_index", "zab_set_sliders", "zab_get_sliders", "zab_prepare", "zab_process", "zab_sync", "zab_read_vars",
     "zab_read_mem", "zab_write_mem", "zab_read_mem_high", "zab_device_alloc", "zab_device_free", "zab_device_upload",
     "zab_device_download", "zab_device_noise", "zab_last_timing", "zab_timing_history", "zab_stream",
-    "zab_used_fast_path", "zab_last_kernel_name", "zab_state_upload", "zab_state_download", "zab_run_section", "zab_gmem_read", "zab_gmem_write", "zab_gmem_seq", "zab_pool_upload", "zab_file_slot_set",
+    "zab_used_fast_path", "zab_last_kernel_name", "zab_launch_shape", "zab_state_upload", "zab_state_download", "zab_run_section", "zab_gmem_read", "zab_gmem_write", "zab_gmem_seq", "zab_pool_upload", "zab_file_slot_set",
 ]
 
 _lib = None
@@ -104,6 +104,7 @@ def load_runtime():
     L.zab_used_fast_path.argtypes = [vp]
     L.zab_last_kernel_name.argtypes = [vp]
     L.zab_last_kernel_name.restype = C.c_char_p
+    L.zab_launch_shape.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.zab_state_upload.argtypes = [vp, i32, C.POINTER(zab_host_state)]
     L.zab_state_download.argtypes = [vp, i32, C.POINTER(zab_host_state)]
     L.zab_run_section.argtypes = [vp, i32, i32]
@@ -266,6 +267,12 @@ class Engine:
 
     def last_kernel_name(self) -> str:
         return self.L.zab_last_kernel_name(self.h).decode()
+
+    def launch_shape(self):
+        """(instances per wavefront, mem[] words per instance held in LDS) of the lane-per-instance kernels."""
+        ipw, k = C.c_int32(0), C.c_int32(0)
+        self._chk(self.L.zab_launch_shape(self.h, C.byref(ipw), C.byref(k)))
+        return ipw.value, k.value
 
     # -- state
     def read_vars(self, first=0, count=None) -> np.ndarray:

@@ -211,6 +211,7 @@ class Emitter:
             self.features.add("gmem")
             return f"za_gmem_load(s, {self.expr(n.index)})"
         pre, (b, i) = self.ordered([n.base, n.index])
+        self.features.add("mem")
         return self.wrap(pre, f"za_ld(s, za_addr({b}, {i}))")
 
     def e_Unary(self, n):
@@ -274,7 +275,9 @@ class Emitter:
             pre, (b, i) = self.ordered([tgt.base, tgt.index])
             addr = f"{pre} int64_t {a} = za_addr({b}, {i});"
             if bop is None:
+                self.features.add("mem")
                 return f"({{ double {r} = {rhs}; {addr} za_st(s, {a}, {r}); }})"
+            self.features.add("mem")
             return f"({{ double {r} = {rhs}; {addr} za_st(s, {a}, {self.binop(bop, f'za_ld(s, {a})', r)}); }})"
         if isinstance(tgt, S.Call) and tgt.fn in ("slider", "spl") and len(tgt.args) == 1:
             arr, off = self._dyn(tgt.fn)
@@ -341,6 +344,7 @@ class Emitter:
         if isinstance(node, S.Index) and not self._is_gmem(node):
             self.features.add("memptr")
             pre, (b, i) = self.ordered([node.base, node.index])
+            self.features.add("mem")
             return self.wrap(pre, f"za_mem_ptr(s, za_addr({b}, {i}))")
         raise EmitError(f"{api} output arguments must be assignable variables or mem[] slots")
 
@@ -468,9 +472,11 @@ class Emitter:
             return f"({{ double i_ = {idx}; za_slider_next_chg(s, i_, {ptr}); }})"
         if fn == "memset":
             self.nargs(n, 3)
+            self.features.add("mem")
             return self.call_rt(n, "za_memset")
         if fn == "memcpy":
             self.nargs(n, 3)
+            self.features.add("mem")
             return self.call_rt(n, "za_memcpy")
         if fn in FFT_CALLS:
             self.nargs(n, 2)
