@@ -196,8 +196,14 @@ def main() -> int:
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": kernel_name, "kernel_ms": k_ms,
-                         "algorithmic_bytes_per_launch": alg, "bytes_per_frame": alg / (n_inst * frames)},
+                         "algorithmic_bytes_per_launch": alg, "bytes_per_frame": alg / (n_inst * frames),
+                         # context: the script's own arithmetic, 14 flop per tap + 80 per frame, all f64,
+                         # against the FP64 vector peak (half the guide's 157.3 TFLOP/s FP32 vector figure)
+                         "fp64_flop_per_frame": 14 * tapN + 80,
+                         "fp64_tflops": (14 * tapN + 80) * n_inst * frames / (k_ms * 1e-3) / 1e12,
+                         "fp64_vector_peak_tflops": 78.6},
         }
+        line["roofline"]["fp64_frac"] = line["roofline"]["fp64_tflops"] / 78.6
         try:    # what a plain device copy reaches on this box (SURVEY §8d asks for it beside the spec peak)
             src = torch.empty(1 << 28, dtype=torch.float32, device="cuda")        # 1 GiB
             dst = torch.empty_like(src)
