@@ -302,10 +302,10 @@ static hipError_t za_launch_section(const ZabBatch* b, int which, double samples
 }
 
 #if ZA_USES_MSG
-// DspJsfxRuntime::endBlock of every instance, in instance order (one thread: the ring order must be deterministic)
-extern "C" __global__ void ZA_KERNEL(msgflush)(ZabBatch b) { za_msg_flush_all((const ZaBusView*)b.bus); }
+// DspJsfxRuntime::endBlock of every instance, in instance order (one wavefront: the ring order must be the serial one)
+extern "C" __global__ void __launch_bounds__(64) ZA_KERNEL(msgflush)(ZabBatch b) { za_msg_flush_all((const ZaBusView*)b.bus); }
 static hipError_t za_launch_msg_flush(const ZabBatch* b, hipStream_t st) {
-  hipLaunchKernelGGL(ZA_KERNEL(msgflush), dim3(1), dim3(1), 0, st, *b);
+  hipLaunchKernelGGL(ZA_KERNEL(msgflush), dim3(1), dim3(64), 0, st, *b);
   return hipGetLastError();
 }
 #endif

@@ -63,8 +63,8 @@ template <class S> ZA_FN int za_msg_slot(S& s, uint64_t chan, bool create) {
   int free_k = -1;
   for (int k = 0; k < ZA_MSG_CHANNELS; ++k) {
     const uint32_t f = B->ch_flags[base + k];
-    if ((f & 4u) && B->ch_hash[base + k] == chan) return k;
-    if (!(f & 4u) && free_k < 0) free_k = k;
+    if (!(f & 4u)) { free_k = k; break; }               // slots are handed out first-free and never released: a prefix
+    if (B->ch_hash[base + k] == chan) return k;
   }
   if (!create || free_k < 0) return -1;
   B->ch_hash[base + free_k] = chan;
@@ -182,7 +182,8 @@ ZA_FN bool za_msg_matches(const ZaBusView* B, uint32_t j, uint64_t chan, int rol
   const int64_t base = (int64_t)j * ZA_MSG_CHANNELS;
   for (int k = 0; k < ZA_MSG_CHANNELS; ++k) {
     const uint32_t f = B->ch_flags[base + k];
-    if ((f & 4u) && B->ch_hash[base + k] == chan) return (wantSub && (f & 1u)) || (wantPub && (f & 2u));
+    if (!(f & 4u)) break;                                // used slots are a prefix (za_msg_slot)
+    if (B->ch_hash[base + k] == chan) return (wantSub && (f & 1u)) || (wantPub && (f & 2u));
   }
   return false;
 }
@@ -252,8 +253,20 @@ template <class S> ZA_NOINLINE void za_msg_begin_block(S& s) {
   B->in_count[me] = n;
 }
 
-// endBlock of every instance, in instance order (one thread): DspJsfxMessageBus::flushOutbox
+// endBlock of every instance, in instance order: DspJsfxMessageBus::flushOutbox. One thread on the CPU; one wavefront on
+// the device, where the lanes share the search for a subscriber (the only part that grows with the instance count) and
+// lane 0 does the bookkeeping, so the ring order stays the serial one.
+#if defined(__HIPCC__)
+#define ZA_MSG_LANE() ((uint32_t)threadIdx.x)
+#define ZA_MSG_LANES 64u
+#define ZA_MSG_ANY(p) (__ballot(p) != 0ull)
+#else
+#define ZA_MSG_LANE() 0u
+#define ZA_MSG_LANES 1u
+#define ZA_MSG_ANY(p) (p)
+#endif
 ZA_FN void za_msg_flush_all(const ZaBusView* B) {
+  const uint32_t lane = ZA_MSG_LANE();
   for (uint32_t i = 0; i < B->n_inst; ++i) {
     const uint32_t cnt = B->out_count[i];
     const uint64_t dom = B->domain[i], me = B->first_id + i;
@@ -264,16 +277,20 @@ ZA_FN void za_msg_flush_all(const ZaBusView* B) {
         const int64_t j = (int64_t)in.target - (int64_t)B->first_id;
         has_target = j >= 0 && j < (int64_t)B->n_inst && B->domain[j] == dom;
       } else {
-        for (uint32_t j = 0; j < B->n_inst && !has_target; ++j)
-          has_target = j != i && B->domain[j] == dom && za_msg_matches(B, j, in.chan, 1);
+        for (uint32_t j0 = 0; j0 < B->n_inst && !has_target; j0 += ZA_MSG_LANES) {
+          const uint32_t j = j0 + lane;
+          const bool mine = j < B->n_inst && j != i && B->domain[j] == dom && za_msg_matches(B, j, in.chan, 1);
+          has_target = ZA_MSG_ANY(mine);
+        }
       }
+      if (lane != 0) continue;
       if (!has_target) {                                 // dropped[channel]++ on the sender
         const int64_t base = (int64_t)i * ZA_MSG_CHANNELS;
         int slot = -1, free_k = -1;
         for (int c = 0; c < ZA_MSG_CHANNELS; ++c) {
           const uint32_t f = B->ch_flags[base + c];
-          if ((f & 4u) && B->ch_hash[base + c] == in.chan) { slot = c; break; }
-          if (!(f & 4u) && free_k < 0) free_k = c;
+          if (!(f & 4u)) { free_k = c; break; }
+          if (B->ch_hash[base + c] == in.chan) { slot = c; break; }
         }
         if (slot < 0 && free_k >= 0) { slot = free_k; B->ch_hash[base + slot] = in.chan; B->ch_flags[base + slot] = 4u; B->ch_caps[base + slot] = 0; B->ch_dropped[base + slot] = 0; }
         if (slot >= 0) B->ch_dropped[base + slot] += 1u;
@@ -285,6 +302,6 @@ ZA_FN void za_msg_flush_all(const ZaBusView* B) {
       if (!in.pad) out.target = 0;
       B->ring[seq % ZA_MSG_RING] = out;
     }
-    B->out_count[i] = 0;
+    if (lane == 0) B->out_count[i] = 0;
   }
 }
