@@ -36,6 +36,9 @@
 #endif
 
 typedef ZaState<ZA_NV> ZaS;
+#if ZA_USES_LMEM
+typedef ZaState<ZA_NV, true> ZaSLm;     // the process kernel's second body: mem[0, lmem_words) in LDS (zart.h)
+#endif
 
 // Phase boundary inside a single-wave workgroup: a wave's LDS accesses execute in order, so only the compiler has to be
 // kept from reordering them; __syncthreads() would also wait for the tile's output stores to reach memory (vmcnt(0)).
@@ -45,7 +48,8 @@ __device__ __forceinline__ void za_wave_sync() { asm volatile("s_waitcnt lgkmcnt
 #define ZA_KERNEL_ENTRY() (void)0      /* leaves with FFT builtins reset their LDS twiddle flag here (zart_fft.h) */
 #endif
 
-__device__ __forceinline__ void za_state_bind(ZaS& s, const ZabBatch& b, int inst) {
+template <class SS>
+__device__ __forceinline__ void za_state_bind(SS& s, const ZabBatch& b, int inst) {
   s.srate = b.srate;
   s.samplesblock = 0.0;
   s.midi_bus = 0.0;
@@ -83,7 +87,8 @@ __device__ __forceinline__ void za_state_bind(ZaS& s, const ZabBatch& b, int ins
   s.lm_words = s.lm_stride = s.lm_off = 0;
 }
 
-__device__ __forceinline__ void za_state_load(ZaS& s, const ZabBatch& b, int inst) {
+template <class SS>
+__device__ __forceinline__ void za_state_load(SS& s, const ZabBatch& b, int inst) {
   za_state_bind(s, b, inst);
 #pragma unroll
   for (int k = 0; k < ZA_NV; ++k) s.v[k] = b.vars[k * b.var_se + inst * b.var_si];
@@ -95,7 +100,8 @@ __device__ __forceinline__ void za_state_load(ZaS& s, const ZabBatch& b, int ins
 #undef ZA_X
 }
 
-__device__ __forceinline__ void za_state_store(const ZaS& s, const ZabBatch& b, int inst) {
+template <class SS>
+__device__ __forceinline__ void za_state_store(const SS& s, const ZabBatch& b, int inst) {
 #pragma unroll
   for (int k = 0; k < ZA_NV; ++k) b.vars[k * b.var_se + inst * b.var_si] = s.v[k];
 #define ZA_X(k) b.sliders[(k) * b.sl_se + inst * b.sl_si] = s.sl[k];
@@ -117,7 +123,8 @@ __device__ __forceinline__ void za_state_store(const ZaS& s, const ZabBatch& b, 
 }
 
 // sliderN:var=... aliases: the host keeps the named var equal to the slider (src/JSFXJuceProcessor.cpp:9349-9353)
-__device__ __forceinline__ void za_alias_sync(ZaS& s) {
+template <class SS>
+__device__ __forceinline__ void za_alias_sync(SS& s) {
 #define ZA_X(sl_idx, var_idx) s.v[var_idx] = s.sl[sl_idx];
   ZA_FOR_ALIAS(ZA_X)
 #undef ZA_X
@@ -152,11 +159,13 @@ extern "C" __global__ void __launch_bounds__(64) ZA_KERNEL(prepare)(ZabBatch b) 
   b.flags[inst] = ZAB_FLAG_PREPARED;
 }
 
-extern "C" __global__ void __launch_bounds__(64) ZA_KERNEL(process)(ZabBatch b, ZabAudio a) {
-  ZA_KERNEL_ENTRY();
 #if ZA_NCH > 0
-  __shared__ float tile[ZA_NCH][64][ZA_TT + 1];
+typedef float ZaTile[64][ZA_TT + 1];
+#else
+typedef float ZaTile;
 #endif
+template <class SS>
+__device__ __forceinline__ void za_process_body(const ZabBatch& b, const ZabAudio& a, ZaTile* tile) {
   const int lane = threadIdx.x;
   const int ipw = b.ipw;
   const int inst0 = blockIdx.x * ipw;
@@ -174,12 +183,12 @@ extern "C" __global__ void __launch_bounds__(64) ZA_KERNEL(process)(ZabBatch b, 
   const int inst = inst0 + lane;
   const bool active = lane < ipw && inst < b.n_inst;
 #endif
-  ZaS s;
+  SS s;
   if (active) {
     za_state_load(s, b, inst);
     s.replica = primary ? 0u : 1u;
 #if ZA_USES_LMEM
-    if (b.lmem_words > 0) {         // LDS window over mem[0, lmem_words) (zart.h): load it, eight reads in flight
+    if (SS::kLm) {                  // LDS window over mem[0, lmem_words) (zart.h): load it, eight reads in flight
       s.lm_stride = (uint32_t)ipw;
       s.lm_off = (uint32_t)lane;
       const uint32_t K = (uint32_t)b.lmem_words;      // multiple of 8 (runtime), <= mem_cap
@@ -255,12 +264,26 @@ extern "C" __global__ void __launch_bounds__(64) ZA_KERNEL(process)(ZabBatch b, 
     if (active) s.pend_change = s.pend_automate = s.pend_automate_end = 0;   // consumeDspSliderChanges (:3745)
   }
 #if ZA_USES_LMEM
-  if (active && s.lm_words) {       // write the stored part of the window back (words at or above mem_high never changed)
+  if (SS::kLm && active) {          // write the stored part of the window back (words at or above mem_high never changed)
     const int64_t top = s.mem_high < (int64_t)s.lm_words ? s.mem_high : (int64_t)s.lm_words;
     for (int64_t a = 0; a < top; ++a) s.mem[a * s.mem_stride] = za_lmem[(uint32_t)a * s.lm_stride + s.lm_off];
   }
 #endif
   if (active && primary) za_state_store(s, b, inst);
+}
+
+extern "C" __global__ void __launch_bounds__(64) ZA_KERNEL(process)(ZabBatch b, ZabAudio a) {
+  ZA_KERNEL_ENTRY();
+#if ZA_NCH > 0
+  __shared__ float tile[ZA_NCH][64][ZA_TT + 1];
+  ZaTile* const tp = tile;
+#else
+  ZaTile* const tp = nullptr;
+#endif
+#if ZA_USES_LMEM
+  if (b.lmem_words > 0) { za_process_body<ZaSLm>(b, a, tp); return; }     // (uniform: a launch runs one body or the other)
+#endif
+  za_process_body<ZaS>(b, a, tp);
 }
 
 // processBlock prologue for the hand-written kernels: instances whose sliders changed run @slider first (:3545-3547).

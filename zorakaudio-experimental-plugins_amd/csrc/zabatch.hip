@@ -272,6 +272,11 @@ int zab_create(const char* module, const zab_config* cfg, zab_engine** out) {
     if (!strcmp(f, "il")) b.instance_major = 0;
   }
   b.mem_cap = cfg->mem_cap > 0 ? cfg->mem_cap : m->default_mem_cap;
+  if (b.mem_cap > 2147483520ll - 1024) {   // device addresses are converted with one 32-bit instruction (zart.h za_addr1)
+    rc = fail(ZAB_E_ARG, "zab_create: mem_cap %lld: at most 2^31 - 1152 doubles per instance", (long long)b.mem_cap);
+    zab_destroy(e);
+    return rc;
+  }
   b.srate = cfg->srate;
   b.first_id = cfg->first_instance_id ? cfg->first_instance_id : 1;
   {

@@ -54,8 +54,9 @@ struct ZaPoolView;   // zart_pool.h
 struct ZaFileView;   // zart_file.h
 struct ZaBusView;    // zart_msg.h
 
-template <int NV>
+template <int NV, bool LM = false>
 struct ZaState {
+  static constexpr bool kLm = LM;   // this instantiation routes mem[0, lm_words) to LDS (device process kernel only)
   double v[NV];
   double sl[64];
   double spl[64];
@@ -108,7 +109,15 @@ ZA_FN int64_t za_f2i64(double x) {
   if (!(x > -9.2233720368547758e18 && x < 9.2233720368547758e18)) return INT64_MIN;
   return (int64_t)x;
 }
-ZA_FN int32_t za_i32(double x) { return (int32_t)(uint32_t)(uint64_t)za_f2i64(x); }
+ZA_FN int32_t za_i32(double x) {
+#if defined(__HIPCC__)
+  // One v_cvt_i32_f64 when the operand fits 32 bits (the usual case for | & ~ << >> %); the wrap-around of wider values
+  // needs the 64-bit conversion, ~9 VALU instructions. The empty asm keeps that a branch: as a select both would always run.
+  if (__builtin_expect(x > -2147483648.0 && x < 2147483647.0, 1)) return (int32_t)x;
+  asm volatile("" ::: "memory");
+#endif
+  return (int32_t)(uint32_t)(uint64_t)za_f2i64(x);
+}
 ZA_FN double za_or(double a, double b) { return (double)(za_i32(a) | za_i32(b)); }
 ZA_FN double za_and(double a, double b) { return (double)(za_i32(a) & za_i32(b)); }
 ZA_FN double za_xor(double a, double b) { return (double)(za_i32(a) ^ za_i32(b)); }
@@ -133,12 +142,27 @@ ZA_FN double za_invsqrt(double a) {
   double y0 = (double)y;
   return y0 * (1.5 - (0.5 * a) * (y0 * y0));
 }
+#if defined(__HIPCC__)
+// Conversions whose result is only meaningful below 2^31 (arena addresses: mem_cap < 2^31 - 1024, zabatch.hip; loop counts:
+// ZA_LOOP_CAP = 2^26): clamp in f64, then ONE 32-bit convert, no branch. NaN and negatives end at -1 -> 0 like the
+// reference's clamp; anything at or above `hi` stays out of range for the caller's own check (arena bound / loop cap).
+ZA_FN int64_t za_f2i_low(double x, double hi) {
+  const int32_t a = (int32_t)fmin(fmax(x, -1.0), hi);
+  return a < 0 ? 0 : a;
+}
+ZA_FN int64_t za_loopcount(double n) { return za_f2i_low(n, 134217728.0); }
+#else
 ZA_FN int64_t za_loopcount(double n) { int64_t c = za_f2i64(n); return c < 0 ? 0 : c; }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // mem[]
 // ---------------------------------------------------------------------------------------------
+#if defined(__HIPCC__)
+ZA_FN int64_t za_addr1(double x) { return za_f2i_low(x + 1.0e-5, 2147483520.0); }
+#else
 ZA_FN int64_t za_addr1(double x) { int64_t a = za_f2i64(x + 1.0e-5); return a < 0 ? 0 : a; }
+#endif
 ZA_FN int64_t za_addr(double base, double idx) { return za_addr1(base + idx); }
 
 // LDS WINDOW (device, leaves whose only mem[] users are the functions of this section): a serial script is bound by the
@@ -148,17 +172,26 @@ ZA_FN int64_t za_addr(double base, double idx) { return za_addr1(base + idx); }
 // other kernel, use the arena in HBM. Addresses are >= 0 here (za_addr1 clamps).
 #if defined(__HIPCC__) && defined(ZA_USES_LMEM) && ZA_USES_LMEM
 extern __shared__ double za_lmem[];
-#define ZA_LM_HIT(s, a) ((uint64_t)(a) < (uint64_t)(s).lm_words)
+#define ZA_LM_HIT(s, a) (S::kLm && (uint64_t)(a) < (uint64_t)(s).lm_words)
 #define ZA_LM_REF(s, a) za_lmem[(uint32_t)(a) * (s).lm_stride + (s).lm_off]
 #else
 #define ZA_LM_HIT(s, a) false
 #define ZA_LM_REF(s, a) (s).sink
 #endif
 
+// The arena load is unconditional (address clamped into the arena, result discarded when out of range): without a
+// branch per access the compiler can issue the loads of neighbouring iterations of a read-only loop together instead of
+// paying one memory latency per iteration.
 template <class S>
 ZA_FN double za_ld(S& s, int64_t a) {
   if (ZA_LM_HIT(s, a)) return ZA_LM_REF(s, a);
+#if defined(ZA_LD_BRANCH)
   return a < s.mem_cap ? s.mem[a * s.mem_stride] : 0.0;
+#else
+  const bool in = a < s.mem_cap;
+  const double v = s.mem[(in ? a : 0) * s.mem_stride];
+  return in ? v : 0.0;
+#endif
 }
 
 template <class S>

@@ -13,6 +13,7 @@ wherever C++ leaves it unspecified:
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Set
 
 from . import syntax as S
@@ -73,8 +74,14 @@ def c_ident(name: str) -> str:
 
 
 class Emitter:
+    UNROLL_MAX_NODES = 120           # loop bodies up to this many AST nodes (callees included) are written out four times
+    UNROLL_MAX_LOOPS = 12            # ... at most this many times per program (everything is inlined: code size)
+
     def __init__(self, prog: Program):
         self.p = prog
+        self.unroll = not os.environ.get("ZA_NO_UNROLL")
+        self.unrolled = 0
+        self._fn_nodes: Dict[str, int] = {}
         self.tmp = 0
         self.strings: List[str] = []
         self.scope: List[Set[str]] = []          # parameter names of the function being emitted
@@ -332,9 +339,33 @@ class Emitter:
 
     def e_Loop(self, n):
         c, l, i = self.t("n"), self.t("l"), self.t("k")
-        return (f"({{ int64_t {c} = za_loopcount({self.expr(n.count)}); double {l} = 0.0; "
-                f"if ({c} > ZA_LOOP_CAP) {{ {c} = ZA_LOOP_CAP; s.err |= ZA_ERR_LOOP_CAP; }} "
-                f"for (int64_t {i} = 0; {i} < {c}; ++{i}) {{ {l} = {self.expr(n.body)}; }} {l}; }})")
+        count = self.expr(n.count)
+        body = self.expr(n.body)
+        head = (f"({{ int64_t {c} = za_loopcount({count}); double {l} = 0.0; "
+                f"if ({c} > ZA_LOOP_CAP) {{ {c} = ZA_LOOP_CAP; s.err |= ZA_ERR_LOOP_CAP; }} ")
+        # Small innermost bodies are written out four times per trip: the trip count differs per lane, so the device
+        # compiler does not unroll these loops itself, and one iteration alone leaves it nothing to overlap the arena
+        # loads of the next iteration with (a serial script pays a full memory latency per iteration otherwise).
+        inner = not any(isinstance(x, (S.Loop, S.While)) for x in _walk(n.body))
+        if (inner and self.unroll and self.unrolled < self.UNROLL_MAX_LOOPS
+                and self._nodes(n.body) <= self.UNROLL_MAX_NODES):
+            self.unrolled += 1
+            one = f"{l} = {body};"
+            return (head + f"int64_t {i} = 0; for (; {i} + 4 <= {c}; {i} += 4) {{ {one} {one} {one} {one} }} "
+                    f"for (; {i} < {c}; ++{i}) {{ {one} }} {l}; }})")
+        return head + f"for (int64_t {i} = 0; {i} < {c}; ++{i}) {{ {l} = {body}; }} {l}; }})"
+
+    def _nodes(self, node, depth=0) -> int:
+        """AST size of an expression with user-function bodies counted at every call site (they are all inlined)."""
+        total = 0
+        for x in _walk(node):
+            total += 1
+            if isinstance(x, S.Call) and x.fn in self.p.fns and depth < 8:
+                if x.fn not in self._fn_nodes:
+                    self._fn_nodes[x.fn] = 0          # (specialisation forbids recursion; belt and braces)
+                    self._fn_nodes[x.fn] = self._nodes(self.p.fns[x.fn].body, depth + 1)
+                total += self._fn_nodes[x.fn]
+        return total
 
     # -- calls ------------------------------------------------------------------------------
     def out_ptr(self, node, api) -> str:
