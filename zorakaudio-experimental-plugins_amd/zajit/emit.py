@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import math
 import os
+import re
 from typing import Dict, List, Optional, Set
 
 from . import syntax as S
@@ -81,6 +82,7 @@ class Emitter:
         self.p = prog
         self.unroll = not os.environ.get("ZA_NO_UNROLL")
         self.unrolled = 0
+        self.cur_sec = "sample"
         self._fn_nodes: Dict[str, int] = {}
         self.tmp = 0
         self.strings: List[str] = []
@@ -347,7 +349,7 @@ class Emitter:
         # compiler does not unroll these loops itself, and one iteration alone leaves it nothing to overlap the arena
         # loads of the next iteration with (a serial script pays a full memory latency per iteration otherwise).
         inner = not any(isinstance(x, (S.Loop, S.While)) for x in _walk(n.body))
-        if (inner and self.unroll and self.unrolled < self.UNROLL_MAX_LOOPS
+        if (inner and self.unroll and self.unrolled < self.UNROLL_MAX_LOOPS and self.cur_sec in ("block", "sample")
                 and self._nodes(n.body) <= self.UNROLL_MAX_NODES):
             self.unrolled += 1
             one = f"{l} = {body};"
@@ -529,12 +531,15 @@ class Emitter:
     # -- top level --------------------------------------------------------------------------
     def function(self, name: str, f) -> str:
         self.scope.append(set(f.params))
+        m = re.match(r"__fn__(init|slider|block|sample)__", name)      # specialised per calling section (program.py)
+        self.cur_sec = m.group(1) if m else "sample"
         body = self.expr(f.body)
         self.scope.pop()
         params = "".join(f", double p_{c_ident(p)}" for p in f.params)
         return f"template <class S> ZA_UFN double fn_{c_ident(name)}(S& s{params}) {{ return {body}; }}"
 
     def section(self, sec: str) -> str:
+        self.cur_sec = sec
         body = " ".join(self.stmt(st) for st in self.p.sections.get(sec, []))
         return f"template <class S> ZA_FN void za_section_{sec}(S& s) {{ {body} }}"
 
