@@ -183,6 +183,12 @@ int zab_used_fast_path(zab_engine* e); /* 1 if the most recent zab_process ran t
 /* Name of the kernel the most recent zab_process launched (as rocprofv3 --kernel-trace lists it; templated kernels by the
  * substring before the template arguments). Valid until the next zab_process on any engine of the same leaf. */
 const char* zab_last_kernel_name(zab_engine* e);
+/* Page-locked host memory for audio buffers handed to zab_process(ZAB_BUF_HOST): with it the copies of the chunked
+ * host-buffer pipeline (copy-in, kernels and copy-out of consecutive time chunks on three HIP streams) are truly
+ * asynchronous. Any host memory works; pageable buffers are staged by the HIP runtime and overlap less.
+ * The reference's host owns its channel buffers (juce::AudioBuffer, src/JSFXJuceProcessor.cpp:3435). */
+int zab_host_alloc(size_t bytes, void** out);
+int zab_host_free(void* p);
 /* Launch shape of the lane-per-instance kernels as of the most recent zab_process: instances per wavefront and the
  * number of mem[] words per instance held in LDS for the length of a launch (0: the arena is read in place). */
 int zab_launch_shape(zab_engine* e, int32_t* instances_per_wave, int32_t* lds_mem_words);

@@ -121,6 +121,12 @@ struct zab_engine {
   float* stage_in = nullptr;
   float* stage_out = nullptr;
   int64_t stage_bytes = 0;
+  // host-buffer pipeline (zab_process, ZAB_BUF_HOST): copy-in / compute / copy-out of consecutive time chunks overlap
+  hipStream_t s_in = nullptr, s_out = nullptr;
+  hipEvent_t in_ready[2] = {}, k_done[2] = {}, out_done[2] = {};
+  float* pipe_in[2] = {};
+  float* pipe_out[2] = {};
+  int64_t pipe_bytes = 0;
 
   template <class T>
   int alloc(T** p, size_t count) {
@@ -332,6 +338,15 @@ int zab_destroy(zab_engine* e) {
   for (void* p : e->owned) hipFree(p);
   if (e->stage_in) hipFree(e->stage_in);
   if (e->stage_out) hipFree(e->stage_out);
+  for (int k = 0; k < 2; ++k) {
+    if (e->pipe_in[k]) hipFree(e->pipe_in[k]);
+    if (e->pipe_out[k]) hipFree(e->pipe_out[k]);
+    if (e->in_ready[k]) hipEventDestroy(e->in_ready[k]);
+    if (e->k_done[k]) hipEventDestroy(e->k_done[k]);
+    if (e->out_done[k]) hipEventDestroy(e->out_done[k]);
+  }
+  if (e->s_in) hipStreamDestroy(e->s_in);
+  if (e->s_out) hipStreamDestroy(e->s_out);
   if (e->state_stage) hipFree(e->state_stage);
   for (int i = 0; i < zab_engine::kTimingSlots; ++i) {
     if (e->ev0[i]) hipEventDestroy(e->ev0[i]);
@@ -494,6 +509,86 @@ int zab_prepare(zab_engine* e) {
   return check_device_errors(e, "zab_prepare");
 }
 
+// One span of frames through the leaf's kernels on the engine's stream: the message leaves host block by host block with a
+// bus flush in between, everything else in one launch (hand-written kernel when it applies).
+static hipError_t launch_span(zab_engine* e, const ZabAudio& a, bool fast) {
+  hipError_t he = hipSuccess;
+  if (e->mod->uses_msg && e->mod->launch_msg_flush) {
+    // block k's messages are block k + 1's inbox (csrc/zart_msg.h)
+    for (int64_t pos = 0; pos < a.frames && he == hipSuccess; pos += a.block) {
+      ZabAudio ab = a;
+      ab.in = a.in ? a.in + pos : nullptr;
+      ab.out = a.out ? a.out + pos : nullptr;
+      ab.frames = (a.frames - pos < a.block) ? (a.frames - pos) : a.block;
+      he = e->mod->launch_process(&e->b, &ab, e->stream);
+      if (he == hipSuccess) he = e->mod->launch_msg_flush(&e->b, e->stream);
+      e->launches += 2;
+    }
+    return he;
+  }
+  e->launches += 1;
+  if (fast) return e->mod->launch_fast(&e->b, &a, e->stream);
+  he = e->mod->launch_process(&e->b, &a, e->stream);
+  if (he != hipSuccess && e->b.lmem_words) {          // the device refused that much LDS: run from the arena instead
+    (void)hipGetLastError();
+    e->b.lmem_words = 0; e->b.ipw = e->ipw0;
+    he = e->mod->launch_process(&e->b, &a, e->stream);
+  }
+  return he;
+}
+
+// Host buffers, chunked along time: H2D of chunk k + 1 (stream s_in), kernels of chunk k (engine stream) and D2H of chunk
+// k - 1 (stream s_out) run together; two device buffers per direction. Instance state simply carries over from launch to
+// launch, as between any two zab_process calls. Pinned host memory (zab_host_alloc) makes the copies truly asynchronous.
+static int process_host_pipelined(zab_engine* e, const float* in, float* out, const ZabAudio& a, bool fast, int64_t chunk) {
+  const int64_t rows = (int64_t)e->b.n_inst * e->mod->nch;
+  const int64_t need = rows * chunk * (int64_t)sizeof(float);
+  if (!e->s_in) {
+    HIP_TRY(hipStreamCreateWithFlags(&e->s_in, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&e->s_out, hipStreamNonBlocking));
+    for (int k = 0; k < 2; ++k) {
+      HIP_TRY(hipEventCreateWithFlags(&e->in_ready[k], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&e->k_done[k], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&e->out_done[k], hipEventDisableTiming));
+    }
+  }
+  if (need > e->pipe_bytes) {
+    for (int k = 0; k < 2; ++k) {
+      if (e->pipe_in[k]) hipFree(e->pipe_in[k]);
+      if (e->pipe_out[k]) hipFree(e->pipe_out[k]);
+      e->pipe_in[k] = e->pipe_out[k] = nullptr;
+    }
+    e->pipe_bytes = 0;
+    for (int k = 0; k < 2; ++k) {
+      HIP_TRY(hipMalloc((void**)&e->pipe_in[k], need));
+      HIP_TRY(hipMalloc((void**)&e->pipe_out[k], need));
+    }
+    e->pipe_bytes = need;
+  }
+  // whatever the engine stream has queued so far (slider prologue, earlier calls) precedes the first chunk
+  int64_t k = 0;
+  for (int64_t pos = 0; pos < a.frames; pos += chunk, ++k) {
+    const int buf = (int)(k & 1);
+    const int64_t n = a.frames - pos < chunk ? a.frames - pos : chunk;
+    if (k >= 2) HIP_TRY(hipStreamWaitEvent(e->s_in, e->k_done[buf], 0));            // kernels of chunk k - 2 have read this buffer
+    HIP_TRY(hipMemcpy2DAsync(e->pipe_in[buf], (size_t)chunk * 4, in + pos, (size_t)a.frame_stride * 4, (size_t)n * 4, (size_t)rows,
+                             hipMemcpyHostToDevice, e->s_in));
+    HIP_TRY(hipEventRecord(e->in_ready[buf], e->s_in));
+    HIP_TRY(hipStreamWaitEvent(e->stream, e->in_ready[buf], 0));
+    if (k >= 2) HIP_TRY(hipStreamWaitEvent(e->stream, e->out_done[buf], 0));        // chunk k - 2's output has left this buffer
+    ZabAudio ac = a;
+    ac.in = e->pipe_in[buf]; ac.out = e->pipe_out[buf]; ac.frames = n; ac.frame_stride = chunk;
+    const hipError_t he = launch_span(e, ac, fast);
+    if (he != hipSuccess) return fail(ZAB_E_HIP, "process launch failed: %s", hipGetErrorString(he));
+    HIP_TRY(hipEventRecord(e->k_done[buf], e->stream));
+    HIP_TRY(hipStreamWaitEvent(e->s_out, e->k_done[buf], 0));
+    HIP_TRY(hipMemcpy2DAsync(out + pos, (size_t)a.frame_stride * 4, e->pipe_out[buf], (size_t)chunk * 4, (size_t)n * 4, (size_t)rows,
+                             hipMemcpyDeviceToHost, e->s_out));
+    HIP_TRY(hipEventRecord(e->out_done[buf], e->s_out));
+  }
+  return ZAB_OK;
+}
+
 int zab_process(zab_engine* e, const void* in, void* out, int64_t frames, int64_t frame_stride, int32_t block, int32_t placement) {
   if (!e) return fail(ZAB_E_ARG, "zab_process: null engine");
   if (!e->prepared) return fail(ZAB_E_STATE, "zab_process before zab_prepare");
@@ -505,7 +600,21 @@ int zab_process(zab_engine* e, const void* in, void* out, int64_t frames, int64_
   ZabAudio a{};
   a.frames = frames; a.frame_stride = frame_stride; a.block = block;
   const int64_t bytes = (int64_t)e->b.n_inst * nch * frame_stride * (int64_t)sizeof(float);
-  if (placement == ZAB_BUF_HOST) {
+  // Host buffers longer than two chunks go through the three-stream pipeline (chunks are whole host blocks, so the
+  // script sees the same block sequence); short ones are staged whole.
+  const int64_t rows = (int64_t)e->b.n_inst * nch;
+  int64_t chunk = 0;
+  bool pipelined = false;
+  if (placement == ZAB_BUF_HOST && rows > 0 && e->mod->has_sample) {
+    const char* env = getenv("ZAB_PIPE_CHUNK_KB");                             // 0 disables the pipeline
+    const int64_t target = (env ? atoll(env) : 32768) << 10;                   // bytes per chunk and direction
+    chunk = target > 0 ? (target / (rows * 4) / block) * block : 0;
+    if (chunk < block) chunk = block;
+    pipelined = target > 0 && frames >= 3 * chunk;
+  }
+  if (placement == ZAB_BUF_HOST && pipelined) {
+    a.in = nullptr; a.out = nullptr;          // per chunk, see process_host_pipelined
+  } else if (placement == ZAB_BUF_HOST) {
     if (bytes > e->stage_bytes) {
       if (e->stage_in) hipFree(e->stage_in);
       if (e->stage_out) hipFree(e->stage_out);
@@ -531,39 +640,28 @@ int zab_process(zab_engine* e, const void* in, void* out, int64_t frames, int64_
   if (e->cfg.path != ZAB_PATH_GENERIC && e->mod->launch_fast && e->mod->fast_applies) fast = e->mod->fast_applies(&e->b, &a) != 0;
   if (e->cfg.path == ZAB_PATH_FAST && !fast)
     return fail(ZAB_E_ARG, "ZAB_PATH_FAST requested but %s's hand-written kernel does not apply to this configuration", e->mod->name);
+  if (!fast && e->lmem_stale) { const int rc = choose_lmem(e); if (rc) return rc; }
   const int slot = (int)(e->n_process % zab_engine::kTimingSlots);
   HIP_TRY(hipEventRecord(e->ev0[slot], e->stream));
+  e->launches = 0;
   hipError_t he = hipSuccess;
-  if (e->mod->uses_msg && e->mod->launch_msg_flush) {
-    // message leaves: one launch per host block, every outbox flushed to the bus in between (block k's messages are
-    // block k + 1's inbox; csrc/zart_msg.h)
-    e->launches = 0;
-    for (int64_t pos = 0; pos < frames && he == hipSuccess; pos += block) {
-      ZabAudio ab = a;
-      ab.in = a.in ? a.in + pos : nullptr;
-      ab.out = a.out ? a.out + pos : nullptr;
-      ab.frames = (frames - pos < block) ? (frames - pos) : block;
-      he = e->mod->launch_process(&e->b, &ab, e->stream);
-      if (he == hipSuccess) he = e->mod->launch_msg_flush(&e->b, e->stream);
-      e->launches += 2;
-    }
-  } else if (fast) {
-    he = e->mod->launch_fast(&e->b, &a, e->stream);
+  if (pipelined) {
+    const int rc = process_host_pipelined(e, (const float*)in, (float*)out, a, fast, chunk);
+    if (rc) return rc;
   } else {
-    if (e->lmem_stale) { const int rc = choose_lmem(e); if (rc) return rc; }
-    he = e->mod->launch_process(&e->b, &a, e->stream);
-    if (he != hipSuccess && e->b.lmem_words) {          // the device refused that much LDS: run from the arena instead
-      (void)hipGetLastError();
-      e->b.lmem_words = 0; e->b.ipw = e->ipw0;
-      he = e->mod->launch_process(&e->b, &a, e->stream);
-    }
+    he = launch_span(e, a, fast);
   }
   if (he != hipSuccess) return fail(ZAB_E_HIP, "process launch failed: %s", hipGetErrorString(he));
   HIP_TRY(hipEventRecord(e->ev1[slot], e->stream));
   e->n_process++;
-  e->timing_valid = true; if (!(e->mod->uses_msg && e->mod->launch_msg_flush)) e->launches = 1; e->used_fast = fast;
+  e->timing_valid = true; e->used_fast = fast;
   if (placement == ZAB_BUF_HOST) {
-    if (bytes) HIP_TRY(hipMemcpyAsync(out, e->stage_out, bytes, hipMemcpyDeviceToHost, e->stream));
+    if (pipelined) {
+      HIP_TRY(hipStreamSynchronize(e->s_out));
+      HIP_TRY(hipStreamSynchronize(e->s_in));
+    } else if (bytes) {
+      HIP_TRY(hipMemcpyAsync(out, e->stage_out, bytes, hipMemcpyDeviceToHost, e->stream));
+    }
     return zab_sync(e);
   }
   return ZAB_OK;
@@ -864,6 +962,16 @@ int zab_run_section(zab_engine* e, int32_t section, int32_t samplesblock) {
   return check_device_errors(e, "zab_run_section");
 }
 
+int zab_host_alloc(size_t bytes, void** out) {
+  if (!out) return fail(ZAB_E_ARG, "zab_host_alloc: null out");
+  *out = nullptr;
+  HIP_TRY(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+  return ZAB_OK;
+}
+int zab_host_free(void* p) {
+  if (p) HIP_TRY(hipHostFree(p));
+  return ZAB_OK;
+}
 int zab_used_fast_path(zab_engine* e) { return e && e->used_fast ? 1 : 0; }
 int zab_launch_shape(zab_engine* e, int32_t* instances_per_wave, int32_t* lds_mem_words) {
   if (!e) return fail(ZAB_E_ARG, "zab_launch_shape: null engine");

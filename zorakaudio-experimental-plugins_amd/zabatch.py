@@ -57,7 +57,7 @@ ABI_SYMBOLS = [
     "zab_var_index", "zab_set_sliders", "zab_get_sliders", "zab_prepare", "zab_process", "zab_sync", "zab_read_vars",
     "zab_read_mem", "zab_write_mem", "zab_read_mem_high", "zab_device_alloc", "zab_device_free", "zab_device_upload",
     "zab_device_download", "zab_device_noise", "zab_last_timing", "zab_timing_history", "zab_stream",
-    "zab_used_fast_path", "zab_last_kernel_name", "zab_launch_shape", "zab_state_upload", "zab_state_download", "zab_run_section", "zab_gmem_read", "zab_gmem_write", "zab_gmem_seq", "zab_pool_upload", "zab_file_slot_set",
+    "zab_used_fast_path", "zab_last_kernel_name", "zab_launch_shape", "zab_host_alloc", "zab_host_free", "zab_state_upload", "zab_state_download", "zab_run_section", "zab_gmem_read", "zab_gmem_write", "zab_gmem_seq", "zab_pool_upload", "zab_file_slot_set",
 ]
 
 _lib = None
@@ -105,6 +105,8 @@ def load_runtime():
     L.zab_last_kernel_name.argtypes = [vp]
     L.zab_last_kernel_name.restype = C.c_char_p
     L.zab_launch_shape.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.zab_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+    L.zab_host_free.argtypes = [vp]
     L.zab_state_upload.argtypes = [vp, i32, C.POINTER(zab_host_state)]
     L.zab_state_download.argtypes = [vp, i32, C.POINTER(zab_host_state)]
     L.zab_run_section.argtypes = [vp, i32, i32]
@@ -115,6 +117,32 @@ def load_runtime():
     L.zab_file_slot_set.argtypes = [vp, i32, i32, C.c_double, C.POINTER(C.c_double), i64]
     _lib = L
     return L
+
+
+class PinnedArray:
+    """float32 numpy array over page-locked host memory (zab_host_alloc); .array is valid until close()."""
+
+    def __init__(self, shape):
+        self.L = load_runtime()
+        n = int(np.prod(shape)) * 4
+        p = C.c_void_p()
+        rc = self.L.zab_host_alloc(n, C.byref(p))
+        if rc:
+            raise ZabError(rc, self.L.zab_last_error().decode(errors="replace"))
+        self.ptr = p
+        self.array = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(int(np.prod(shape)),)).reshape(shape)
+
+    def close(self):
+        if self.ptr:
+            self.array = None
+            self.L.zab_host_free(self.ptr)
+            self.ptr = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
 
 def module_path(leaf: str) -> Path:
@@ -212,12 +240,14 @@ class Engine:
         self._chk(self.L.zab_prepare(self.h))
 
     # -- audio
-    def process_host(self, x: np.ndarray, block: int = 512) -> np.ndarray:
-        """x: float32 [N, nch, frames] in host memory; staged over PCIe; returns the output array."""
+    def process_host(self, x: np.ndarray, block: int = 512, out: np.ndarray = None) -> np.ndarray:
+        """x: float32 [N, nch, frames] in host memory; staged over PCIe (long buffers: chunked three-stream pipeline);
+        returns the output array (`out` if given, e.g. a PinnedArray's .array)."""
         x = np.ascontiguousarray(x, dtype=np.float32)
         assert x.shape[0] == self.n and x.shape[1] == self.nch, (x.shape, self.n, self.nch)
         frames = x.shape[2]
-        y = np.empty_like(x)
+        y = np.empty_like(x) if out is None else out
+        assert y.shape == x.shape and y.dtype == np.float32 and y.flags.c_contiguous
         self._chk(self.L.zab_process(self.h, x.ctypes.data, y.ctypes.data, frames, frames, int(block), ZAB_BUF_HOST))
         return y
 
