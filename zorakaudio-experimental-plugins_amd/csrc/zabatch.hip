@@ -335,6 +335,8 @@ int zab_create(const char* module, const zab_config* cfg, zab_engine** out) {
 int zab_destroy(zab_engine* e) {
   if (!e) return ZAB_OK;
   if (e->stream) hipStreamSynchronize(e->stream);
+  if (e->s_in) hipStreamSynchronize(e->s_in);          // (a failed pipelined call may have left copies in flight)
+  if (e->s_out) hipStreamSynchronize(e->s_out);
   for (void* p : e->owned) hipFree(p);
   if (e->stage_in) hipFree(e->stage_in);
   if (e->stage_out) hipFree(e->stage_out);
@@ -647,7 +649,12 @@ int zab_process(zab_engine* e, const void* in, void* out, int64_t frames, int64_
   hipError_t he = hipSuccess;
   if (pipelined) {
     const int rc = process_host_pipelined(e, (const float*)in, (float*)out, a, fast, chunk);
-    if (rc) return rc;
+    if (rc) {                                            // drain what was queued: the caller owns the host buffers again
+      if (e->s_in) hipStreamSynchronize(e->s_in);
+      hipStreamSynchronize(e->stream);
+      if (e->s_out) hipStreamSynchronize(e->s_out);
+      return rc;
+    }
   } else {
     he = launch_span(e, a, fast);
   }
