@@ -268,6 +268,10 @@ int zab_create(const char* module, const zab_config* cfg, zab_engine** out) {
     // 11.4 / 2.9 / 1.45 / 1.45 / 1.46 ms, STFT fixture 443 / 276 / 248 / 232 / 780 ms, DOT 642 / 600 / 593 / 593 / 2200 ms --
     // below ~4 the serial parts pay for 64x the memory instructions chip-wide.
     int ipw = m->prefer_instance_major == 2 ? 8 : (m->nch >= 6 ? 16 : 64);
+    // FFT-hot leaves hold a 64 KB LDS transform buffer per wavefront (two wavefronts per CU): small batches get thinner
+    // waves so that ~256 of them exist (2048 x 4096-pt round trips: 1.44 ms at any ipw; 256 buffers: 5.6 / 2.8 / 1.4 ms at
+    // ipw 8 / 4 / 2; the STFT fixture at 1024 instances 395 / 365 / 668 ms)
+    if (m->prefer_instance_major == 2 && cfg->n_instances <= 1024) ipw = cfg->n_instances <= 512 ? 2 : 4;
     while (ipw < 64 && (int64_t)cfg->n_instances > 2048ll * ipw) ipw <<= 1;
     if (const char* f = getenv("ZAB_IPW")) { const int v = atoi(f); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) ipw = v; }
     b.ipw = ipw;
