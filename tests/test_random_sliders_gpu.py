@@ -1,6 +1,8 @@
 """Every JSFX leaf at RANDOM slider settings, device vs CPU port: the VM fixtures pin the default settings; this walks other
 branches of the scripts (mode switches, bypasses, extreme times and gains). Slider rows are drawn inside each slider's declared
 range and snapped to its step like a host parameter would be (src/JSFXJuceProcessor.cpp:5556-5596), one row per instance."""
+import os
+
 import numpy as np
 import pytest
 
@@ -38,7 +40,7 @@ def test_random_slider_rows_device_vs_port(leaf):
     meta = zabatch.leaf_meta(leaf)
     nch, n, frames, block = int(meta["nch"]), 6, 3072, 512
     cap = CAPS.get(leaf, 1 << 16)
-    rows = _rows(meta, n, seed=sum(map(ord, leaf)))
+    rows = _rows(meta, n, seed=sum(map(ord, leaf)) + 1000 * int(os.environ.get("ZA_RAND_SEED", "0")))     # (other draws: ZA_RAND_SEED=k)
     x = np.zeros((n, nch, frames), np.float32)
     x[:, :2] = noise.white_noise(range(n), frames)[:, :min(2, nch)]
     with zabatch.Engine(leaf, n, mem_cap=cap, max_block=block) as e:
