@@ -85,6 +85,7 @@ __device__ __forceinline__ void za_state_bind(SS& s, const ZabBatch& b, int inst
   s.fh = b.fh ? b.fh + (int64_t)inst * b.fh_si : nullptr;
   s.fh_stride = b.fh_se;
   s.lm_words = s.lm_stride = s.lm_off = 0;
+  s.rep_i = 0; s.rep_n = 1; s.rep_stride = 64;
 }
 
 template <class SS>
@@ -169,7 +170,8 @@ __device__ __forceinline__ void za_process_body(const ZabBatch& b, const ZabAudi
   const int lane = threadIdx.x;
   const int ipw = b.ipw;
   const int inst0 = blockIdx.x * ipw;
-#if ZA_USES_FFT && !ZA_USES_GMEM
+#if (ZA_USES_FFT || ZA_USES_COOP) && !ZA_USES_GMEM
+#define ZA_REPLICAS 1
   // REPLICA LANES: a thin wavefront (ipw < 64) runs every instance on 64 / ipw lanes at once -- identical state, identical
   // control flow, identical (hence harmless) stores. Nothing is gained for the serial code, but every lane now reaches the
   // FFT builtins, whose wave-cooperative form (zart_fft.h) spreads ONE instance's transform over all of them.
@@ -187,10 +189,13 @@ __device__ __forceinline__ void za_process_body(const ZabBatch& b, const ZabAudi
   if (active) {
     za_state_load(s, b, inst);
     s.replica = primary ? 0u : 1u;
+#ifdef ZA_REPLICAS
+    s.rep_i = (uint32_t)(lane / ipw); s.rep_n = (uint32_t)(64 / ipw); s.rep_stride = (uint32_t)ipw;    // (accumulation loops, zart.h)
+#endif
 #if ZA_USES_LMEM
     if (SS::kLm) {                  // LDS window over mem[0, lmem_words) (zart.h): load it, eight reads in flight
       s.lm_stride = (uint32_t)ipw;
-      s.lm_off = (uint32_t)lane;
+      s.lm_off = (uint32_t)row;         // (replica lanes share their instance's words)
       const uint32_t K = (uint32_t)b.lmem_words;      // multiple of 8 (runtime), <= mem_cap
       for (uint32_t a0 = 0; a0 < K; a0 += 8) {
         double w[8];
@@ -264,7 +269,7 @@ __device__ __forceinline__ void za_process_body(const ZabBatch& b, const ZabAudi
     if (active) s.pend_change = s.pend_automate = s.pend_automate_end = 0;   // consumeDspSliderChanges (:3745)
   }
 #if ZA_USES_LMEM
-  if (SS::kLm && active) {          // write the stored part of the window back (words at or above mem_high never changed)
+  if (SS::kLm && active && primary) {   // write the stored part of the window back (words at or above mem_high never changed)
     const int64_t top = s.mem_high < (int64_t)s.lm_words ? s.mem_high : (int64_t)s.lm_words;
     for (int64_t a = 0; a < top; ++a) s.mem[a * s.mem_stride] = za_lmem[(uint32_t)a * s.lm_stride + s.lm_off];
   }

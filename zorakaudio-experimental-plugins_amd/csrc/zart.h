@@ -89,6 +89,7 @@ struct ZaState {
   const ZaFileView* files; // file slots of the engine (zart_file.h); null when the leaf has no file builtins
   int64_t* fh;           // this instance's file handle words, word k at fh[k * fh_stride]
   int64_t fh_stride;
+  uint32_t rep_i, rep_n, rep_stride;   // replica lanes of this instance (zab_generic.hip.h): my index, how many, lane stride
   uint32_t lm_words;     // LDS window over mem[0, lm_words) for the length of a launch (device only; 0 = none)
   uint32_t lm_stride;    // word a of this lane at za_lmem[a * lm_stride + lm_off]
   uint32_t lm_off;
@@ -153,6 +154,23 @@ ZA_FN int64_t za_f2i_low(double x, double hi) {
 ZA_FN int64_t za_loopcount(double n) { return za_f2i_low(n, 134217728.0); }
 #else
 ZA_FN int64_t za_loopcount(double n) { int64_t c = za_f2i64(n); return c < 0 ? 0 : c; }
+#endif
+
+// ---------------------------------------------------------------------------------------------
+// accumulation loops shared by the replica lanes of an instance (zajit/emit.py e_Loop)
+// ---------------------------------------------------------------------------------------------
+ZA_FN bool za_coop_int(double x) { return x == floor(x) && fabs(x) < 1.0e15; }   // counters stay exact under i0 + k * step
+#if defined(__HIPCC__)
+#define ZA_COOP_ON(s) ((s).rep_n > 1u)
+template <class S>
+ZA_FN double za_coop_sum(S& s, double x) {          // every replica lane ends with the same bits (fp addition commutes)
+  for (uint32_t off = s.rep_stride; off < 64u; off <<= 1) x += __shfl_xor(x, (int)off, 64);
+  return x;
+}
+#else
+#define ZA_COOP_ON(s) false
+template <class S>
+ZA_FN double za_coop_sum(S& s, double x) { (void)s; return x; }
 #endif
 
 // ---------------------------------------------------------------------------------------------

@@ -78,6 +78,7 @@ def make_unit(prog: Program) -> Unit:
         "ZA_USES_FILE": "1" if "file" in em.features else "0",
         "ZA_USES_MSG": "1" if "msg" in em.features else "0",
         "ZA_USES_FFT": "1" if "fft" in em.features else "0",
+        "ZA_USES_COOP": "1" if "coop" in em.features else "0",      # has accumulation loops shared by replica lanes (emit.py)
         # leaves whose mem[] is touched only by zart.h's load/store/memset/memcpy can keep its low part in LDS (zart.h)
         "ZA_USES_LMEM": "1" if "mem" in em.features and not em.features & {"fft", "gmem", "pool", "file", "msg"} else "0",
         # very large scripts (Sample: 754 specialised functions, 1 MB of expressions) cannot be flattened into one kernel body

@@ -83,6 +83,8 @@ class Emitter:
         self.unroll = not os.environ.get("ZA_NO_UNROLL")
         self.unrolled = 0
         self.cur_sec = "sample"
+        self.redirect: Dict[str, str] = {}
+        self.coop = not os.environ.get("ZA_NO_COOP")
         self._fn_nodes: Dict[str, int] = {}
         self.tmp = 0
         self.strings: List[str] = []
@@ -156,6 +158,8 @@ class Emitter:
     def var_ref(self, name: str) -> str:
         if self._is_param(name):
             return "p_" + c_ident(name)
+        if name in self.redirect:              # accumulator of a loop shared by replica lanes (e_Loop): its partial sum
+            return self.redirect[name]
         k = is_spl_name(name)
         if k is not None:
             if not 0 <= k < 64:
@@ -339,23 +343,155 @@ class Emitter:
     def e_While(self, n):
         return "({ " + self.stmt(n) + " 0.0; })"
 
+    # -- loops shared by replica lanes -------------------------------------------------------
+    _COOP_PURE = set(PURE_MATH1) | set(PURE_MATH2) | {"abs", "min", "max", "sqr", "sign", "invsqrt", "__memtop"}
+
+    def _coop_plan(self, loop):
+        """Is `loop` a read-only accumulation loop whose trips only depend on each other through `acc += expr` sums and
+        `i += <integer literal>` counters? Returns (accumulators, {induction: step}) or None. Every other variable written in a
+        trip (the callees' local()s included) must be assigned before it is read in that trip, unconditionally; no arena / gmem
+        / spl / slider stores, no nested loops, only pure builtins."""
+        items = loop.body.items if isinstance(loop.body, S.Seq) else [loop.body]
+        acc, ind, written, bad = {}, {}, [], []
+        seen_write = set()
+
+        def fail(why):
+            bad.append(why)
+
+        def walk(node, params, cond, top):
+            if bad:
+                return
+            if isinstance(node, (S.Num, S.Str)):
+                return
+            if isinstance(node, S.Var):
+                nm = node.name
+                if nm in params or nm.startswith("$"):
+                    return
+                reads.append(nm)
+                if nm in temps_pending:
+                    pass
+                return
+            if isinstance(node, S.Index):
+                if self._is_gmem(node):
+                    return fail("gmem")
+                walk(node.base, params, cond, False); walk(node.index, params, cond, False)
+                return
+            if isinstance(node, (S.Loop, S.While, S.If, S.FuncDef)):
+                return fail("control flow")
+            if isinstance(node, S.Cond):
+                walk(node.cond, params, cond, False)
+                walk(node.then, params, True, False)
+                if node.els is not None:
+                    walk(node.els, params, True, False)
+                return
+            if isinstance(node, S.Binary):
+                walk(node.l, params, cond, False)
+                walk(node.r, params, cond or node.op in ("&&", "||"), False)
+                return
+            if isinstance(node, S.Unary):
+                return walk(node.a, params, cond, False)
+            if isinstance(node, S.Seq):
+                for it in node.items:
+                    walk(it, params, cond, False)
+                return
+            if isinstance(node, S.Call):
+                for a in node.args:
+                    walk(a, params, cond, False)
+                if node.fn in self.p.fns:
+                    f = self.p.fns[node.fn]
+                    if len(stack) > 6 or node.fn in stack:
+                        return fail("call depth")
+                    stack.append(node.fn)
+                    walk(f.body, set(f.params), cond, False)
+                    stack.pop()
+                    return
+                if node.fn not in self._COOP_PURE:
+                    return fail("builtin " + node.fn)
+                return
+            if isinstance(node, S.Assign):
+                tgt = node.target
+                if not isinstance(tgt, S.Var) or tgt.name in params or is_spl_name(tgt.name) is not None \
+                        or is_slider_name(tgt.name) is not None or tgt.name not in self.p.vars:
+                    return fail("store")
+                nm = tgt.name
+                if node.op in ("+=", "-=") and top and not cond:
+                    if isinstance(node.value, S.Num) and float(node.value.value) == int(node.value.value) and nm not in acc:
+                        if nm in ind or nm in seen_write:
+                            return fail("induction written twice")
+                        ind[nm] = (1.0 if node.op == "+=" else -1.0) * float(node.value.value)
+                        seen_write.add(nm)
+                        events.append(("ind", nm, len(reads)))
+                        return
+                    if nm not in ind and nm not in temps:
+                        mark = len(reads)
+                        walk(node.value, params, cond, False)
+                        acc.setdefault(nm, []).append((mark, len(reads)))
+                        seen_write.add(nm)
+                        return
+                    return fail("mixed update of " + nm)
+                if node.op != "=" or cond:
+                    return fail("conditional or compound write of " + nm)
+                if nm in acc or nm in ind:
+                    return fail("mixed update of " + nm)
+                walk(node.value, params, cond, False)
+                temps.setdefault(nm, len(reads))          # reads before this index saw the previous trip's value
+                seen_write.add(nm)
+                return
+            return fail("node " + type(node).__name__)
+
+        reads, events, temps, temps_pending, stack = [], [], {}, set(), []
+        for it in items:
+            walk(it, set(self.scope[-1]) if self.scope else set(), False, True)
+        if bad or not acc:
+            return None
+        for nm, first_def in temps.items():                # def before use inside a trip
+            if nm in reads[:first_def]:
+                return None
+        for nm in acc:                                       # accumulators are only ever accumulated
+            if nm in reads or nm in temps or nm in ind:
+                return None
+        return sorted(acc), ind
+
     def e_Loop(self, n):
         c, l, i = self.t("n"), self.t("l"), self.t("k")
         count = self.expr(n.count)
-        body = self.expr(n.body)
         head = (f"({{ int64_t {c} = za_loopcount({count}); double {l} = 0.0; "
                 f"if ({c} > ZA_LOOP_CAP) {{ {c} = ZA_LOOP_CAP; s.err |= ZA_ERR_LOOP_CAP; }} ")
-        # Small innermost bodies are written out four times per trip: the trip count differs per lane, so the device
-        # compiler does not unroll these loops itself, and one iteration alone leaves it nothing to overlap the arena
-        # loads of the next iteration with (a serial script pays a full memory latency per iteration otherwise).
         inner = not any(isinstance(x, (S.Loop, S.While)) for x in _walk(n.body))
-        if (inner and self.unroll and self.unrolled < self.UNROLL_MAX_LOOPS and self.cur_sec in ("block", "sample")
+        hot = self.cur_sec in ("block", "sample")
+        coop = ""
+        if inner and hot and self.coop and not self.redirect and self._nodes(n.body) <= 400:
+            plan = self._coop_plan(n)
+            if plan:
+                accs, ind = plan
+                self.features.add("coop")
+                part = {a: self.t("p") for a in accs}
+                start = {v: self.t("i") for v in ind}
+                self.redirect = dict(part)
+                body_r = self.expr(n.body)
+                self.redirect = {}
+                k = self.t("k")
+                seti = lambda kk: " ".join(f"{self.var_ref(v)} = {start[v]} + (double)({kk}) * {c_double(st)};" for v, st in ind.items())
+                ok = " && ".join([f"{c} >= 2 * (int64_t)s.rep_n"] + [f"za_coop_int({self.var_ref(v)})" for v in ind])
+                # REPLICA LANES SHARE THE TRIPS (zab_generic.hip.h): lane r of the instance takes trips k = r, r + R, ...; the
+                # partial sums meet in a fixed-order butterfly; every lane repeats the last trip (partials discarded) so that the
+                # script's temporaries and the loop's value end as they would serially. Differs from the serial sum by rounding.
+                coop = (f"if (ZA_COOP_ON(s) && {ok}) {{ "
+                        + " ".join(f"const double {start[v]} = {self.var_ref(v)};" for v in ind)
+                        + " " + " ".join(f"double {part[a]} = 0.0;" for a in accs)
+                        + f" for (int64_t {k} = s.rep_i; {k} < {c}; {k} += s.rep_n) {{ {seti(k)} (void)({body_r}); }} "
+                        + " ".join(f"{part[a]} = za_coop_sum(s, {part[a]});" for a in accs)
+                        + " " + " ".join(f"{self.var_ref(a)} = {self.var_ref(a)} + {part[a]};" for a in accs)
+                        + f" {{ " + " ".join(f"double {part[a]} = 0.0;" for a in accs) + f" {seti(c + ' - 1')} {l} = {body_r}; "
+                        + " ".join(f"(void){part[a]};" for a in accs) + " } } else ")
+        body = self.expr(n.body)
+        if (inner and hot and self.unroll and self.unrolled < self.UNROLL_MAX_LOOPS
                 and self._nodes(n.body) <= self.UNROLL_MAX_NODES):
             self.unrolled += 1
             one = f"{l} = {body};"
-            return (head + f"int64_t {i} = 0; for (; {i} + 4 <= {c}; {i} += 4) {{ {one} {one} {one} {one} }} "
-                    f"for (; {i} < {c}; ++{i}) {{ {one} }} {l}; }})")
-        return head + f"for (int64_t {i} = 0; {i} < {c}; ++{i}) {{ {l} = {body}; }} {l}; }})"
+            return (head + coop + f"{{ int64_t {i} = 0; for (; {i} + 4 <= {c}; {i} += 4) {{ {one} {one} {one} {one} }} "
+                    f"for (; {i} < {c}; ++{i}) {{ {one} }} }} {l}; }})")
+        return head + coop + f"{{ for (int64_t {i} = 0; {i} < {c}; ++{i}) {{ {l} = {body}; }} }} {l}; }})"
 
     def _nodes(self, node, depth=0) -> int:
         """AST size of an expression with user-function bodies counted at every call site (they are all inlined)."""
