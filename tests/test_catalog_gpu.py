@@ -277,3 +277,35 @@ def test_sample_leaf_device_vs_port(pooled):
         assert np.abs(y[i].astype(np.float64) - ref).max() <= AUDIO_EPS, i
         assert_state_close(names, v[i], p.vars(), what=f"Sample vars[{i}]")
     assert np.abs(y).max() > 0
+
+
+@pytest.mark.parametrize("ipw", ["auto", "1", "16", "64"])
+def test_accumulation_loops_on_replica_lanes(ipw, monkeypatch):
+    """tests/fixtures/coopkat.jsfx: every loop variant of the replica-lane form (zajit/emit.py e_Loop) against the CPU port, which
+    runs the same loops serially: 64, 16, 4 and 1 lanes per instance, tap counts from 1 (serial fallback: fewer trips than lanes)
+    to 200, one slider row per instance. Sums differ from the serial order by rounding only."""
+    import zabatch
+    from oracle import port
+    from zajit import noise
+    if ipw != "auto":
+        monkeypatch.setenv("ZAB_IPW", ipw)
+        monkeypatch.setenv("ZAB_LMEM", "0")          # (the LDS window would thin the waves further)
+    else:
+        monkeypatch.delenv("ZAB_IPW", raising=False)
+    meta = zabatch.leaf_meta("fx_coopkat")
+    assert "coop" in meta["features"]
+    n, frames = 7, 1024
+    rows = np.tile(np.array(meta["default_sliders"], dtype=np.float64), (n, 1))
+    rows[:, 0] = [1, 2, 7, 48, 64, 129, 200]
+    x = noise.white_noise(range(n), frames)
+    with zabatch.Engine("fx_coopkat", n) as e:
+        e.set_sliders(rows); e.prepare()
+        y = e.process_host(x, block=256)
+        v = e.read_vars(); names = e.var_names()
+        assert e.launch_shape()[0] == (int(ipw) if ipw != "auto" else e.launch_shape()[0])
+    for i in range(n):
+        p = port.Port("fx_coopkat", 48000.0)
+        p.set_sliders(rows[i]); p.prepare()
+        ref = p.process(x[i], 256)
+        assert np.abs(y[i].astype(np.float64) - ref).max() <= AUDIO_EPS, (i, rows[i][0])
+        assert_state_close(names, v[i], p.vars(), what=f"coopkat vars[{i}] taps {rows[i][0]}")

@@ -173,3 +173,27 @@ def test_reference_compile_smoke_scripts():
     p.prepare()
     y = p.process(np.zeros((2, 64), np.float32) + 0.25, 64)
     assert np.isfinite(y).all()
+
+
+COOP_CASES = [
+    # (body of @sample, expected number of loops emitted in the replica-lane form)
+    ("s = 0; i = 0; loop(64, s += mem[100 + i] * mem[i]; i += 1;); spl0 = s;", 1),                     # FIR
+    ("a = 0; b = 0; i = 0; loop(32, c = mem[i]; a += c * spl0; b -= c; i += 2;); spl0 = a + b;", 1),       # two sums, temp, step 2
+    ("function tap(k) local(j) ( j = (k + 3) & 63; mem[j]; ); s = 0; i = 0; loop(64, s += tap(i); i += 1;); spl0 = s;", 1),
+    ("s = 0; i = 0; loop(64, mem[i] = s; s += 1; i += 1;);", 0),                                         # arena store
+    ("s = 0; i = 0; loop(64, s += mem[i] * s; i += 1;);", 0),                                            # sum read in the trip
+    ("s = 0; i = 0; y = 0; loop(64, s += y; y = mem[i]; i += 1;);", 0),                                  # y carried between trips
+    ("s = 0; i = 0; loop(64, s += mem[i]; i += 0.5;);", 0),                                              # non-integer step
+    ("s = 0; i = 0; loop(64, s += mem[i]; mem[i] > 0 ? i += 1;);", 0),                                   # conditional counter
+    ("s = 0; i = 0; loop(64, s += rand(1); i += 1;);", 0),                                               # impure builtin
+    ("s = 0; i = 0; loop(8, j = 0; loop(8, s += mem[i + j]; j += 1;); i += 1;);", 1),                    # only the inner loop
+]
+
+
+@pytest.mark.parametrize("body,expected", COOP_CASES)
+def test_accumulation_loop_recognition(body, expected):
+    """zajit/emit.py _coop_plan: which loops may run their trips on the replica lanes of an instance."""
+    from zajit import codegen, program
+    unit = codegen.make_unit(program.analyse("desc:t\n@sample\n" + body + "\n"))
+    assert unit.code.count("ZA_COOP_ON(s)") == expected, unit.code
+    assert ("coop" in unit.features) == (expected > 0)
