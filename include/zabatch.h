@@ -23,6 +23,7 @@
 #ifndef ZABATCH_H
 #define ZABATCH_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
