@@ -268,10 +268,16 @@ int zab_create(const char* module, const zab_config* cfg, zab_engine** out) {
     // 11.4 / 2.9 / 1.45 / 1.45 / 1.46 ms, STFT fixture 443 / 276 / 248 / 232 / 780 ms, DOT 642 / 600 / 593 / 593 / 2200 ms --
     // below ~4 the serial parts pay for 64x the memory instructions chip-wide.
     int ipw = m->prefer_instance_major == 2 ? 8 : (m->nch >= 6 ? 16 : 64);
-    // FFT-hot leaves hold a 64 KB LDS transform buffer per wavefront (two wavefronts per CU): small batches get thinner
-    // waves so that ~256 of them exist (2048 x 4096-pt round trips: 1.44 ms at any ipw; 256 buffers: 5.6 / 2.8 / 1.4 ms at
-    // ipw 8 / 4 / 2; the STFT fixture at 1024 instances 395 / 365 / 668 ms)
-    if (m->prefer_instance_major == 2 && cfg->n_instances <= 1024) ipw = cfg->n_instances <= 512 ? 2 : 4;
+    // Replica-lane leaves (FFT builtins or accumulation loops on the audio path) want a fixed number of wavefronts rather than
+    // a fixed width: ~256 when each wavefront holds a 64 KB LDS transform buffer (two per CU), ~1024 otherwise. Measured:
+    // 4096-pt round trips, 256 buffers: 5.6 / 2.8 / 1.4 ms at ipw 8 / 4 / 2, 2048 buffers: 1.44 ms at any; DOT x4096: 133 / 90 /
+    // 75 ms at ipw 4 / 8 / 16; TSEQ x1024: 417 / 274 / 294 / 486 ms at ipw 1 / 2 / 4 / 8, x4096: 329 / 227 / 328 at 2 / 4 / 8,
+    // x16384: 457 / 385 / 340 / 480 at 4 / 8 / 16 / 32.
+    if (m->prefer_instance_major == 2) {
+      const int64_t target = m->fft_scratch_doubles > 0 ? 256 : 1024;
+      ipw = 2;
+      while (ipw < 64 && (int64_t)cfg->n_instances > target * ipw) ipw <<= 1;
+    }
     while (ipw < 64 && (int64_t)cfg->n_instances > 2048ll * ipw) ipw <<= 1;
     if (const char* f = getenv("ZAB_IPW")) { const int v = atoi(f); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) ipw = v; }
     b.ipw = ipw;
