@@ -1,27 +1,40 @@
 #!/usr/bin/env python3
-"""Headline benchmark: Msamples/s of the batched DDT hot path (48 kHz stereo, block = 512) on MI355X.
+"""Headline benchmark: Msamples/s of the batched hot path (48 kHz, block = 512) on MI355X, with the null test beside it.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--leaf DDT] [--instances-total 4096]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A *step* is one pass of the hot path over one batch: every instance on this rank processes 10 s (480 000 frames) of
-its own 48 kHz stereo white noise in host blocks of 512 (937 full + one 256-frame tail), i.e. one
-zab_process(frames=480000, block=512) over N_inst instances with inputs and outputs resident in HBM.
-Workload at N=1 = BASELINE.json configs[1]: "DDT 1024 batched instances on 1 MI355X, block=512".
-Instances are independent, so ranks shard them with no data-path collective (weak scaling: 1024 instances per GPU);
-RCCL is used only for the barrier and the max-over-ranks of the timed region.
+A *step* is one pass of the hot path over one batch: every instance of the job processes 10 s (480 000 frames) of its own
+48 kHz white noise in host blocks of 512 (937 full + one 256-frame tail), i.e. one zab_process(frames, block=512) per rank
+over that rank's instances, inputs and outputs resident in HBM.
 
-One JSON line on rank 0 (see README/DESIGN for the field definitions), including
-  roofline     -- dominant kernel's algorithmic HBM bytes / its mean duration (HIP events on the engine stream)
-  cpu_baseline -- the CPU port of the same path (oracle/port.py, g++ -O2 scalar f64; kind "port") timed on this box's host
-                  cores on a bounded sample. (The reference's EEL2 VM needs the leaf's script text, which does not travel
-                  to the GPU box; its speed is recorded in DESIGN.md.)
+Default workload = the north-star headline (BASELINE.md "headline"): Spatialization/DDT x 4096 instances in
+total, STRONG scaling -- rank r of W owns sharding.instance_range(4096, r, W), no data-path collective; RCCL carries the
+barrier and the max / sum of the run statistics only. BASELINE.json configs[1] (DDT x 1024 on one GPU) is
+`--instances-total 1024`; config C5 is `--leaf ClickBeGoneSG --instances-total 8192`; `--instances-per-gpu K` gives a
+weak-scaling run instead. `--gpus N` without a torchrun environment starts the N ranks itself (child torchrun).
+
+One JSON line on rank 0:
+  value / ms_per_step .... whole-job throughput of the timed region (max over ranks of the wall time)
+  null_test_dbfs ......... max and RMS of (engine output - CPU checker output) in dBFS over a sample of instances of every
+                           rank, taken from the FIRST launch of the very engine that is timed (same kernel, same batch
+                           shape), outside the timed region. Checker = oracle/port.py (pinned to the reference VM's
+                           fixtures) for JSFX leaves, oracle/faust_ref.c for Faust leaves.
+  roofline ............... dominant kernel's algorithmic HBM bytes / its mean duration (HIP events on the engine stream);
+                           `traffic` is read from the committed PMC passes of this command (`traffic_source` says which)
+  cpu_baseline ........... the CPU checker of the same leaf timed on this box's host cores on a bounded sample (kind "port"),
+                           plus `reference_vm`: the reference's own WDL/EEL2 VM (oracle/_ref, built from the reference
+                           sources) timed on one core on the repo-authored tap-delay script tests/fixtures/delaytaps.jsfx
+                           (the reference's leaf scripts do not travel to the GPU box), with the port's speed on the same
+                           script beside it.
 """
 from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
+import subprocess
 import sys
 import time
 from concurrent.futures import ThreadPoolExecutor
@@ -38,74 +51,174 @@ for p in (str(PKG), str(ROOT)):
 SRATE = 48000.0
 FRAMES = 480_000          # 10 s
 BLOCK = 512
-NCH = 2
-HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy kernel achieves
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md); ~5 TB/s is what a device copy reaches
+MIN_TIMED_S = 2.5         # --steps default: as many as make the timed region at least this long
 
 
-def algorithmic_bytes_per_launch(n_inst: int, frames: int, meta_state: dict) -> float:
-    """DESIGN.md §roofline. The DDT kernel is persistent over the launch (state stays on-chip across host blocks), so
-    per frame only the audio moves: 2 ch x 4 B in + 2 ch x 4 B out = 16 B. Per launch and instance, once:
-    delay history read 2 x 8 x H, ring write-back 2 x 8 x min(frames, 16384), tap tables 5 x 8 x tapN, vars r/w."""
-    per_frame = 16.0
-    H, tapN, nvars = meta_state["H"], meta_state["tapN"], meta_state["nvars"]
-    per_launch = 2 * 8 * H + 2 * 8 * min(frames, 16384) + 5 * 8 * tapN + 2 * 8 * nvars
-    return n_inst * (per_frame * frames + per_launch)
+# ----------------------------------------------------------------------------------------------------------------------
+# CPU checker leg (the only part of this file that touches oracle/): null test + cpu_baseline
+# ----------------------------------------------------------------------------------------------------------------------
+class Checker:
+    """CPU restatement of one leaf: oracle/port.py for JSFX leaves, oracle/faust_ref.c for Faust leaves."""
+
+    def __init__(self, leaf: str, meta: dict):
+        self.leaf, self.meta = leaf, meta
+        self.faust = meta.get("kind") == "faust"
+        self.kind_text = ("oracle/faust_ref.c (CPU restatement of the .dsp, gcc -O2, scalar f32; parity unpinned)" if self.faust
+                          else "oracle/port.py (AOT lowering compiled by g++ -O2, scalar f64; pinned to reference-VM fixtures)")
+
+    def fresh(self):
+        if self.faust:
+            from oracle import faust_ref
+            return faust_ref.FaustRef(self.leaf, SRATE)
+        from oracle import port
+        p = port.Port(self.leaf, SRATE)
+        p.set_sliders(self.meta["default_sliders"])
+        p.prepare()
+        return p
+
+    def run(self, obj, x, block):
+        if self.faust:
+            return obj.compute(x, self.meta["default_sliders"][:8], block=block)
+        return obj.process(x, block)
 
 
-def cpu_baseline(seconds_budget: float = 12.0):
-    """CPU restatement of the same hot path (oracle/port.py: the AOT lowering compiled by g++ -O2, scalar f64 -- the
-    stand-in for the reference's LLVM-AOT object) on this box's host cores, on a bounded sample of the same workload:
-    DDT defaults, 48 kHz stereo white noise, block 512, one instance per thread (ctypes releases the GIL).
-    The reference's own EEL2 VM cannot serve here: it needs the leaf's script text, which must not travel to the GPU
-    box; its speed measured in the dev container is recorded in DESIGN.md instead."""
-    from oracle import port
-    import zabatch
+def null_test(checker: Checker, outs: dict):
+    """outs: {instance: (x, y)} float32 [nch, frames] input (as generated in HBM) and output of the engine's first launch.
+    Returns (max |d|, sum d^2, count)."""
+    mx, ss, cnt = 0.0, 0.0, 0
+    for _, (x, y) in outs.items():
+        ref = checker.run(checker.fresh(), x, BLOCK)
+        d = y.astype(np.float64) - ref.astype(np.float64)
+        mx = max(mx, float(np.abs(d).max()))
+        ss += float((d * d).sum())
+        cnt += d.size
+    return mx, ss, cnt
+
+
+def cpu_baseline(checker: Checker, nch: int, seconds_budget: float = 10.0):
+    """The leaf's CPU checker on this box's host cores, bounded sample: one instance per thread (ctypes releases the GIL),
+    2 s passes of the benchmark's own noise repeated for ~seconds_budget."""
     from zajit import noise
-    meta = zabatch.leaf_meta("DDT")
     cores = max(1, min(os.cpu_count() or 1, 16))
-    frames = 96_000   # 2 s of audio per pass and thread
-    x = noise.white_noise(range(cores), frames)
+    frames = 96_000
+    x = noise.white_noise(range(cores), frames, channels=nch)
 
     def work(i, budget=seconds_budget):
-        p = port.Port("DDT", SRATE)
-        p.set_sliders(meta["default_sliders"]); p.prepare()
+        obj = checker.fresh()
         t = time.perf_counter()
         reps = 0
         while True:
-            p.process(x[i], BLOCK)
+            checker.run(obj, x[i], BLOCK)
             reps += 1
             if time.perf_counter() - t > budget:
                 break
         return reps
 
     t1 = time.perf_counter()
-    one = work(0, 3.0) * frames * NCH / (time.perf_counter() - t1) / 1e6       # SURVEY §8d: 1 core beside all cores
+    one = work(0, 2.5) * frames * nch / (time.perf_counter() - t1) / 1e6
     t0 = time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:
         reps = list(ex.map(work, range(cores)))
     wall = time.perf_counter() - t0
-    total = sum(reps) * frames * NCH
-    return {"value": total / wall / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port", "one_core": one,
-            "sample": f"DDT defaults, {cores} threads x 1 instance, {frames}-frame passes repeated for ~{seconds_budget:.0f} s, block 512, g++ -O2 scalar f64"}
+    return {"value": sum(reps) * frames * nch / wall / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "one_core": one, "checker": checker.kind_text,
+            "sample": f"{checker.leaf} defaults, {cores} threads x 1 instance, {frames}-frame passes repeated for ~{seconds_budget:.0f} s, block {BLOCK}"}
+
+
+def reference_vm_baseline(seconds_budget: float = 4.0):
+    """The reference's own CPU path -- its WDL/EEL2 VM, compiled from the reference sources into oracle/_ref -- on one host
+    core, on the repo-authored tap-delay script (the leaf scripts themselves stay in the reference tree), and the CPU port
+    on the same script: the ratio relates `cpu_baseline.value` (port) to what the reference VM would do."""
+    from oracle import eel_oracle, port
+    from zajit import noise, program, sliders
+    src = ROOT / "tests" / "fixtures" / "delaytaps.jsfx"
+    if not eel_oracle.available() or not src.exists():
+        return None
+    text = program.expand_imports(src)
+    prog = program.analyse(text, "fx_delaytaps")
+    row = sliders.default_slider_values(prog.slider_decls)
+    frames = 24_000
+    x = noise.white_noise([0], frames)[0]
+    vm = eel_oracle.EelOracle(text, prog.aliases)
+    vm.set_sliders(row)
+    vm.prepare(SRATE)
+    vm.set_write_trace(False)        # the correctness monitor's store instrumentation is not part of the VM's own speed
+    t0, reps = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds_budget:
+        vm.process(x, BLOCK)
+        reps += 1
+    vm_rate = reps * frames * 2 / (time.perf_counter() - t0) / 1e6
+    out = {"value": vm_rate, "unit": "Msamples/s", "cores": 1, "kind": "reference",
+           "sample": f"WDL/EEL2 portable VM (oracle/_ref, gcc -O2) on tests/fixtures/delaytaps.jsfx defaults, {frames}-frame passes "
+                     f"for ~{seconds_budget:.0f} s, block {BLOCK}, one core"}
+    if port.port_path("fx_delaytaps").exists():
+        p = port.Port("fx_delaytaps", SRATE)
+        p.set_sliders(row)
+        p.prepare()
+        t0, reps = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 1.5:
+            p.process(x, BLOCK)
+            reps += 1
+        out["port_same_script_one_core"] = reps * frames * 2 / (time.perf_counter() - t0) / 1e6
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def algorithmic_bytes(leaf: str, n_inst: int, frames: int, nch_io: int, nvars: int, ddt_state, mem_words: int) -> float:
+    """the kernels are persistent over a launch (state stays on-chip across host blocks), so per frame
+    only the audio moves: 4 B in + 4 B out per channel. Once per launch and instance: vars r/w, and
+      DDT:      delay history read 2 x 8 x H, ring write-back 2 x 8 x min(frames, 16384), tap tables 5 x 8 x tapN
+      others:   the arena footprint (write high-water mark) read + written once."""
+    per_frame = 8.0 * nch_io
+    once = 2 * 8 * nvars
+    if ddt_state:
+        once += 2 * 8 * ddt_state["H"] + 2 * 8 * min(frames, 16384) + 5 * 8 * ddt_state["tapN"]
+    else:
+        once += 2 * 8 * mem_words
+    return n_inst * (per_frame * frames + once)
+
+
+def spawn_ranks(n: int, argv) -> int:
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as a child torchrun (nothing here has touched the GPU)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + list(argv)
+    return subprocess.call(cmd)
 
 
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=0, help=f"0 = as many as make the timed region >= {MIN_TIMED_S} s")
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--instances-per-gpu", type=int, default=1024)
+    ap.add_argument("--leaf", default="DDT")
+    ap.add_argument("--instances-total", type=int, default=4096, help="strong scaling: split over the ranks")
+    ap.add_argument("--instances-per-gpu", type=int, default=0, help="weak scaling: this many on every rank")
     ap.add_argument("--frames", type=int, default=FRAMES)
     ap.add_argument("--path", choices=["auto", "generic", "fast"], default="auto")
+    ap.add_argument("--null-instances", type=int, default=4, help="instances per rank checked against the CPU checker")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-null-test", action="store_true")
     args = ap.parse_args()
-
-    import torch
-    import zabatch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and "RANK" not in os.environ and args.gpus > 1:
+            return spawn_ranks(args.gpus, sys.argv[1:])
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}", file=sys.stderr)
+        return 2
+
+    import torch
+    import sharding
+    import zabatch
+
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (the engine has no CPU path)", file=sys.stderr)
         return 2
@@ -116,17 +229,28 @@ def main() -> int:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    n_inst = args.instances_per_gpu
+    leaf = args.leaf
+    meta = zabatch.leaf_meta(leaf)
+    weak = args.instances_per_gpu > 0
+    if weak:
+        lo, hi = rank * args.instances_per_gpu, (rank + 1) * args.instances_per_gpu
+        n_total = world * args.instances_per_gpu
+    else:
+        n_total = args.instances_total
+        lo, hi = sharding.instance_range(n_total, rank, world)
+    n_inst = hi - lo
+    if n_inst <= 0:
+        print(f"bench.py: rank {rank} owns no instances ({n_total} over {world} ranks)", file=sys.stderr)
+        return 2
     frames = args.frames
     path = {"auto": zabatch.ZAB_PATH_AUTO, "generic": zabatch.ZAB_PATH_GENERIC, "fast": zabatch.ZAB_PATH_FAST}[args.path]
-    meta = zabatch.leaf_meta("DDT")
-    eng = zabatch.Engine("DDT", n_inst, srate=SRATE, max_block=BLOCK, device=local_rank, path=path,
-                         first_instance_id=1 + rank * n_inst)
+    eng = zabatch.Engine(leaf, n_inst, srate=SRATE, max_block=BLOCK, device=local_rank, path=path, first_instance_id=1 + lo)
+    nch = eng.nch
     eng.set_sliders(meta["default_sliders"])
     eng.prepare()
-    nbytes = n_inst * NCH * frames * 4
+    nbytes = n_inst * nch * frames * 4
     d_in, d_out = eng.device_alloc(nbytes), eng.device_alloc(nbytes)
-    eng.device_noise(d_in, frames, id_offset=rank * n_inst)      # synthetic white noise, generated in HBM
+    eng.device_noise(d_in, frames, id_offset=lo)      # synthetic white noise, generated in HBM; noise id = global instance index
     eng.sync()
 
     def barrier():
@@ -135,77 +259,120 @@ def main() -> int:
         if dist is not None:
             dist.barrier()
 
-    for _ in range(args.warmup):
+    # first launch of the timed engine: its output for a sample of instances is what the null test checks
+    eng.process_device(d_in, d_out, frames, block=BLOCK)
+    eng.sync()
+    t_first = eng.last_timing()[0] * 1e-3
+    sample_out = {}
+    if not args.no_null_test:
+        k = max(1, min(args.null_instances, n_inst))
+        for j in sorted({int(round(q * (n_inst - 1) / max(1, k - 1))) for q in range(k)}):
+            off = j * nch * frames * 4
+            sample_out[lo + j] = (eng.download(d_in + off, (nch, frames)), eng.download(d_out + off, (nch, frames)))
+    for _ in range(max(0, args.warmup - 1)):
         eng.process_device(d_in, d_out, frames, block=BLOCK)
+    eng.sync()
+    t_step = eng.last_timing()[0] * 1e-3
+    steps = args.steps
+    if steps <= 0:
+        steps = max(10, int(math.ceil(MIN_TIMED_S / max(t_step, 1e-6))))
+        if dist is not None:
+            t = torch.tensor([steps], dtype=torch.int64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            steps = int(t[0])
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         eng.process_device(d_in, d_out, frames, block=BLOCK)
     eng.sync()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
     # device duration of each launch of the timed region: HIP event pairs recorded on the engine's own stream
-    kernel_ms = eng.timing_history(min(args.steps, 64))
+    kernel_ms = eng.timing_history(min(steps, 64))
     used_fast = eng.used_fast_path()
     kernel_name = eng.last_kernel_name()
-    import sharding
-    job = sharding.reduce_stats(sharding.RunStats(elapsed_s=elapsed, units=float(n_inst) * NCH * frames * args.steps),
+
+    checker = Checker(leaf, meta)
+    null_mx, null_ss, null_n = (0.0, 0.0, 0)
+    if sample_out:
+        null_mx, null_ss, null_n = null_test(checker, sample_out)
+    job = sharding.reduce_stats(sharding.RunStats(elapsed_s=elapsed, units=float(n_inst) * nch * frames * steps, max_abs_err=null_mx),
                                 dist, device="cuda" if dist is not None else None)
+    if dist is not None:
+        t = torch.tensor([null_ss, float(null_n)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        null_ss, null_n = float(t[0]), int(t[1])
     elapsed = job.elapsed_s            # MAX over ranks
 
     # state-dependent constants for the algorithmic byte count
     names = eng.var_names()
-    v = eng.read_vars(0, 1)[0]
-    tapN = int(v[names.index("tapN")])
-    dl = eng.read_mem(32768, 64, 0, 1)[0][:tapN]
-    dr = eng.read_mem(32768 + 64, 64, 0, 1)[0][:tapN]
-    dmax = int(max(dl.max(), dr.max()))
-    # history the taps can reach back into = Dmax frames (the kernel stages a power-of-two ring; the surplus is not counted)
-    alg = algorithmic_bytes_per_launch(n_inst, frames, {"H": dmax, "tapN": tapN, "nvars": len(names)})
+    ddt_state = None
+    if leaf == "DDT":
+        v = eng.read_vars(0, 1)[0]
+        tapN = int(v[names.index("tapN")])
+        dl = eng.read_mem(32768, 64, 0, 1)[0][:tapN]
+        dr = eng.read_mem(32768 + 64, 64, 0, 1)[0][:tapN]
+        # history the taps can reach back into = Dmax frames (the kernel stages a longer ring; the surplus is not counted)
+        ddt_state = {"H": int(max(dl.max(), dr.max())), "tapN": tapN}
+    mem_words = int(eng.mem_high(0, 1)[0]) if meta.get("kind") != "faust" else 0
+    nch_io = (meta["io"]["inputs"] + meta["io"]["outputs"]) / 2.0 if "io" in meta else nch
+    alg = algorithmic_bytes(leaf, n_inst, frames, nch_io, len(names), ddt_state, mem_words)
 
     if rank == 0:
         total_samples = job.units      # SUM over ranks
         k_ms = float(np.mean(kernel_ms))
         achieved = alg / (k_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_source = None, None
         pmc = ROOT / "profiles" / "pmc_traffic.json"
         if pmc.exists():
             try:
                 rec = json.loads(pmc.read_text())
-                if rec.get("instances") == n_inst and rec.get("frames") == frames and rec.get("fast") == used_fast:
+                if (rec.get("leaf", "DDT") == leaf and rec.get("instances") == n_inst and rec.get("frames") == frames
+                        and rec.get("fast") == used_fast):
                     traffic = rec.get("hbm_bytes_per_launch")
+                    traffic_source = ("profiles/pmc_traffic.json: committed rocprofv3 --pmc passes of this command "
+                                      "(FETCH_SIZE / WRITE_SIZE, separate runs), not measured in this run")
             except Exception:
                 traffic = None
+        null_db = lambda a: None if null_n == 0 else (float(20.0 * math.log10(a)) if a > 0 else -400.0)
         line = {
-            "metric": "Msamples/sec across batched instances, 48 kHz stereo block=512",
+            "metric": "Msamples/sec across batched instances, 48 kHz stereo block=512; null-test dBFS",
             "value": total_samples / elapsed / 1e6,
             "unit": "Msamples/s",
             "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "steps": steps,
+            "warmup": max(1, args.warmup),
+            "ms_per_step": elapsed / steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if weak else "strong",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f32" if meta.get("kind") == "faust" else "f64",
             "data": "synthetic",
-            "config": {"workload": f"DDT x{n_inst} instances per GPU, defaults, 48 kHz stereo, {frames} frames white noise, block={BLOCK}",
-                       "leaf": "Spatialization/DDT", "instances_total": world * n_inst, "frames_per_step": frames,
-                       "kernel": kernel_name, "sharding": f"instances x{world}, no collective"},
-            "mframes_per_s": total_samples / NCH / elapsed / 1e6,
-            "realtime_factor_per_instance": frames / SRATE / (elapsed / args.steps),
+            "null_test_dbfs": null_db(job.max_abs_err),
+            "null_test": {"max_dbfs": null_db(job.max_abs_err), "rms_dbfs": null_db(math.sqrt(null_ss / null_n)) if null_n else None,
+                          "max_abs": job.max_abs_err if null_n else None, "instances_checked": null_n // max(1, nch * frames),
+                          "frames": frames, "pass_bar_dbfs": -100.0, "checker": checker.kind_text,
+                          "what": "first launch of the timed engine vs the CPU checker on the same noise, outside the timed region"},
+            "config": {"workload": f"{leaf} x{n_total} instances in total ({'weak' if weak else 'strong'} scaling, "
+                                   f"{n_inst} on rank 0), defaults, 48 kHz x{nch} ch, {frames} frames white noise, block={BLOCK}",
+                       "leaf": leaf, "instances_total": n_total, "instances_rank0": n_inst, "frames_per_step": frames,
+                       "kernel": kernel_name, "sharding": f"sharding.instance_range over {world} rank(s), no data-path collective"},
+            "mframes_per_s": total_samples / nch / elapsed / 1e6,
+            "realtime_factor_per_instance": frames / SRATE / (elapsed / steps),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": kernel_name, "kernel_ms": k_ms,
-                         "algorithmic_bytes_per_launch": alg, "bytes_per_frame": alg / (n_inst * frames),
-                         # context: the script's own arithmetic, 14 flop per tap + 80 per frame, all f64,
-                         # against the FP64 vector peak (half the guide's 157.3 TFLOP/s FP32 vector figure)
-                         "fp64_flop_per_frame": 14 * tapN + 80,
-                         "fp64_tflops": (14 * tapN + 80) * n_inst * frames / (k_ms * 1e-3) / 1e12,
-                         "fp64_vector_peak_tflops": 78.6},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": kernel_name, "kernel_ms": k_ms, "kernel_ms_min": float(np.min(kernel_ms)),
+                         "kernel_ms_first_launch": t_first * 1e3,
+                         "algorithmic_bytes_per_launch": alg, "bytes_per_frame": alg / (n_inst * frames)},
         }
-        line["roofline"]["fp64_frac"] = line["roofline"]["fp64_tflops"] / 78.6
+        if ddt_state:
+            # context: the script's own arithmetic, 14 flop per tap + 80 per frame, all f64, against the FP64
+            # vector peak (half the guide's 157.3 TFLOP/s FP32 vector figure)
+            fl = 14 * ddt_state["tapN"] + 80
+            line["roofline"].update(fp64_flop_per_frame=fl, fp64_tflops=fl * n_inst * frames / (k_ms * 1e-3) / 1e12,
+                                    fp64_vector_peak_tflops=78.6)
+            line["roofline"]["fp64_frac"] = line["roofline"]["fp64_tflops"] / 78.6
         try:    # what a plain device copy reaches on this box (SURVEY §8d asks for it beside the spec peak)
             src = torch.empty(1 << 28, dtype=torch.float32, device="cuda")        # 1 GiB
             dst = torch.empty_like(src)
@@ -222,7 +389,13 @@ def main() -> int:
         except Exception:
             pass
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+            line["cpu_baseline"] = cpu_baseline(checker, nch)
+            try:
+                ref = reference_vm_baseline()
+            except Exception as ex:  # noqa: BLE001  (the VM library is optional on a box that never saw the reference)
+                ref = {"error": str(ex)[:200]}
+            if ref:
+                line["cpu_baseline"]["reference_vm"] = ref
         print(json.dumps(line), flush=True)
     eng.close()
     if dist is not None:

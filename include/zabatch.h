@@ -96,9 +96,17 @@ int zab_var_index(zab_engine* e, const char* name);   /* -1 if unknown */
 /* Slider values as the host bridge would write them into st.sliders[] (already clamped/quantised by the caller,
  * zajit.sliders mirrors src/JSFXJuceProcessor.cpp:5556-5596). values = count x 64 doubles for instances
  * [first, first+count); count = 0 with first = 0 broadcasts one row of 64 to every instance.
- * Instances whose values changed run @slider at the start of the next zab_process (processBlock :3545-3547). */
+ * Instances whose values differ from what the host pushed last (the reference's lastSliders comparison in
+ * pushParamsToStateSliders, :9286-9357 -- not from what a script may have written into its sliders meanwhile) run @slider
+ * at the start of the next zab_process (processBlock :3545-3547). The values always overwrite the device's. */
 int zab_set_sliders(zab_engine* e, int32_t first, int32_t count, const double* values);
 int zab_get_sliders(zab_engine* e, int32_t first, int32_t count, double* values);
+/* consumeDspSliderChanges() (src/JSFXJuceProcessor.cpp:5665-5739) for instances [first, first+count): masks[i] receives the
+ * OR of the pendingSlider{Change,Automate,AutomateEnd} masks the scripts raised (sliderchange / slider_automate) since the
+ * previous call and the device-side record is cleared; values receives the 64 current slider values of each instance. For the
+ * sliders named in a mask the engine also takes the script's value as "last pushed" (lastSliders / internalSliderShadow in
+ * the reference), so that a host which pushes it back does not trigger @slider again. Either pointer may be null. */
+int zab_consume_slider_changes(zab_engine* e, int32_t first, int32_t count, uint64_t* masks, double* values);
 
 /* prepareToPlay(): @init, slider-alias re-apply, @slider on every instance (sliders must be set before). */
 int zab_prepare(zab_engine* e);
@@ -134,7 +142,14 @@ typedef struct zab_host_state {
   uint32_t* rand_index;           /*        ::randIndex */
   int64_t* slider_visible_mask;   /*        ::sliderVisibleMask */
   int32_t* slider_visibility_init;/*        ::sliderVisibilityInit */
+  /* engine-side bookkeeping with no counterpart in DSPJSFX_State (null = derive): the write high-water mark of mem[]
+   * (upload: null means mem_n, i.e. the whole host image counts as written) and the ZAB_FLAG_* word of the instance
+   * (bit 0: sliders changed, @slider runs at the next zab_process; upload: null leaves it alone). */
+  int64_t* mem_high;
+  uint32_t* flags;
 } zab_host_state;
+/* zab_state_upload replaces the instance's whole image: arena cells above the uploaded prefix that an earlier run had stored
+ * to are zeroed (the host image holds nothing there), the high-water mark becomes *mem_high (or mem_n). */
 int zab_state_upload(zab_engine* e, int32_t instance, const zab_host_state* h);
 int zab_state_download(zab_engine* e, int32_t instance, zab_host_state* h);
 enum { ZAB_SECTION_INIT = 0, ZAB_SECTION_SLIDER = 1, ZAB_SECTION_BLOCK = 2, ZAB_SECTION_SAMPLE = 3 };
@@ -182,7 +197,7 @@ int zab_timing_history(zab_engine* e, double* kernel_ms, int32_t max_entries);
 void* zab_stream(zab_engine* e);   /* hipStream_t of the engine */
 int zab_used_fast_path(zab_engine* e); /* 1 if the most recent zab_process ran the leaf's hand-written kernel */
 /* Name of the kernel the most recent zab_process launched (as rocprofv3 --kernel-trace lists it; templated kernels by the
- * substring before the template arguments). Valid until the next zab_process on any engine of the same leaf. */
+ * substring before the template arguments). Valid until the next zab_process on this engine. */
 const char* zab_last_kernel_name(zab_engine* e);
 /* Page-locked host memory for audio buffers handed to zab_process(ZAB_BUF_HOST): with it the copies of the chunked
  * host-buffer pipeline (copy-in, kernels and copy-out of consecutive time chunks on three HIP streams) are truly

@@ -451,6 +451,11 @@ int64_t eelo_mem_write(eelo* e, int64_t start, int64_t count, const double* src)
   return done;
 }
 int64_t eelo_mem_high(eelo* e) { return e->high; }
+// The write trace is the shadow runtime's instrumentation (src/JSFXCorrectnessCheck.h registers it to follow the touched
+// pages); it costs a RAM-block search per store. Timing runs switch it off to see the VM itself; fixtures keep it on.
+void eelo_set_write_trace(eelo* e, int on) {
+  if (e && e->m_vm) NSEEL_VM_SetWriteTrace(e->m_vm, on ? &eelo::write_trace : nullptr, on ? e : nullptr);
+}
 void eelo_pending_masks(eelo* e, uint64_t* m3) { m3[0] = e->m_change; m3[1] = e->m_automate; m3[2] = e->m_automate_end; }
 
 // Direct access to the reference FFT (src/WDL/fft.c) for builtin known-answer tests.

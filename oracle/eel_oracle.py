@@ -49,6 +49,7 @@ def lib():
         L.eelo_mem_read.restype = i64; L.eelo_mem_read.argtypes = [vp, i64, i64, dp]
         L.eelo_mem_write.restype = i64; L.eelo_mem_write.argtypes = [vp, i64, i64, dp]
         L.eelo_mem_high.restype = i64; L.eelo_mem_high.argtypes = [vp]
+        L.eelo_set_write_trace.argtypes = [vp, i32]
         L.eelo_pending_masks.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.eelo_wdl_fft.argtypes = [dp, i32, i32]
         L.eelo_wdl_real_fft.argtypes = [dp, i32, i32]
@@ -138,6 +139,10 @@ class EelOracle:
     @property
     def mem_high(self) -> int:
         return int(self.L.eelo_mem_high(self.h))
+
+    def set_write_trace(self, on: bool):
+        """Shadow-runtime store instrumentation (mem_high tracking); off for timing runs."""
+        self.L.eelo_set_write_trace(self.h, 1 if on else 0)
 
     def pending_masks(self):
         m = (C.c_uint64 * 3)()

@@ -47,6 +47,8 @@ CASES = [
     ("TSEQ", "default", {}, 2048, 512),
     ("fx_stft", "default", {0: 0.4}, 4096, 512),      # repo-authored fixture leaf (tests/fixtures/stft.jsfx)
     ("fx_stft4k", "default", {0: -0.3}, 12288, 512),  # the same at BASELINE config C3's size: 4096-point, hop 1024
+    ("fx_delaytaps", "default", {}, 4096, 512),       # repo-authored tap-delay script (also the VM's benchmark script)
+    ("fx_delaytaps", "far", {0: 90, 1: 24, 2: 80, 3: -6.0, 4: 100}, 3000, 500),
     # random programs over the constructs the AOT lowering and the EEL2 VM agree on (tests/fixtures/make_fuzz.py)
     ("fx_fuzz0", "default", {0: 3.0}, 600, 128), ("fx_fuzz1", "default", {0: 7.5}, 600, 128),
     ("fx_fuzz2", "default", {0: 0.0}, 600, 128), ("fx_fuzz3", "default", {0: 10.0}, 600, 128),

@@ -309,3 +309,33 @@ def test_accumulation_loops_on_replica_lanes(ipw, monkeypatch):
         ref = p.process(x[i], 256)
         assert np.abs(y[i].astype(np.float64) - ref).max() <= AUDIO_EPS, (i, rows[i][0])
         assert_state_close(names, v[i], p.vars(), what=f"coopkat vars[{i}] taps {rows[i][0]}")
+
+
+def test_script_originated_slider_changes_reach_the_host_mirror():
+    """consumeDspSliderChanges / pushParamsToStateSliders (src/JSFXJuceProcessor.cpp:5665-5739, 9286-9357) through
+    JsfxBatchProcessor: a slider the script sets and announces with sliderchange() becomes the host parameter and is not
+    overwritten by the next push; @slider runs for it exactly once; an unannounced slider write is overwritten by the host
+    value without re-running @slider."""
+    import zabatch
+    from zajit import noise
+    if not zabatch.module_path("fx_slidewrite").exists():
+        pytest.skip("fx_slidewrite not built")
+    n, block, nblocks = 3, 64, 7
+    proc = zabatch.JsfxBatchProcessor("fx_slidewrite", n)
+    proc.prepareToPlay(48000.0, block)
+    x = noise.white_noise(range(n), block * nblocks)
+    outs = [proc.processBlock(x[:, :, k * block:(k + 1) * block]) for k in range(nblocks)]
+    names = proc.engine.var_names()
+    v = proc.engine.read_vars()
+    sl = proc.engine.get_sliders()
+    host = proc.host_params.copy()
+    proc.releaseResources()
+    y = np.concatenate(outs, axis=2)
+    gain = np.ones(block * nblocks); gain[2 * block:] = 1.45            # @slider runs inside block 3, before its samples
+    want = (x.astype(np.float64) * gain[None, None, :]).astype(np.float32)
+    assert np.abs(y.astype(np.float64) - want).max() <= AUDIO_EPS
+    assert (v[:, names.index("nsl")] == 2).all(), v[:, names.index("nsl")]       # prepare + the announced change, nothing else
+    assert (v[:, names.index("cnt")] == nblocks).all()
+    assert np.allclose(v[:, names.index("g")], 0.45, atol=1e-12)
+    assert (sl[:, 0] == 4.5).all() and (host[:, 0] == 4.5).all()
+    assert (sl[:, 1] == 3.0).all() and (v[:, names.index("seen2")] == 3.0).all()   # the unannounced 6.3 was pushed over

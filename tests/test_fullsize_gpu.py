@@ -131,3 +131,77 @@ def test_checkpoint_resume_continues_bit_identically(leaf, tmp_path):
         got = e2.process_host(x[:, :, frames:], block=512)
         assert np.array_equal(got, want)
         assert np.array_equal(e2.read_vars(), want_vars)
+
+
+@pytest.mark.parametrize("leaf", ["SOMA", "fx_delaytaps"])
+def test_checkpoint_chain_and_rollback_into_a_used_engine(leaf, tmp_path):
+    """Checkpoints survive being taken from a restored engine (the arena's write high-water mark travels with them), and
+    restoring into an engine that has run FURTHER rolls it back completely: arena cells it stored to after the checkpoint
+    read as zeros again, marks and pending-@slider flags are the checkpoint's."""
+    import zabatch
+    from zajit import noise
+    if not zabatch.module_path(leaf).exists():
+        pytest.skip(f"{leaf} not built")
+    meta = zabatch.leaf_meta(leaf)
+    n, frames = 3, 1200
+    cap = 1 << 20 if leaf == "SOMA" else 0
+    x = noise.white_noise(range(n), 3 * frames)
+    seg = [x[:, :, k * frames:(k + 1) * frames] for k in range(3)]
+    rows = np.tile(np.array(meta["default_sliders"], dtype=np.float64), (n, 1))
+    with zabatch.Engine(leaf, n, mem_cap=cap) as e:
+        e.set_sliders(rows); e.prepare()
+        e.process_host(seg[0], block=512)
+        ck1 = e.checkpoint()
+        want1 = e.process_host(seg[1], block=512)
+        want2 = e.process_host(seg[2], block=512)
+        want_vars, want_high = e.read_vars(), e.mem_high()
+        want_mem = e.read_mem(0, int(want_high.max())) if want_high.max() else None
+        # rollback: this engine has stored further into its arena than the checkpoint knows about
+        e.write_mem(int(ck1["mem_high"].max()) + 5, np.full((n, 3), 7.25))
+        e.restore(ck1)
+        assert np.array_equal(e.mem_high(), ck1["mem_high"])
+        assert not e.read_mem(int(ck1["mem_high"].max()), 16).any()
+        assert np.array_equal(e.process_host(seg[1], block=512), want1)
+    # chain: restore -> run -> checkpoint -> restore -> run, each hop in a fresh engine
+    with zabatch.Engine(leaf, n, mem_cap=cap) as e2:
+        e2.restore(ck1)
+        assert np.array_equal(e2.mem_high(), ck1["mem_high"])
+        assert np.array_equal(e2.process_host(seg[1], block=512), want1)
+        ck2 = e2.checkpoint()
+        assert (ck2["mem_high"] >= ck1["mem_high"]).all() and ck2["mem_data"].size >= ck1["mem_data"].size
+    np.savez(tmp_path / "ck2.npz", **ck2)
+    ck2 = dict(np.load(tmp_path / "ck2.npz"))
+    with zabatch.Engine(leaf, n, mem_cap=cap) as e3:
+        e3.restore(ck2)
+        assert np.array_equal(e3.process_host(seg[2], block=512), want2)
+        assert np.array_equal(e3.read_vars(), want_vars)
+        assert np.array_equal(e3.mem_high(), want_high)
+        if want_mem is not None:
+            assert np.array_equal(e3.read_mem(0, want_mem.shape[1]), want_mem)
+    with zabatch.Engine(leaf, n, mem_cap=(cap or 65536) * 2) as e4:
+        with pytest.raises(zabatch.ZabError):
+            e4.restore(ck2)                       # arena capacity differs
+    with zabatch.Engine(leaf, n, srate=44100.0, mem_cap=cap) as e5:
+        with pytest.raises(zabatch.ZabError):
+            e5.restore(ck2)                       # sample rate differs
+
+
+def test_pending_slider_flag_survives_a_checkpoint():
+    """Sliders changed but @slider not yet run when the checkpoint is taken: the restored engine runs it, like the original."""
+    import zabatch
+    from zajit import noise
+    meta = zabatch.leaf_meta("DPT")
+    n, frames = 2, 700
+    x = noise.white_noise(range(n), 2 * frames)
+    rows = np.tile(np.array(meta["default_sliders"], dtype=np.float64), (n, 1))
+    d0 = meta["sliders"][str(min(int(k) for k in meta["sliders"]))]
+    with zabatch.Engine("DPT", n) as e:
+        e.set_sliders(rows); e.prepare()
+        e.process_host(x[:, :, :frames], block=256)
+        rows[1, min(int(k) for k in meta["sliders"])] = d0["min"] + 0.5 * (d0["max"] - d0["min"])
+        e.set_sliders(rows)                       # dirty, not yet applied
+        ck = e.checkpoint()
+        want = e.process_host(x[:, :, frames:], block=256)
+    with zabatch.Engine("DPT", n) as e2:
+        e2.restore(ck)
+        assert np.array_equal(e2.process_host(x[:, :, frames:], block=256), want)

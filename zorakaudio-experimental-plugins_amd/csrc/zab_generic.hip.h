@@ -186,6 +186,7 @@ __device__ __forceinline__ void za_process_body(const ZabBatch& b, const ZabAudi
   const bool active = lane < ipw && inst < b.n_inst;
 #endif
   SS s;
+  uint64_t pend_seen = 0;           // slider masks the script raised in any block of this launch (host: consumeDspSliderChanges)
   if (active) {
     za_state_load(s, b, inst);
     s.replica = primary ? 0u : 1u;
@@ -266,7 +267,10 @@ __device__ __forceinline__ void za_process_body(const ZabBatch& b, const ZabAudi
       za_wave_sync();
     }
 #endif
-    if (active) s.pend_change = s.pend_automate = s.pend_automate_end = 0;   // consumeDspSliderChanges (:3745)
+    if (active) {                   // consumeDspSliderChanges (:3745): the host mirror collects them after the launch
+      pend_seen |= s.pend_change | s.pend_automate | s.pend_automate_end;
+      s.pend_change = s.pend_automate = s.pend_automate_end = 0;
+    }
   }
 #if ZA_USES_LMEM
   if (SS::kLm && active && primary) {   // write the stored part of the window back (words at or above mem_high never changed)
@@ -274,7 +278,10 @@ __device__ __forceinline__ void za_process_body(const ZabBatch& b, const ZabAudi
     for (int64_t a = 0; a < top; ++a) s.mem[a * s.mem_stride] = za_lmem[(uint32_t)a * s.lm_stride + s.lm_off];
   }
 #endif
-  if (active && primary) za_state_store(s, b, inst);
+  if (active && primary) {
+    za_state_store(s, b, inst);
+    if (pend_seen) b.pend[3 * (int64_t)b.n_pad + inst] |= pend_seen;
+  }
 }
 
 extern "C" __global__ void __launch_bounds__(64) ZA_KERNEL(process)(ZabBatch b, ZabAudio a) {

@@ -6,7 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define ZAB_MODULE_ABI 12
+#define ZAB_MODULE_ABI 13
 
 enum { ZAB_FLAG_SLIDER_DIRTY = 1u, ZAB_FLAG_PREPARED = 2u };
 
@@ -28,7 +28,8 @@ struct ZabBatch {
   int64_t* mem_need;                           // capacity wanted      [n_pad]
   uint32_t* err;                               // ZA_ERR_* bits        [n_pad]
   uint32_t* flags;                             // ZAB_FLAG_*           [n_pad]
-  uint64_t* pend;                              // pendingSlider{Change,Automate,AutomateEnd}Mask  [3][n_pad]
+  uint64_t* pend;                              // pendingSlider{Change,Automate,AutomateEnd}Mask  [3][n_pad], then [n_pad]:
+                                               // their OR over the blocks since the host last consumed it
   uint64_t* vis_mask;                          // sliderVisibleMask    [n_pad]
   int32_t* vis_init;                           // sliderVisibilityInit [n_pad]
   double srate;

@@ -76,6 +76,12 @@ __global__ void zab_k_scatter(T* base, int64_t se, int64_t n, const T* staging) 
   if (k < n) base[k * se] = staging[k];
 }
 
+template <class T>
+__global__ void zab_k_fill(T* base, int64_t se, int64_t n, T v) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) base[k * se] = v;
+}
+
 }  // namespace
 
 // mirrors ZaFileSlot / ZaFileView of csrc/zart_file.h (the runtime does not include the device headers)
@@ -108,6 +114,9 @@ struct zab_engine {
   int ipw0 = 64;             // instances per wavefront by policy; the LDS window may thin the waves further
   int launches = 0;
   bool used_fast = false;
+  std::string kernel_name;              // of the most recent zab_process (copied: modules format theirs into a shared buffer)
+  std::vector<double> last_pushed;      // [n_inst][64] slider values as the host pushed them last (reference: lastSliders)
+  std::vector<uint8_t> pushed_valid;    // [n_inst]
   std::vector<void*> owned;
   unsigned long long *gmem_cells = nullptr, *gmem_page_seq = nullptr, *gmem_global_seq = nullptr;
   uint64_t gmem_cell_count = 0;
@@ -323,7 +332,7 @@ int zab_create(const char* module, const zab_config* cfg, zab_engine** out) {
       (rc = e->alloc(&b.mt, (size_t)P * 624)) || (rc = e->alloc(&b.mti, (size_t)P)) ||
       (rc = e->alloc(&b.mem_high, (size_t)P)) || (rc = e->alloc(&b.mem_need, (size_t)P)) ||
       (rc = e->alloc(&b.err, (size_t)P)) || (rc = e->alloc(&b.flags, (size_t)P)) ||
-      (rc = e->alloc(&b.pend, (size_t)P * 3)) || (rc = e->alloc(&b.vis_mask, (size_t)P)) ||
+      (rc = e->alloc(&b.pend, (size_t)P * 4)) ||      /* change / automate / automate-end, + their OR since the host last looked */ (rc = e->alloc(&b.vis_mask, (size_t)P)) ||
       (rc = e->alloc(&b.vis_init, (size_t)P)) ||
       (m->fft_scratch_doubles > 0 && (rc = e->alloc(&b.fft, (size_t)P * m->fft_scratch_doubles))) ||
       (m->uses_gmem && (rc = setup_gmem(e))) ||
@@ -402,31 +411,29 @@ int zab_set_sliders(zab_engine* e, int32_t first, int32_t count, const double* v
   if (!bcast && !range_ok(e, first, count)) return fail(ZAB_E_ARG, "zab_set_sliders: range [%d,+%d) outside batch", first, count);
   const ZabBatch& b = e->b;
   const int lo = bcast ? 0 : first, n = bcast ? b.n_inst : count;
+  HIP_TRY(hipSetDevice(e->cfg.device));
   HIP_TRY(hipStreamSynchronize(e->stream));
-  // stage as the device layout of the touched range; dirty flags only where a value actually changed
-  std::vector<double> cur((size_t)n * 64);
+  if (e->last_pushed.empty()) { e->last_pushed.assign((size_t)b.n_inst * 64, 0.0); e->pushed_valid.assign((size_t)b.n_inst, 0); }
+  // pushParamsToStateSliders (:9286-9357): the host's values always land in st.sliders[]; "changed" compares them with what
+  // the host pushed last time, not with what a script may have written there since
+  std::vector<double> stage((size_t)n * 64);
   std::vector<uint32_t> flags((size_t)n);
   HIP_TRY(hipMemcpy(flags.data(), b.flags + lo, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
-  if (b.instance_major) {
-    HIP_TRY(hipMemcpy(cur.data(), b.sliders + (size_t)lo * 64, sizeof(double) * 64 * n, hipMemcpyDeviceToHost));
-    for (int i = 0; i < n; ++i) {
-      const double* src = values + (bcast ? 0 : (size_t)i * 64);
-      if (memcmp(&cur[(size_t)i * 64], src, 64 * sizeof(double))) { memcpy(&cur[(size_t)i * 64], src, 64 * sizeof(double)); flags[i] |= ZAB_FLAG_SLIDER_DIRTY; }
+  for (int i = 0; i < n; ++i) {
+    const double* src = values + (bcast ? 0 : (size_t)i * 64);
+    double* last = &e->last_pushed[(size_t)(lo + i) * 64];
+    if (!e->pushed_valid[(size_t)(lo + i)] || memcmp(last, src, 64 * sizeof(double))) {
+      memcpy(last, src, 64 * sizeof(double));
+      e->pushed_valid[(size_t)(lo + i)] = 1;
+      flags[(size_t)i] |= ZAB_FLAG_SLIDER_DIRTY;
     }
-    HIP_TRY(hipMemcpy(b.sliders + (size_t)lo * 64, cur.data(), sizeof(double) * 64 * n, hipMemcpyHostToDevice));
-  } else {
-    HIP_TRY(hipMemcpy2D(cur.data(), sizeof(double) * n, b.sliders + lo, sizeof(double) * b.n_pad, sizeof(double) * n, 64, hipMemcpyDeviceToHost));
-    for (int i = 0; i < n; ++i) {
-      const double* src = values + (bcast ? 0 : (size_t)i * 64);
-      bool ch = false;
-      for (int k = 0; k < 64; ++k) {
-        double& d = cur[(size_t)k * n + i];
-        if (memcmp(&d, &src[k], sizeof(double))) { d = src[k]; ch = true; }
-      }
-      if (ch) flags[i] |= ZAB_FLAG_SLIDER_DIRTY;
-    }
-    HIP_TRY(hipMemcpy2D(b.sliders + lo, sizeof(double) * b.n_pad, cur.data(), sizeof(double) * n, sizeof(double) * n, 64, hipMemcpyHostToDevice));
+    if (b.instance_major) memcpy(&stage[(size_t)i * 64], src, 64 * sizeof(double));
+    else for (int k = 0; k < 64; ++k) stage[(size_t)k * n + i] = src[k];
   }
+  if (b.instance_major)
+    HIP_TRY(hipMemcpy(b.sliders + (size_t)lo * 64, stage.data(), sizeof(double) * 64 * n, hipMemcpyHostToDevice));
+  else
+    HIP_TRY(hipMemcpy2D(b.sliders + lo, sizeof(double) * b.n_pad, stage.data(), sizeof(double) * n, sizeof(double) * n, 64, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(b.flags + lo, flags.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
   for (uint32_t f : flags) if (f & ZAB_FLAG_SLIDER_DIRTY) e->sliders_dirty = true;
   e->b.epoch++;
@@ -454,6 +461,30 @@ static int read_strided(zab_engine* e, const double* base, int64_t se, int64_t s
 int zab_get_sliders(zab_engine* e, int32_t first, int32_t count, double* values) {
   if (!e || !values || !range_ok(e, first, count)) return fail(ZAB_E_ARG, "zab_get_sliders: bad argument");
   return read_strided(e, e->b.sliders, e->b.sl_se, e->b.sl_si, first, count, 0, 64, values);
+}
+
+int zab_consume_slider_changes(zab_engine* e, int32_t first, int32_t count, uint64_t* masks, double* values) {
+  if (!e || !range_ok(e, first, count)) return fail(ZAB_E_ARG, "zab_consume_slider_changes: bad argument");
+  if (count == 0) return ZAB_OK;
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  const ZabBatch& b = e->b;
+  std::vector<uint64_t> m((size_t)count);
+  uint64_t* sticky = b.pend + 3 * (int64_t)b.n_pad + first;
+  HIP_TRY(hipMemcpy(m.data(), sticky, sizeof(uint64_t) * count, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemset(sticky, 0, sizeof(uint64_t) * count));
+  bool any = false;
+  for (uint64_t v : m) any = any || v != 0;
+  std::vector<double> rows;
+  double* dst = values;
+  if (!dst && any) { rows.resize((size_t)count * 64); dst = rows.data(); }
+  if (dst) { const int rc = read_strided(e, b.sliders, b.sl_se, b.sl_si, first, count, 0, 64, dst); if (rc) return rc; }
+  if (any && !e->last_pushed.empty())
+    for (int i = 0; i < count; ++i)
+      for (int k = 0; k < 64; ++k)
+        if (m[(size_t)i] >> k & 1ull) e->last_pushed[(size_t)(first + i) * 64 + k] = dst[(size_t)i * 64 + k];
+  if (masks) memcpy(masks, m.data(), sizeof(uint64_t) * count);
+  return ZAB_OK;
 }
 
 static int check_device_errors(zab_engine* e, const char* where) {
@@ -672,6 +703,7 @@ int zab_process(zab_engine* e, const void* in, void* out, int64_t frames, int64_
   HIP_TRY(hipEventRecord(e->ev1[slot], e->stream));
   e->n_process++;
   e->timing_valid = true; e->used_fast = fast;
+  { const char* kn = fast ? e->mod->fast_kernel_name : e->mod->generic_kernel_name; e->kernel_name = kn ? kn : ""; }
   if (placement == ZAB_BUF_HOST) {
     if (pipelined) {
       HIP_TRY(hipStreamSynchronize(e->s_out));
@@ -926,9 +958,36 @@ int zab_state_upload(zab_engine* e, int32_t inst, const zab_host_state* h) {
   if ((rc = put_strided(e, "spl", b.spl + inst * b.sl_si, b.sl_se, 64, h->spl))) return rc;
   if ((rc = put_strided(e, "sliders", b.sliders + inst * b.sl_si, b.sl_se, 64, h->sliders))) return rc;
   if ((rc = put_strided(e, "vars", b.vars + inst * b.var_si, b.var_se, e->mod->nvars, h->vars))) return rc;
+  if (h->sliders) {                 // the host's state object is what it pushed last
+    if (e->last_pushed.empty()) { e->last_pushed.assign((size_t)b.n_inst * 64, 0.0); e->pushed_valid.assign((size_t)b.n_inst, 0); }
+    memcpy(&e->last_pushed[(size_t)inst * 64], h->sliders, 64 * sizeof(double));
+    e->pushed_valid[(size_t)inst] = 1;
+  }
   if (h->mem) {
-    const int64_t n = h->mem_n < b.mem_cap ? h->mem_n : b.mem_cap;
+    const int64_t n = h->mem_n < b.mem_cap ? (h->mem_n > 0 ? h->mem_n : 0) : b.mem_cap;
     if ((rc = put_strided(e, "mem", b.mem + inst * b.mem_si, b.mem_se, n, h->mem))) return rc;
+    // The host image ends at n: cells above it that an earlier run of this instance stored to must read as zeros again
+    // (cells at or above the instance's high-water mark never left their zero state).
+    int64_t old_high = 0;
+    HIP_TRY(hipMemcpyAsync(&old_high, b.mem_high + inst, 8, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (old_high > b.mem_cap) old_high = b.mem_cap;
+    if (old_high > n) {
+      const int64_t cnt = old_high - n;
+      hipLaunchKernelGGL(zab_k_fill<double>, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, e->stream,
+                         b.mem + inst * b.mem_si + n * b.mem_se, b.mem_se, cnt, 0.0);
+      HIP_TRY(hipGetLastError());
+    }
+    int64_t high = h->mem_high ? *h->mem_high : n;
+    if (high < 0) high = 0;
+    HIP_TRY(hipMemcpyAsync(b.mem_high + inst, &high, 8, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));       // `high` leaves scope
+  }
+  if (h->flags) {
+    const uint32_t f = *h->flags;
+    HIP_TRY(hipMemcpyAsync(b.flags + inst, &f, 4, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (f & ZAB_FLAG_SLIDER_DIRTY) e->sliders_dirty = true;
   }
   if (h->pending_masks) {
     for (int k = 0; k < 3; ++k) HIP_TRY(hipMemcpyAsync(b.pend + (int64_t)k * b.n_pad + inst, h->pending_masks + k, 8, hipMemcpyHostToDevice, e->stream));
@@ -964,6 +1023,8 @@ int zab_state_download(zab_engine* e, int32_t inst, zab_host_state* h) {
   if (h->rand_index) HIP_TRY(hipMemcpy(h->rand_index, b.mti + inst, 4, hipMemcpyDeviceToHost));
   if (h->slider_visible_mask) HIP_TRY(hipMemcpy(h->slider_visible_mask, b.vis_mask + inst, 8, hipMemcpyDeviceToHost));
   if (h->slider_visibility_init) HIP_TRY(hipMemcpy(h->slider_visibility_init, b.vis_init + inst, 4, hipMemcpyDeviceToHost));
+  if (h->mem_high) HIP_TRY(hipMemcpy(h->mem_high, b.mem_high + inst, 8, hipMemcpyDeviceToHost));
+  if (h->flags) HIP_TRY(hipMemcpy(h->flags, b.flags + inst, 4, hipMemcpyDeviceToHost));
   return ZAB_OK;
 }
 
@@ -997,9 +1058,7 @@ int zab_launch_shape(zab_engine* e, int32_t* instances_per_wave, int32_t* lds_me
   return ZAB_OK;
 }
 const char* zab_last_kernel_name(zab_engine* e) {
-  if (!e) return "";
-  const char* n = e->used_fast ? e->mod->fast_kernel_name : e->mod->generic_kernel_name;
-  return n ? n : "";
+  return e ? e->kernel_name.c_str() : "";
 }
 
 }  // extern "C"

@@ -260,7 +260,9 @@ template <class S> ZA_NOINLINE void za_msg_begin_block(S& s) {
 #define ZA_MSG_LANE() ((uint32_t)threadIdx.x)
 #define ZA_MSG_LANES 64u
 #define ZA_MSG_ANY(p) (__ballot(p) != 0ull)
+#define ZA_MSG_CONVERGE() __builtin_amdgcn_wave_barrier()
 #else
+#define ZA_MSG_CONVERGE() ((void)0)
 #define ZA_MSG_LANE() 0u
 #define ZA_MSG_LANES 1u
 #define ZA_MSG_ANY(p) (p)
@@ -283,24 +285,28 @@ ZA_FN void za_msg_flush_all(const ZaBusView* B) {
           has_target = ZA_MSG_ANY(mine);
         }
       }
-      if (lane != 0) continue;
-      if (!has_target) {                                 // dropped[channel]++ on the sender
-        const int64_t base = (int64_t)i * ZA_MSG_CHANNELS;
-        int slot = -1, free_k = -1;
-        for (int c = 0; c < ZA_MSG_CHANNELS; ++c) {
-          const uint32_t f = B->ch_flags[base + c];
-          if (!(f & 4u)) { free_k = c; break; }
-          if (B->ch_hash[base + c] == in.chan) { slot = c; break; }
+      // Lane 0 alone does the bookkeeping, inside an `if` (no `continue`): every lane reaches the next trip's ballot together,
+      // and the wave barrier keeps the compiler from scheduling a later ballot across the divergent region.
+      if (lane == 0) {
+        if (!has_target) {                               // dropped[channel]++ on the sender
+          const int64_t base = (int64_t)i * ZA_MSG_CHANNELS;
+          int slot = -1, free_k = -1;
+          for (int c = 0; c < ZA_MSG_CHANNELS; ++c) {
+            const uint32_t f = B->ch_flags[base + c];
+            if (!(f & 4u)) { free_k = c; break; }
+            if (B->ch_hash[base + c] == in.chan) { slot = c; break; }
+          }
+          if (slot < 0 && free_k >= 0) { slot = free_k; B->ch_hash[base + slot] = in.chan; B->ch_flags[base + slot] = 4u; B->ch_caps[base + slot] = 0; B->ch_dropped[base + slot] = 0; }
+          if (slot >= 0) B->ch_dropped[base + slot] += 1u;
+        } else {
+          const uint64_t seq = ++*B->global_seq;
+          ZaMsg out = in;
+          out.seq = seq; out.src = me; out.pad = 0;
+          if (!in.pad) out.target = 0;
+          B->ring[seq % ZA_MSG_RING] = out;
         }
-        if (slot < 0 && free_k >= 0) { slot = free_k; B->ch_hash[base + slot] = in.chan; B->ch_flags[base + slot] = 4u; B->ch_caps[base + slot] = 0; B->ch_dropped[base + slot] = 0; }
-        if (slot >= 0) B->ch_dropped[base + slot] += 1u;
-        continue;
       }
-      const uint64_t seq = ++*B->global_seq;
-      ZaMsg out = in;
-      out.seq = seq; out.src = me; out.pad = 0;
-      if (!in.pad) out.target = 0;
-      B->ring[seq % ZA_MSG_RING] = out;
+      ZA_MSG_CONVERGE();
     }
     if (lane == 0) B->out_count[i] = 0;
   }

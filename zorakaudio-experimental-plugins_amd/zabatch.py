@@ -36,7 +36,8 @@ class zab_host_state(C.Structure):      # include/zabatch.h
     _fields_ = [("spl", C.POINTER(C.c_double)), ("sliders", C.POINTER(C.c_double)), ("vars", C.POINTER(C.c_double)),
                 ("mem", C.POINTER(C.c_double)), ("mem_n", C.c_int64), ("pending_masks", C.POINTER(C.c_int64)),
                 ("rand_mt", C.POINTER(C.c_uint32)), ("rand_index", C.POINTER(C.c_uint32)),
-                ("slider_visible_mask", C.POINTER(C.c_int64)), ("slider_visibility_init", C.POINTER(C.c_int32))]
+                ("slider_visible_mask", C.POINTER(C.c_int64)), ("slider_visibility_init", C.POINTER(C.c_int32)),
+                ("mem_high", C.POINTER(C.c_int64)), ("flags", C.POINTER(C.c_uint32))]
 
 
 class zab_pool_entry(C.Structure):
@@ -54,7 +55,7 @@ class zab_info(C.Structure):
 # every symbol include/zabatch.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "zab_last_error", "zab_abi_version", "zab_create", "zab_destroy", "zab_get_info", "zab_var_count", "zab_var_name",
-    "zab_var_index", "zab_set_sliders", "zab_get_sliders", "zab_prepare", "zab_process", "zab_sync", "zab_read_vars",
+    "zab_var_index", "zab_set_sliders", "zab_get_sliders", "zab_consume_slider_changes", "zab_prepare", "zab_process", "zab_sync", "zab_read_vars",
     "zab_read_mem", "zab_write_mem", "zab_read_mem_high", "zab_device_alloc", "zab_device_free", "zab_device_upload",
     "zab_device_download", "zab_device_noise", "zab_last_timing", "zab_timing_history", "zab_stream",
     "zab_used_fast_path", "zab_last_kernel_name", "zab_launch_shape", "zab_host_alloc", "zab_host_free", "zab_state_upload", "zab_state_download", "zab_run_section", "zab_gmem_read", "zab_gmem_write", "zab_gmem_seq", "zab_pool_upload", "zab_file_slot_set",
@@ -86,6 +87,7 @@ def load_runtime():
     L.zab_var_index.argtypes = [vp, C.c_char_p]
     L.zab_set_sliders.argtypes = [vp, i32, i32, C.POINTER(d)]
     L.zab_get_sliders.argtypes = [vp, i32, i32, C.POINTER(d)]
+    L.zab_consume_slider_changes.argtypes = [vp, i32, i32, C.POINTER(C.c_uint64), C.POINTER(d)]
     L.zab_prepare.argtypes = [vp]
     L.zab_process.argtypes = [vp, vp, vp, i64, i64, i32, i32]
     L.zab_sync.argtypes = [vp]
@@ -236,6 +238,15 @@ class Engine:
         self._chk(self.L.zab_get_sliders(self.h, int(first), int(cnt), _dp(out)))
         return out
 
+    def consume_slider_changes(self, first=0, count=None):
+        """(masks [count] uint64, sliders [count, 64]): slider masks the scripts raised since the last call (cleared), and the
+        current slider values -- consumeDspSliderChanges() of the reference host."""
+        cnt = self.n - first if count is None else count
+        masks = np.zeros(cnt, dtype=np.uint64)
+        rows = np.zeros((cnt, 64))
+        self._chk(self.L.zab_consume_slider_changes(self.h, int(first), int(cnt), masks.ctypes.data_as(C.POINTER(C.c_uint64)), _dp(rows)))
+        return masks, rows
+
     def prepare(self):
         self._chk(self.L.zab_prepare(self.h))
 
@@ -375,21 +386,25 @@ class Engine:
         h.rand_mt = arrs["mt"].ctypes.data_as(P(C.c_uint32)); h.rand_index = arrs["mti"].ctypes.data_as(P(C.c_uint32))
         h.slider_visible_mask = arrs["vis"].ctypes.data_as(P(C.c_int64))
         h.slider_visibility_init = arrs["visi"].ctypes.data_as(P(C.c_int32))
+        h.mem_high = arrs["high"].ctypes.data_as(P(C.c_int64))
+        h.flags = arrs["flags"].ctypes.data_as(P(C.c_uint32))
         return h
 
     def checkpoint(self) -> dict:
         """Everything zab_process depends on, per instance, as numpy arrays: spl / sliders / vars, mem[] up to the write
-        high-water mark (sparse: untouched tails are not stored), pending slider masks, MT19937 state, visibility. The
-        shared gmem segment, sample pool and file slots belong to the host and are not part of it."""
+        high-water mark (sparse: untouched tails are not stored) and the mark itself, pending slider masks, the engine's
+        per-instance flags (sliders changed -> @slider pending), MT19937 state, visibility. The shared gmem segment, sample
+        pool and file slots belong to the host and are not part of it."""
         n, nv = self.n, max(1, self.nvars)
         high = self.mem_high()
         out = {"leaf": np.array(self.leaf), "srate": np.array(self.srate), "spl": np.zeros((n, 64)), "sliders": np.zeros((n, 64)),
                "vars": np.zeros((n, nv)), "masks": np.zeros((n, 3), np.int64), "mt": np.zeros((n, 624), np.uint32),
                "mti": np.zeros(n, np.uint32), "vis": np.zeros(n, np.int64), "visi": np.zeros(n, np.int32),
-               "mem_high": high.astype(np.int64)}
+               "mem_high": high.astype(np.int64), "flags": np.zeros(n, np.uint32), "mem_cap": np.array(self.mem_cap, np.int64)}
         mems = []
         for i in range(n):
-            a = {k: out[k][i:i + 1].reshape(-1) if out[k].ndim > 1 else out[k][i:i + 1] for k in ("spl", "sliders", "vars", "masks", "mt", "mti", "vis", "visi")}
+            a = {k: out[k][i:i + 1].reshape(-1) if out[k].ndim > 1 else out[k][i:i + 1] for k in ("spl", "sliders", "vars", "masks", "mt", "mti", "vis", "visi", "flags")}
+            a["high"] = out["mem_high"][i:i + 1]
             a["mem"] = np.zeros(int(min(high[i], self.mem_cap)))
             h = self._host_state(a)
             self._chk(self.L.zab_state_download(self.h, i, C.byref(h)))
@@ -399,12 +414,21 @@ class Engine:
         return out
 
     def restore(self, ck: dict):
-        """Load a checkpoint() into this engine (same leaf, same instance count); the next zab_process continues from it."""
+        """Load a checkpoint() into this engine (same leaf, instance count, sample rate and arena capacity), whatever the
+        engine ran before: every instance's image is replaced -- arena cells above the stored prefix read as zeros again, the
+        write high-water marks and pending-@slider flags are the checkpoint's -- and the next zab_process continues from it."""
         if str(ck["leaf"]) != self.leaf or ck["vars"].shape[0] != self.n:
             raise ZabError(-1, "checkpoint does not match this engine (leaf / instance count)")
+        if float(ck["srate"]) != self.srate:
+            raise ZabError(-1, f"checkpoint was taken at srate {float(ck['srate'])}, this engine runs at {self.srate}")
+        if "mem_cap" in ck and int(ck["mem_cap"]) != self.mem_cap:
+            raise ZabError(-1, f"checkpoint was taken with mem_cap {int(ck['mem_cap'])}, this engine has {self.mem_cap}")
         off = ck["mem_offsets"]
+        flags = ck["flags"] if "flags" in ck else np.zeros(self.n, np.uint32)
         for i in range(self.n):
             a = {k: np.ascontiguousarray(ck[k][i:i + 1].reshape(-1) if ck[k].ndim > 1 else ck[k][i:i + 1]) for k in ("spl", "sliders", "vars", "masks", "mt", "mti", "vis", "visi")}
+            a["high"] = np.ascontiguousarray(ck["mem_high"][i:i + 1], dtype=np.int64)
+            a["flags"] = np.ascontiguousarray(flags[i:i + 1], dtype=np.uint32)
             a["mem"] = np.ascontiguousarray(ck["mem_data"][off[i]:off[i + 1]])
             h = self._host_state(a)
             self._chk(self.L.zab_state_upload(self.h, i, C.byref(h)))
@@ -444,6 +468,9 @@ class JsfxBatchProcessor:
             if dcl.is_choice:
                 host = (dcl.default - dcl.vmin) / dcl.step if dcl.step > 0 else 0.0
             self.host_params[:, i] = host
+        # script-originated slider values the host has not caught up with yet (internalSliderShadow / internalSliderPendingMask)
+        self.shadow = np.zeros((self.n, 64))
+        self.shadow_pending = np.zeros(self.n, dtype=np.uint64)
         self.engine: Optional[Engine] = None
 
     def set_parameter(self, slider_index0: int, host_value, instance=None):
@@ -463,7 +490,43 @@ class JsfxBatchProcessor:
                 if hv not in uniq:
                     uniq[hv] = dcl.to_slider_value(float(hv))
                 rows[j, i] = uniq[hv]
+            bit = np.uint64(1) << np.uint64(i)
+            for j in np.flatnonzero(self.shadow_pending & bit):      # pushParamsToStateSliders (:9333-9340)
+                if self._equivalent(dcl, rows[j, i], self.shadow[j, i]):
+                    self.shadow_pending[j] &= ~bit
+                else:
+                    rows[j, i] = self.shadow[j, i]
         return rows
+
+    @staticmethod
+    def _equivalent(dcl, a: float, b: float) -> bool:
+        """sliderValuesEquivalent (src/JSFXJuceProcessor.cpp:5599-5606)."""
+        from zajit.sliders import _llround
+        if dcl.is_choice:
+            return _llround(a) == _llround(b)
+        return abs(a - b) <= max(1.0e-6, dcl.step * 0.25 if dcl.step > 0 else 1.0e-6)
+
+    def _consume_slider_changes(self):
+        """consumeDspSliderChanges (:5665-5739): sliders a script changed and announced (sliderchange / slider_automate)
+        become the host's parameter values (through the parameter's own range and step, as setValueNotifyingHost does), and
+        the raw script value stays in st.sliders[] until the host value is equivalent to it."""
+        masks, rows = self.engine.consume_slider_changes()
+        for j in np.flatnonzero(masks):
+            for i, dcl in self.decls.items():
+                if dcl.is_string or not (int(masks[j]) >> i) & 1:
+                    continue
+                v = float(rows[j, i])
+                if dcl.is_choice:
+                    step = dcl.step if dcl.step > 0 else 1.0
+                    from zajit.sliders import _llround
+                    nchoice = max(1, len(dcl.choices))
+                    host = float(min(max(_llround((v - dcl.vmin) / step), 0), nchoice - 1))
+                else:
+                    host = float(np.float32(dcl.to_slider_value(v)))       # rawForParam is a float
+                if not self._equivalent(dcl, dcl.to_slider_value(self.host_params[j, i]), v):
+                    self.host_params[j, i] = host
+                self.shadow[j, i] = v
+                self.shadow_pending[j] |= np.uint64(1) << np.uint64(i)
 
     def prepareToPlay(self, sampleRate: float, samplesPerBlockExpected: int):
         if self.engine is not None:
@@ -479,7 +542,10 @@ class JsfxBatchProcessor:
             raise ZabError(-7, "processBlock before prepareToPlay")
         self.engine.set_sliders(self._slider_rows())      # pushParamsToStateSliders(); changed rows re-run @slider
         n = buffer.shape[2]
-        return self.engine.process_host(buffer, block=max(1, min(self.block, n)) if n else self.block)
+        out = self.engine.process_host(buffer, block=max(1, min(self.block, n)) if n else self.block)
+        if self.meta.get("features") and "sliderchange" in self.meta["features"]:
+            self._consume_slider_changes()
+        return out
 
     def releaseResources(self):
         if self.engine is not None:

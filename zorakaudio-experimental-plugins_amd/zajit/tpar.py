@@ -1,0 +1,873 @@
+"""Time-parallel lowering of a leaf's @sample section: ONE WAVEFRONT PER INSTANCE, lane = frame.
+
+The generic kernels (csrc/zab_generic.hip.h) run a script the way jsfx_process_block does (dsp_jsfx_aot.py:5814-5899): one
+frame after the other, one lane per instance. Most of a dynamics / filter script is not serial in time at all, though. This
+module proves which parts are, per leaf, and emits a second kernel `zab_<leaf>_tpar` that processes 64 consecutive frames
+of one instance at once:
+
+  1. @sample (user functions inlined, conditionals if-converted) becomes a DAG over the values of ONE frame: inputs
+     spl0.., invariants (variables / sliders that @sample never writes: they change only in @slider / @init), constants,
+     and `state-in` nodes -- the value a variable written by @sample had at the end of the PREVIOUS frame.
+  2. The cross-frame edges out(v)[t-1] -> state-in(v)[t] close cycles. Strongly connected components of that graph are
+     the true recurrences; everything else is feed-forward in time and runs one lane per frame.
+       * no cycle through state-in(v) ......... v is a delayed signal: a one-lane shift of out(v) (DPP wave_shr),
+       * a cycle that is AFFINE in its states .. y[t] = A[t] y[t-1] + b[t] with A, b free of y (one-poles, leaky
+         integrators, counters, sample-and-hold `c ? y = x`, biquads as 2x2): a weighted prefix scan over the wavefront
+         with DPP row_shr / row_bcast moves (the scheme of the hand-written DDT kernel, csrc/kernels/ddt_fast.hip.h:98-108),
+       * anything else (attack/release smoothers whose coefficient depends on the state, hold counters, ...): the
+         minimal cycle runs as a uniform 64-step loop, inputs broadcast with v_readlane, independent cycles that are ready
+         at the same time share one loop (instruction-level parallelism instead of lanes).
+     In every case the component only has to deliver state-in(v) per lane; all nodes of the frame, the components' own
+     included, are then evaluated one lane per frame with the script's own expressions.
+  3. Values that depend on invariants only are computed once per launch.
+
+The state a launch leaves in vars[] / spl[] is what the serial path leaves: every variable @sample writes holds its value
+at the last frame. Affine components differ from the serial order of operations by re-association only (O(1e-16)
+relative), checked by the same reference-VM fixtures as the generic path (tests/test_tpar.py, tests/test_catalog_gpu.py).
+
+`Plan.simulate` is a numpy restatement of the staged algorithm (one array element per lane) used by the CPU tests to pin
+the analysis itself -- classification, coefficients, carries, partial chunks -- without a GPU.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import syntax as S
+from .emit import NOOP_CALLS, PURE_MATH1, PURE_MATH2, c_double
+from .program import Program, is_slider_name, is_spl_name
+
+WAVE = 64
+
+
+class Unsupported(Exception):
+    """@sample uses a construct the time-parallel lowering does not handle; the leaf keeps the generic kernel only."""
+
+
+class N:
+    __slots__ = ("i", "kind", "op", "args", "val", "name", "uniform")
+
+    def __init__(self, i, kind, op=None, args=(), val=None, name=None):
+        self.i, self.kind, self.op, self.args, self.val, self.name = i, kind, op, tuple(args), val, name
+        self.uniform = False
+
+    def __repr__(self):
+        if self.kind == "const":
+            return f"#{self.i}:{self.val!r}"
+        if self.kind in ("var", "inv", "st", "in"):
+            return f"#{self.i}:{self.kind}({self.name})"
+        return f"#{self.i}:{self.op}(" + ",".join(str(a.i) for a in self.args) + ")"
+
+
+BIN_OPS = {"+", "-", "*", "/", "<", "<=", ">", ">=", "==", "!=", "^", "|", "&", "~", "<<", ">>", "%"}
+CALL1 = set(PURE_MATH1) | {"sqr", "sign", "invsqrt"}
+CALL2 = set(PURE_MATH2) | {"min", "max"}
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# 1. one frame of @sample as a DAG
+# ----------------------------------------------------------------------------------------------------------------------
+class FrameGraph:
+    def __init__(self, prog: Program, nch: int):
+        self.p, self.nch = prog, nch
+        self.nodes: List[N] = []
+        self.memo: Dict[tuple, N] = {}
+        self.env: Dict[str, N] = {}
+        self.varnodes: Dict[str, N] = {}
+        self.written: List[str] = []
+        self.scope: List[Dict[str, str]] = []
+        self.depth = 0
+        self.ZERO, self.ONE = self.const(0.0), self.const(1.0)
+
+    # -- node construction -------------------------------------------------------------------------------------------------
+    def mk(self, kind, op=None, args=(), val=None, name=None) -> N:
+        key = (kind, op, tuple(a.i for a in args), repr(val), name)
+        n = self.memo.get(key)
+        if n is None:
+            n = N(len(self.nodes), kind, op, args, val, name)
+            self.nodes.append(n)
+            self.memo[key] = n
+        return n
+
+    def const(self, v: float) -> N:
+        return self.mk("const", val=float(v))
+
+    def op(self, op, *args) -> N:
+        return self.mk("op", op=op, args=args)
+
+    def sel(self, c: N, a: N, b: N) -> N:
+        return a if a is b else self.mk("op", op="sel", args=(c, a, b))
+
+    # -- names ------------------------------------------------------------------------------------------------------------
+    def _canon(self, name: str) -> str:
+        if self.scope and name in self.scope[-1]:
+            return self.scope[-1][name]
+        return name
+
+    def read(self, name: str) -> N:
+        key = self._canon(name)
+        if key in self.env:
+            return self.env[key]
+        if key.startswith("%"):
+            raise Unsupported(f"parameter {name} read before it was bound")
+        if key in self.varnodes:
+            return self.varnodes[key]
+        k = is_spl_name(key)
+        if k is not None:
+            if not 0 <= k < 64:
+                raise Unsupported("spl index out of range")
+            n = self.mk("in", name=key, val=k) if k < self.nch else self.mk("var", name=key)
+        elif key in ("mem", "gmem"):
+            raise Unsupported("mem/gmem used as a value")
+        elif key == "samplesblock":
+            raise Unsupported("@sample reads samplesblock (per host block)")
+        else:
+            if (is_slider_name(key) is None and key not in ("srate", "midi_bus", "ext_midi_bus") and key not in self.p.vars):
+                raise Unsupported(f"unknown variable {key}")
+            n = self.mk("var", name=key)
+        self.varnodes[key] = n
+        return n
+
+    def write(self, name: str, node: N):
+        key = self._canon(name)
+        if not key.startswith("%"):
+            if is_slider_name(key) is not None:
+                raise Unsupported("@sample writes a slider")
+            if key in ("srate", "samplesblock", "mem", "gmem", "midi_bus", "ext_midi_bus"):
+                raise Unsupported(f"@sample writes {key}")
+            k = is_spl_name(key)
+            if k is not None and not 0 <= k < 64:
+                raise Unsupported("spl index out of range")
+            if k is None and key not in self.p.vars:
+                raise Unsupported(f"unknown variable {key}")
+            if key not in self.written:
+                self.written.append(key)
+        self.env[key] = node
+
+    # -- evaluation in the reference emitter's order (dsp_jsfx_aot.py:4263-5590; zajit/emit.py) -------------------------------
+    def ev(self, n) -> N:
+        return getattr(self, "v_" + type(n).__name__)(n)
+
+    def v_Num(self, n):
+        return self.const(n.value)
+
+    def v_Str(self, n):
+        raise Unsupported("string literal in @sample")
+
+    def v_Var(self, n):
+        nm = n.name
+        if not (self.scope and nm in self.scope[-1]):
+            if nm == "$pi":
+                return self.const(math.pi)
+            if nm == "$phi":
+                return self.const((1.0 + math.sqrt(5.0)) * 0.5)
+            if nm == "$e":
+                return self.const(math.e)
+            if nm.startswith("$x") and len(nm) > 2:
+                try:
+                    return self.const(float(int(nm[2:], 16)))
+                except ValueError:
+                    pass
+            if nm == "mem":
+                return self.ZERO
+        return self.read(nm)
+
+    def v_Index(self, n):
+        raise Unsupported("mem[] / gmem[] access in @sample")
+
+    def v_Loop(self, n):
+        raise Unsupported("loop() in @sample")
+
+    def v_While(self, n):
+        raise Unsupported("while in @sample")
+
+    def v_FuncDef(self, n):
+        raise Unsupported("nested function definition")
+
+    def v_Unary(self, n):
+        a = self.ev(n.a)
+        if n.op == "+":
+            return a
+        if n.op == "-":
+            return self.op("neg", a)
+        if n.op == "!":
+            return self.op("not", a)
+        raise Unsupported(f"unary {n.op}")
+
+    def v_Binary(self, n):
+        if n.op in ("&&", "||"):
+            l = self.ev(n.l)
+            env0 = self.env
+            self.env = dict(env0)
+            r = self.ev(n.r)
+            env_r = self.env
+            if all(env_r.get(k) is v for k, v in env0.items()) and len(env_r) == len(env0):
+                self.env = env0                      # right operand has no effects: both sides evaluated, plain logic
+                return self.op("land" if n.op == "&&" else "lor", l, r)
+            # short circuit with effects on the right: they happen iff the left operand lets the right one run
+            rb = self.op("truth", r)
+            if n.op == "&&":
+                self.env = self._merge(l, env_r, env0, env0)
+                return self.sel(l, rb, self.ZERO)
+            self.env = self._merge(l, env0, env_r, env0)
+            return self.sel(l, self.ONE, rb)
+        if n.op not in BIN_OPS:
+            raise Unsupported(f"binary {n.op}")
+        l = self.ev(n.l)
+        r = self.ev(n.r)
+        return self.op(n.op, l, r)
+
+    def _lookup_incoming(self, key: str, env0) -> N:
+        if key in env0:
+            return env0[key]
+        if key.startswith("%"):
+            return self.ZERO
+        save, self.env = self.env, env0
+        try:
+            return self.read(key)
+        finally:
+            self.env = save
+
+    def _merge(self, c: N, env_t, env_e, env0) -> Dict[str, N]:
+        out = dict(env0)
+        for key in list(env_t.keys()) + [k for k in env_e if k not in env_t]:
+            a = env_t[key] if key in env_t else self._lookup_incoming(key, env0)
+            b = env_e[key] if key in env_e else self._lookup_incoming(key, env0)
+            out[key] = self.sel(c, a, b)
+        return out
+
+    def _branch(self, cond_ast, then_ast, else_ast) -> Tuple[N, N]:
+        c = self.ev(cond_ast)
+        env0 = self.env
+        scope_keys = None
+        self.env = dict(env0)
+        vt = self.ev(then_ast) if then_ast is not None else self.ZERO
+        env_t = self.env
+        self.env = dict(env0)
+        ve = self.ev(else_ast) if else_ast is not None else self.ZERO
+        env_e = self.env
+        self.env = self._merge(c, env_t, env_e, env0)
+        return c, self.sel(c, vt, ve)
+
+    def v_Cond(self, n):
+        return self._branch(n.cond, n.then, n.els)[1]
+
+    def v_If(self, n):
+        self._branch(n.cond, n.then, n.els)
+        return self.ZERO
+
+    def v_Seq(self, n):
+        v = self.ZERO
+        for it in n.items:
+            v = self.ev(it)
+        if n.items and isinstance(n.items[-1], (S.If, S.While)):
+            return self.ZERO
+        return v
+
+    def v_Assign(self, n):
+        tgt = n.target
+        rhs = self.ev(n.value)
+        if not isinstance(tgt, S.Var):
+            raise Unsupported("assignment to mem[] / slider() / spl() in @sample")
+        if n.op == "=":
+            val = rhs
+        else:
+            bop = n.op[:-1]
+            if bop not in BIN_OPS:
+                raise Unsupported(f"assignment operator {n.op}")
+            val = self.op(bop, self.read(tgt.name), rhs)
+        self.write(tgt.name, val)
+        return val
+
+    def v_Call(self, n):
+        fn = n.fn
+        if fn in self.p.fns:
+            f = self.p.fns[fn]
+            if len(n.args) != len(f.params):
+                raise Unsupported(f"{fn}: arity")
+            if self.depth > 32:
+                raise Unsupported("call depth")
+            args = [self.ev(a) for a in n.args]
+            self.depth += 1
+            frame = {p: f"%{self.depth}_{len(self.scope)}_{p}" for p in f.params}
+            self.scope.append(frame)
+            for p, a in zip(f.params, args):
+                self.env[frame[p]] = a
+            v = self.ev(f.body)
+            self.scope.pop()
+            for k in frame.values():
+                self.env.pop(k, None)
+            self.depth -= 1
+            return v
+        if fn.startswith("gfx_") or fn in NOOP_CALLS:
+            for a in n.args:
+                self.ev(a)
+            return self.ZERO
+        if fn == "abs":
+            fn = "fabs"
+        if fn in CALL1:
+            if len(n.args) != 1:
+                raise Unsupported(f"{fn}: arity")
+            return self.op(fn, self.ev(n.args[0]))
+        if fn in CALL2:
+            if len(n.args) != 2:
+                raise Unsupported(f"{fn}: arity")
+            a = self.ev(n.args[0])
+            b = self.ev(n.args[1])
+            return self.op(fn, a, b)
+        if fn == "__memtop" and not n.args:
+            return self.const(float(self.p.memtop))
+        raise Unsupported(f"builtin {fn} in @sample")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# 2. analysis: recurrences, affine forms, schedule
+# ----------------------------------------------------------------------------------------------------------------------
+class Component:
+    """One recurrence: the state variables whose state-in nodes lie on a common cycle."""
+
+    def __init__(self, names, members):
+        self.names: List[str] = names            # state variables, order = order of first write in the frame
+        self.members: List[N] = members          # nodes on the cycle(s), topological order within the frame
+        self.kind = "serial"                     # "scan" when affine with at most 2 states
+        self.A: List[List[N]] = []               # scan: y[t] = A y[t-1] + b  (nodes free of the component's states)
+        self.b: List[N] = []
+        self.ext: List[N] = []                   # non-member operands of the members (varying ones are broadcast per step)
+
+
+class Plan:
+    def __init__(self):
+        self.g: FrameGraph = None
+        self.nch = 0
+        self.outs: Dict[str, N] = {}             # variable (or splK) -> node holding its value at the end of a frame
+        self.spl_out: List[N] = []               # per processed channel
+        self.st: Dict[str, N] = {}               # state variable -> its state-in node
+        self.items: List[tuple] = []             # schedule of one chunk
+        self.uniform: List[N] = []               # per-launch nodes, topological order
+        self.invariants: List[N] = []
+        self.inputs: List[N] = []
+        self.stats: Dict[str, int] = {}
+
+    # ------------------------------------------------------------------------------------------------------------------
+    # numpy restatement of the staged algorithm (tests)
+    # ------------------------------------------------------------------------------------------------------------------
+    def simulate(self, vars0: Dict[str, float], x: np.ndarray, sliders=None, srate=48000.0, spl0=None):
+        """x: [nch, frames] float32. vars0: name -> value before the launch (missing names are 0).
+        Returns (y float32 [nch, frames], vars after {name: value}, spl after {k: value})."""
+        x = np.asarray(x, dtype=np.float32)
+        frames = x.shape[1]
+        sliders = np.zeros(64) if sliders is None else np.asarray(sliders, dtype=np.float64)
+        spl_state = dict(spl0 or {})
+
+        def inv_value(name):
+            k = is_slider_name(name)
+            if k is not None:
+                return float(sliders[k - 1])
+            if name == "srate":
+                return float(srate)
+            if name in ("midi_bus", "ext_midi_bus"):
+                return 0.0
+            k = is_spl_name(name)
+            if k is not None:
+                return float(spl_state.get(k, 0.0))
+            return float(vars0.get(name, 0.0))
+
+        val: Dict[int, np.ndarray] = {}
+        with np.errstate(all="ignore"):
+            for n in self.uniform:
+                if n.kind == "const":
+                    val[n.i] = np.float64(n.val)
+                elif n.kind == "inv":
+                    val[n.i] = np.float64(inv_value(n.name))
+                else:
+                    val[n.i] = _np_op(n.op, [val[a.i] for a in n.args])
+            carry = {name: np.float64(inv_value(name)) for name in self.st}
+            y = np.zeros_like(x)
+            final_vals: Dict[int, float] = {}
+            lane = np.arange(WAVE)
+            for f0 in range(0, max(frames, 0), WAVE):
+                tn = min(WAVE, frames - f0)
+                last = tn - 1
+                for n in self.inputs:
+                    col = np.zeros(WAVE)
+                    col[:tn] = x[int(n.val), f0:f0 + tn].astype(np.float64)
+                    val[n.i] = col
+                for it in self.items:
+                    kind = it[0]
+                    if kind == "par":
+                        n = it[1]
+                        val[n.i] = np.broadcast_to(_np_op(n.op, [val[a.i] for a in n.args]), (WAVE,)).astype(np.float64)
+                    elif kind == "shift":
+                        name = it[1]
+                        src = np.broadcast_to(val[self.outs[name].i], (WAVE,))
+                        sh = np.empty(WAVE)
+                        sh[0] = carry[name]
+                        sh[1:] = src[:-1]
+                        val[self.st[name].i] = sh
+                    elif kind == "scan":
+                        comp: Component = it[1]
+                        d = len(comp.names)
+                        A = np.stack([np.stack([np.broadcast_to(val[comp.A[r][c].i], (WAVE,)) for c in range(d)]) for r in range(d)])
+                        b = np.stack([np.broadcast_to(val[comp.b[r].i], (WAVE,)) for r in range(d)])
+                        A, b = A.astype(np.float64).copy(), b.astype(np.float64).copy()          # [d,d,64], [d,64]
+                        s = 1
+                        while s < WAVE:                   # Kogge-Stone, element = map y -> A y + b; (cur o earlier)
+                            A2, b2 = A.copy(), b.copy()
+                            for t in range(s, WAVE):
+                                A2[:, :, t] = A[:, :, t] @ A[:, :, t - s]
+                                b2[:, t] = A[:, :, t] @ b[:, t - s] + b[:, t]
+                            A, b = A2, b2
+                            s *= 2
+                        c0 = np.array([carry[nm] for nm in comp.names])
+                        yinc = np.einsum("rct,c->rt", A, c0) + b         # state after frame t
+                        for r, nm in enumerate(comp.names):
+                            sh = np.empty(WAVE)
+                            sh[0] = carry[nm]
+                            sh[1:] = yinc[r, :-1]
+                            val[self.st[nm].i] = sh
+                    elif kind == "serial":
+                        comps: List[Component] = it[1]
+                        for comp in comps:
+                            cur = {nm: carry[nm] for nm in comp.names}
+                            caps = {nm: np.zeros(WAVE) for nm in comp.names}
+                            for t in range(tn):
+                                loc: Dict[int, np.float64] = {}
+                                for nm in comp.names:
+                                    caps[nm][t] = cur[nm]
+                                    loc[self.st[nm].i] = cur[nm]
+                                for m in comp.members:
+                                    if m.kind == "st":
+                                        continue
+                                    ops = []
+                                    for a in m.args:
+                                        if a.i in loc:
+                                            ops.append(loc[a.i])
+                                        else:
+                                            v = val[a.i]
+                                            ops.append(v if np.ndim(v) == 0 else v[t])
+                                    loc[m.i] = np.float64(_np_op(m.op, ops))
+                                for nm in comp.names:
+                                    o = self.outs[nm]
+                                    cur[nm] = loc[o.i] if o.i in loc else (val[o.i] if np.ndim(val[o.i]) == 0 else val[o.i][t])
+                            for nm in comp.names:
+                                caps[nm][tn:] = cur[nm]
+                                val[self.st[nm].i] = caps[nm]
+                    else:
+                        raise AssertionError(kind)
+                for ch in range(self.nch):
+                    v = np.broadcast_to(val[self.spl_out[ch].i], (WAVE,))
+                    y[ch, f0:f0 + tn] = v[:tn].astype(np.float32)
+                for name in self.st:
+                    v = val[self.outs[name].i]
+                    carry[name] = np.float64(v if np.ndim(v) == 0 else v[last])
+                if f0 + WAVE >= frames:
+                    for name, o in list(self.outs.items()) + [(f"spl{ch}", self.spl_out[ch]) for ch in range(self.nch)]:
+                        v = val[o.i]
+                        final_vals[name] = float(v if np.ndim(v) == 0 else v[last])
+        vars_after = dict(vars0)
+        spl_after = dict(spl_state)
+        for name, v in final_vals.items():
+            k = is_spl_name(name)
+            if k is not None:
+                spl_after[k] = v
+            else:
+                vars_after[name] = v
+        return y, vars_after, spl_after
+
+
+def _truthy(a):
+    return (a < 0.0) | (a > 0.0)
+
+
+def _i32(a):
+    """za_i32 of csrc/zart.h, element by element (tests only)."""
+    a = np.asarray(a, dtype=np.float64)
+    flat = a.reshape(-1)
+    out = np.zeros(flat.shape, dtype=np.int64)
+    for k, v in enumerate(flat):
+        w = -(1 << 63) if not (-9.2233720368547758e18 < v < 9.2233720368547758e18) else int(v)
+        w &= 0xFFFFFFFF
+        out[k] = w - (1 << 32) if w >= (1 << 31) else w
+    return out.reshape(a.shape)
+
+
+def _np_op(op, a):
+    if op == "+":
+        return a[0] + a[1]
+    if op == "-":
+        return a[0] - a[1]
+    if op == "*":
+        return a[0] * a[1]
+    if op == "/":
+        return np.divide(a[0], a[1])
+    if op == "neg":
+        return 0.0 - a[0]
+    if op == "not":
+        return np.where(a[0] == 0.0, 1.0, 0.0)
+    if op == "truth":
+        return np.where(_truthy(a[0]), 1.0, 0.0)
+    if op in ("<", "<=", ">", ">=", "=="):
+        f = {"<": np.less, "<=": np.less_equal, ">": np.greater, ">=": np.greater_equal, "==": np.equal}[op]
+        return np.where(f(a[0], a[1]), 1.0, 0.0)
+    if op == "!=":
+        return np.where((a[0] < a[1]) | (a[0] > a[1]), 1.0, 0.0)
+    if op == "land":
+        return np.where(_truthy(a[0]) & _truthy(a[1]), 1.0, 0.0)
+    if op == "lor":
+        return np.where(_truthy(a[0]) | _truthy(a[1]), 1.0, 0.0)
+    if op == "sel":
+        return np.where(_truthy(a[0]), a[1], a[2])
+    if op in ("^", "pow"):
+        return np.power(np.asarray(a[0], dtype=np.float64), a[1])
+    if op in ("|", "&", "~", "<<", ">>", "%"):
+        l, r = _i32(a[0]), _i32(a[1])
+        if op == "|":
+            v = l | r
+        elif op == "&":
+            v = l & r
+        elif op == "~":
+            v = l ^ r
+        elif op == "<<":
+            v = ((l & 0xFFFFFFFF) << (r & 31)) & 0xFFFFFFFF
+            v = np.where(v >= 2 ** 31, v - 2 ** 32, v)
+        elif op == ">>":
+            v = l >> (r & 31)
+        else:
+            bad = (r == 0) | ((l == -2 ** 31) & (r == -1))
+            rr = np.where(bad, 1, r)
+            v = np.where(bad, 0, np.fmod(l, rr))           # C remainder: sign of the dividend
+        return np.asarray(v, dtype=np.float64)
+    if op == "min":
+        return np.where(a[0] < a[1], a[0], a[1])
+    if op == "max":
+        return np.where(a[0] > a[1], a[0], a[1])
+    if op == "sqr":
+        return a[0] * a[0]
+    if op == "sign":
+        return np.where(a[0] > 0.0, 1.0, np.where(a[0] < 0.0, -1.0, 0.0))
+    if op == "invsqrt":
+        f = np.asarray(a[0], dtype=np.float64).astype(np.float32)
+        bits = np.atleast_1d(f).view(np.int32)
+        bits = (np.int32(0x5f3759df) - (bits >> 1)).astype(np.int32)
+        y0 = bits.view(np.float32).astype(np.float64).reshape(np.shape(f))
+        return y0 * (1.5 - (0.5 * a[0]) * (y0 * y0))
+    if op == "atan2":
+        return np.arctan2(a[0], a[1])
+    if op in PURE_MATH1:
+        f = {"sin": np.sin, "cos": np.cos, "sqrt": np.sqrt, "fabs": np.fabs, "floor": np.floor, "ceil": np.ceil, "asin": np.arcsin,
+             "acos": np.arccos, "atan": np.arctan, "exp": np.exp, "log": np.log, "tan": np.tan, "log10": np.log10}[op]
+        return f(np.asarray(a[0], dtype=np.float64))
+    raise AssertionError(op)
+
+
+def _sccs(n_nodes: int, succ: List[List[int]]) -> List[List[int]]:
+    """Tarjan, iterative. Returns the components in reverse topological order."""
+    index = [-1] * n_nodes
+    low = [0] * n_nodes
+    on = [False] * n_nodes
+    stack: List[int] = []
+    out: List[List[int]] = []
+    counter = 0
+    for root in range(n_nodes):
+        if index[root] != -1:
+            continue
+        work = [(root, 0)]
+        while work:
+            v, pi = work.pop()
+            if pi == 0:
+                index[v] = low[v] = counter
+                counter += 1
+                stack.append(v)
+                on[v] = True
+            recurse = False
+            for k in range(pi, len(succ[v])):
+                w = succ[v][k]
+                if index[w] == -1:
+                    work.append((v, k + 1))
+                    work.append((w, 0))
+                    recurse = True
+                    break
+                if on[w]:
+                    low[v] = min(low[v], index[w])
+            if recurse:
+                continue
+            if low[v] == index[v]:
+                comp = []
+                while True:
+                    w = stack.pop()
+                    on[w] = False
+                    comp.append(w)
+                    if w == v:
+                        break
+                out.append(comp)
+            if work:
+                u = work[-1][0]
+                low[u] = min(low[u], low[v])
+    return out
+
+
+def build_plan(prog: Program, nch: int) -> Plan:
+    """Raises Unsupported when the leaf cannot take the time-parallel kernel."""
+    if not prog.has("sample") or nch <= 0:
+        raise Unsupported("no audio @sample")
+    if prog.has("block"):
+        raise Unsupported("@block present")
+    g = FrameGraph(prog, nch)
+    for st in prog.sections["sample"]:
+        g.ev(st)
+    if g.scope:
+        raise AssertionError("scope leak")
+    plan = Plan()
+    plan.g, plan.nch = g, nch
+    written = list(g.written)
+    # variables @sample leaves as they were (x = x) are not state
+    for name in list(written):
+        vn = g.varnodes.get(name)
+        if vn is not None and g.env.get(name) is vn:
+            written.remove(name)
+    wset = set(written)
+    for name, vn in g.varnodes.items():
+        if vn.kind == "var":
+            vn.kind = "st" if name in wset else "inv"
+    plan.outs = {name: g.env[name] for name in written}
+    plan.spl_out = [g.env.get(f"spl{ch}", None) or g.read(f"spl{ch}") for ch in range(nch)]
+    plan.st = {name: vn for name, vn in g.varnodes.items() if vn.kind == "st"}
+
+    # live nodes
+    live: Dict[int, N] = {}
+    todo = list(plan.outs.values()) + list(plan.spl_out)
+    while todo:
+        n = todo.pop()
+        if n.i in live:
+            continue
+        live[n.i] = n
+        todo.extend(n.args)
+        if n.kind == "st":
+            todo.append(plan.outs[n.name])
+    order = sorted(live)                     # creation order is a topological order of the in-frame edges
+    pos = {i: k for k, i in enumerate(order)}
+    succ: List[List[int]] = [[] for _ in order]
+    for i in order:
+        n = live[i]
+        for a in n.args:
+            succ[pos[a.i]].append(pos[i])
+        if n.kind == "st":
+            succ[pos[plan.outs[n.name].i]].append(pos[i])
+    comps_raw = _sccs(len(order), succ)
+    comp_of: Dict[int, int] = {}
+    components: List[Component] = []
+    for comp in comps_raw:
+        ids = [order[k] for k in comp]
+        cyclic = len(ids) > 1 or any(pos[ids[0]] in succ[pos[ids[0]]] for _ in (0,))
+        if not cyclic:
+            continue
+        members = [live[i] for i in sorted(ids)]
+        names = [m.name for m in members if m.kind == "st"]
+        names.sort(key=lambda nm: written.index(nm))
+        c = Component(names, members)
+        for m in members:
+            comp_of[m.i] = len(components)
+        components.append(c)
+
+    # uniform (per launch) nodes
+    for i in order:
+        n = live[i]
+        if n.kind in ("const", "inv"):
+            n.uniform = True
+        elif n.kind in ("st", "in"):
+            n.uniform = False
+        else:
+            n.uniform = all(a.uniform for a in n.args) and n.i not in comp_of
+    # affine forms
+    for c in components:
+        _classify(g, plan, c, comp_of)
+    # nodes created by the affine analysis: find liveness / uniformity of the new coefficient nodes
+    extra: Dict[int, N] = {}
+    todo = [x for c in components if c.kind == "scan" for row in c.A for x in row] + [x for c in components if c.kind == "scan" for x in c.b]
+    while todo:
+        n = todo.pop()
+        if n.i in live or n.i in extra:
+            continue
+        extra[n.i] = n
+        todo.extend(n.args)
+    for i in sorted(extra):
+        n = extra[i]
+        live[i] = n
+        n.uniform = n.kind in ("const", "inv") or (n.kind == "op" and all(a.uniform for a in n.args))
+    order = sorted(live)
+
+    # ---- schedule of one chunk --------------------------------------------------------------------------------------------
+    plan.uniform = [live[i] for i in order if live[i].uniform]
+    plan.invariants = [n for n in plan.uniform if n.kind == "inv"]
+    plan.inputs = [live[i] for i in order if live[i].kind == "in"]
+    done = {n.i for n in plan.uniform} | {n.i for n in plan.inputs}
+    pending_nodes = [live[i] for i in order if i not in done]
+    comp_done = [False] * len(components)
+    items: List[tuple] = []
+
+    def comp_inputs(c: Component) -> List[N]:
+        if c.kind == "scan":
+            return [x for row in c.A for x in row] + list(c.b)
+        return c.ext
+
+    for c in components:
+        mem = {m.i for m in c.members}
+        ext, seen = [], set()
+        for m in c.members:
+            for a in m.args:
+                if a.i not in mem and a.i not in seen:
+                    seen.add(a.i)
+                    ext.append(a)
+        c.ext = ext
+
+    remaining = list(pending_nodes)
+    guard = 0
+    while remaining:
+        guard += 1
+        if guard > 10 * len(order) + 100:
+            raise AssertionError("scheduler made no progress")
+        progressed = False
+        nxt = []
+        for n in remaining:
+            if n.kind == "st":
+                ci = comp_of.get(n.i)
+                if ci is None:                              # delayed signal
+                    if plan.outs[n.name].i in done:
+                        items.append(("shift", n.name))
+                        done.add(n.i)
+                        progressed = True
+                    else:
+                        nxt.append(n)
+                elif comp_done[ci]:
+                    done.add(n.i)
+                    progressed = True
+                else:
+                    nxt.append(n)
+                continue
+            if all(a.i in done for a in n.args):
+                items.append(("par", n))
+                done.add(n.i)
+                progressed = True
+            else:
+                nxt.append(n)
+        remaining = nxt
+        # scans as soon as their coefficients exist (they are lane-parallel work too)
+        for ci, c in enumerate(components):
+            if not comp_done[ci] and c.kind == "scan" and all(x.i in done for x in comp_inputs(c)):
+                items.append(("scan", c))
+                comp_done[ci] = True
+                progressed = True
+        if progressed:
+            continue
+        # only serial recurrences can move now: every one that is ready shares one loop
+        ready = [ci for ci, c in enumerate(components) if not comp_done[ci] and c.kind == "serial" and all(x.i in done for x in c.ext)]
+        if not ready:
+            raise AssertionError("dependency cycle outside the recurrences")
+        items.append(("serial", [components[ci] for ci in ready]))
+        for ci in ready:
+            comp_done[ci] = True
+    plan.items = items
+    plan.stats = {
+        "nodes": len(order), "uniform": len(plan.uniform), "par": sum(1 for it in items if it[0] == "par"),
+        "shift": sum(1 for it in items if it[0] == "shift"),
+        "scan1": sum(1 for it in items if it[0] == "scan" and len(it[1].names) == 1),
+        "scan2": sum(1 for it in items if it[0] == "scan" and len(it[1].names) == 2),
+        "serial_loops": sum(1 for it in items if it[0] == "serial"),
+        "serial_chains": sum(len(it[1]) for it in items if it[0] == "serial"),
+        "serial_ops": sum(len([m for m in c.members if m.kind != "st"]) for it in items if it[0] == "serial" for c in it[1]),
+        "states": len(plan.st), "written": len(plan.outs),
+    }
+    return plan
+
+
+def _classify(g: FrameGraph, plan: Plan, c: Component, comp_of: Dict[int, int]):
+    """Affine in the component's own states, with coefficients that do not depend on them? -> scan."""
+    mem = {m.i for m in c.members}
+    names = c.names
+    d = len(names)
+    if d > 2:
+        return
+    memo: Dict[int, Optional[tuple]] = {}
+
+    def add(a: N, b: N) -> N:
+        if a is g.ZERO:
+            return b
+        if b is g.ZERO:
+            return a
+        return g.op("+", a, b)
+
+    def sub(a: N, b: N) -> N:
+        if b is g.ZERO:
+            return a
+        if a is g.ZERO:
+            return g.op("neg", b)
+        return g.op("-", a, b)
+
+    def mul(a: N, b: N) -> N:
+        if a is g.ZERO or b is g.ZERO:
+            return g.ZERO
+        if a is g.ONE:
+            return b
+        if b is g.ONE:
+            return a
+        return g.op("*", a, b)
+
+    def aff(n: N):
+        if n.i not in mem:
+            return ({}, n)
+        if n.i in memo:
+            return memo[n.i]
+        r = None
+        if n.kind == "st":
+            r = ({n.name: g.ONE}, g.ZERO)
+        elif n.kind == "op":
+            op = n.op
+            if op in ("+", "-"):
+                a, b = aff(n.args[0]), aff(n.args[1])
+                if a and b:
+                    f = add if op == "+" else sub
+                    co = {k: f(a[0].get(k, g.ZERO), b[0].get(k, g.ZERO)) for k in set(a[0]) | set(b[0])}
+                    r = (co, f(a[1], b[1]))
+            elif op == "neg":
+                a = aff(n.args[0])
+                if a:
+                    r = ({k: sub(g.ZERO, v) for k, v in a[0].items()}, sub(g.ZERO, a[1]))
+            elif op == "*":
+                a, b = aff(n.args[0]), aff(n.args[1])
+                if a and b:
+                    if not a[0]:
+                        r = ({k: mul(a[1], v) for k, v in b[0].items()}, mul(a[1], b[1]))
+                    elif not b[0]:
+                        r = ({k: mul(v, b[1]) for k, v in a[0].items()}, mul(a[1], b[1]))
+            elif op == "/":
+                a, b = aff(n.args[0]), aff(n.args[1])
+                if a and b and not b[0]:
+                    r = ({k: g.op("/", v, b[1]) for k, v in a[0].items()}, g.op("/", a[1], b[1]) if a[1] is not g.ZERO else g.ZERO)
+            elif op == "sel":
+                cnd = n.args[0]
+                if cnd.i not in mem:
+                    a, b = aff(n.args[1]), aff(n.args[2])
+                    if a and b:
+                        co = {k: g.sel(cnd, a[0].get(k, g.ZERO), b[0].get(k, g.ZERO)) for k in set(a[0]) | set(b[0])}
+                        r = (co, g.sel(cnd, a[1], b[1]))
+        memo[n.i] = r
+        return r
+
+    rows = []
+    for nm in names:
+        r = aff(plan.outs[nm])
+        if r is None:
+            return
+        rows.append(r)
+    c.kind = "scan"
+    c.A = [[rows[r][0].get(names[k], g.ZERO) for k in range(d)] for r in range(d)]
+    c.b = [rows[r][1] for r in range(d)]
+
+
+def try_plan(prog: Program, nch: int) -> Tuple[Optional[Plan], str]:
+    try:
+        return build_plan(prog, nch), ""
+    except Unsupported as ex:
+        return None, str(ex)
