@@ -1,0 +1,187 @@
+"""Time-parallel lowering (zajit/tpar.py): one wavefront per instance, lane = frame.
+
+CPU part (no GPU): the analysis and its staged algorithm -- classification of every recurrence, affine coefficients,
+scans, shifts, shared serial loops, chunk carries, partial chunks -- through `Plan.simulate`, a numpy restatement with one
+array element per lane, against the reference VM's golden vectors (repo-authored recurrence zoo always; the catalog leaves
+where their scripts are present, i.e. in the dev container).
+GPU part: the generated `zab_<leaf>_tpar` kernels against the same golden vectors, against the generic kernel over long
+runs, and across launch boundaries.
+"""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import AUDIO_EPS, GOLDEN, ROOT, SCALAR_EPS, assert_state_close, dbfs, golden_input, leaf_of, load_golden
+
+REF_PLUGINS = Path("/root/reference/plugins")
+FIXTURES = ROOT / "tests" / "fixtures"
+TPAR_CATALOG = ["ADS", "ATTACK", "RTT", "SaliencePush"]
+
+
+def _source(leaf):
+    if leaf.startswith("fx_"):
+        return FIXTURES / (leaf[3:] + ".jsfx")
+    hits = sorted(REF_PLUGINS.glob(f"*/{leaf}/src/*.jsfx")) if REF_PLUGINS.exists() else []
+    return hits[0] if hits else None
+
+
+def _plan(leaf):
+    from zajit import program, tpar
+    src = _source(leaf)
+    if src is None or not src.exists():
+        pytest.skip(f"script of {leaf} not present here")
+    prog = program.analyse_file(src)
+    nch = max(1, min(64, int(prog.io["process"])))
+    return tpar.build_plan(prog, nch), prog
+
+
+def test_recurrence_zoo_classification():
+    plan, _ = _plan("fx_dynkat")
+    kinds = {}
+    for it in plan.items:
+        if it[0] == "scan":
+            kinds[tuple(it[1].names)] = "scan"
+        elif it[0] == "serial":
+            for c in it[1]:
+                kinds[tuple(c.names)] = "serial"
+        elif it[0] == "shift":
+            kinds[(it[1],)] = "shift"
+    assert kinds[("xpL",)] == kinds[("xpR",)] == kinds[("lastsign",)] == "shift"               # delayed signals
+    for one in ("dcL", "dcR", "lpL", "lpR", "cnt", "flips", "heldv", "acc", "tv"):            # affine, one state
+        assert kinds[(one,)] == "scan", one
+    assert kinds[("z1", "z2")] == "scan" and kinds[("swa", "swb")] == "scan"                    # coupled affine pairs
+    for one in ("gr", "pk", "hold", "ph", "__fnlocal__sample__follow__e"):                    # state-dependent coefficients
+        assert kinds[(one,)] == "serial", one
+    assert plan.stats["serial_loops"] == 2          # five chains share two loops
+
+
+def test_unsupported_scripts_keep_the_generic_kernel_only():
+    from zajit import program, tpar
+    for fx, why in (("delaytaps", "mem"), ("slidewrite", "@block"), ("stft", "mem")):
+        plan, msg = tpar.try_plan(program.analyse_file(FIXTURES / f"{fx}.jsfx"), 2)
+        assert plan is None and why in msg, (fx, msg)
+
+
+@pytest.mark.parametrize("case", ["fx_dynkat_default", "fx_dynkat_hot"] + [f"{l}_default" for l in TPAR_CATALOG])
+def test_staged_algorithm_matches_reference_vm(case):
+    leaf = leaf_of(case)
+    plan, _ = _plan(leaf)
+    g = load_golden(case)
+    names = [str(s) for s in g["var_names"]]
+    v0 = {n: (0.0 if np.isnan(v) else float(v)) for n, v in zip(names, g["vars_prepared"])}
+    x = golden_input(g)
+    y, va, _ = plan.simulate(v0, x, sliders=g["sliders"], srate=float(g["srate"]))
+    assert np.abs(y.astype(np.float64) - g["out"]).max() <= AUDIO_EPS
+    assert_state_close(names, [va.get(n, 0.0) for n in names], g["vars"], what=f"{case} vars")
+
+
+def test_staged_algorithm_is_independent_of_launch_boundaries():
+    """Three launches of awkward lengths (chunk remainders 1, 63, 0) leave the same audio and state as one launch."""
+    plan, _ = _plan("fx_dynkat")
+    g = load_golden("fx_dynkat_default")
+    names = [str(s) for s in g["var_names"]]
+    v0 = {n: (0.0 if np.isnan(v) else float(v)) for n, v in zip(names, g["vars_prepared"])}
+    x = golden_input(g)[:, :1000]
+    y1, va1, sp1 = plan.simulate(v0, x, sliders=g["sliders"])
+    ys, va, sp = [], v0, None
+    for lo, hi in ((0, 65), (65, 65 + 447), (65 + 447, 1000)):
+        y, va, sp = plan.simulate(va, x[:, lo:hi], sliders=g["sliders"], spl0=sp)
+        ys.append(y)
+    y3 = np.concatenate(ys, axis=1)
+    assert np.abs(y3.astype(np.float64) - y1).max() <= 1e-7
+    for n in names:
+        assert abs(va.get(n, 0.0) - va1.get(n, 0.0)) <= 1e-9, n
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["fx_dynkat_default", "fx_dynkat_hot"] + [f"{l}_default" for l in TPAR_CATALOG])
+def test_tpar_kernel_matches_reference_vm(case):
+    import zabatch
+    leaf = leaf_of(case)
+    if not zabatch.module_path(leaf).exists():
+        pytest.skip(f"module for {leaf} not built")
+    assert "unsupported" not in zabatch.leaf_meta(leaf)["tpar"], zabatch.leaf_meta(leaf)["tpar"]
+    g = load_golden(case)
+    n = 5
+    x = np.repeat(golden_input(g)[None], n, axis=0)
+    res = {}
+    for label, path in (("tpar", zabatch.ZAB_PATH_FAST), ("generic", zabatch.ZAB_PATH_GENERIC)):
+        with zabatch.Engine(leaf, n, srate=float(g["srate"]), path=path) as e:
+            e.set_sliders(g["sliders"])
+            e.prepare()
+            names = e.var_names()
+            y = e.process_host(x, block=int(g["block"]))
+            assert e.used_fast_path() == (label == "tpar")
+            if label == "tpar":
+                assert e.last_kernel_name().endswith("_tpar")
+            res[label] = (y, e.read_vars())
+    for label, (y, v) in res.items():
+        err = np.abs(y.astype(np.float64) - g["out"].astype(np.float64)[None]).max()
+        print(f"{case} [{label}]: null test max {dbfs(err):.1f} dBFS")
+        assert err <= AUDIO_EPS, label
+        for i in (0, n - 1):
+            assert_state_close(names, v[i], g["vars"], what=f"{case} {label} vars[{i}]")
+    assert np.array_equal(res["tpar"][0][0], res["tpar"][0][n - 1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("leaf", ["fx_dynkat"] + TPAR_CATALOG)
+def test_tpar_kernel_tracks_generic_kernel_over_a_long_run_and_across_launches(leaf):
+    """One second of audio, distinct noise and sliders per instance: the time-parallel kernel in ragged launches (lengths with
+    chunk remainders 1, 63, 0 and a single frame) against the generic kernel in one launch -- audio within the reference's
+    1e-5, final state within 1e-8 (affine recurrences are re-associated, nothing else differs)."""
+    import zabatch
+    from zajit import noise
+    if not zabatch.module_path(leaf).exists():
+        pytest.skip(f"module for {leaf} not built")
+    meta = zabatch.leaf_meta(leaf)
+    n, frames = 6, 48000
+    nch = int(meta["nch"])
+    x = noise.white_noise(range(n), frames, channels=nch)
+    x[:, :, 20000:26000] *= 0.01                                 # a quiet stretch: gates close, holds run out
+    rows = np.tile(np.array(meta["default_sliders"], dtype=np.float64), (n, 1))
+    for k, sd in meta["sliders"].items():                        # spread every continuous slider over the instances
+        if not sd["is_choice"] and not sd["is_string"] and sd["max"] > sd["min"]:
+            k = int(k)
+            rows[:, k] = rows[:, k] + (np.arange(n) / n - 0.4) * 0.2 * (sd["max"] - sd["min"])
+            rows[:, k] = np.clip(rows[:, k], sd["min"], sd["max"])
+    with zabatch.Engine(leaf, n, path=zabatch.ZAB_PATH_GENERIC) as e:
+        e.set_sliders(rows); e.prepare()
+        want = e.process_host(x, block=512)
+        want_v = e.read_vars(); names = e.var_names()
+    cuts = [0, 1, 66, 66 + 63, 4096 + 129, 30000, frames]
+    with zabatch.Engine(leaf, n, path=zabatch.ZAB_PATH_FAST) as e:
+        e.set_sliders(rows); e.prepare()
+        got = np.concatenate([e.process_host(x[:, :, a:b], block=512) for a, b in zip(cuts[:-1], cuts[1:])], axis=2)
+        assert e.used_fast_path()
+        got_v = e.read_vars()
+    err = np.abs(got.astype(np.float64) - want.astype(np.float64)).max()
+    print(f"{leaf}: tpar vs generic over {frames} frames: {dbfs(err):.1f} dBFS")
+    assert err <= AUDIO_EPS
+    for i in range(n):
+        assert_state_close(names, got_v[i], want_v[i], what=f"{leaf} vars[{i}]")
+
+
+@pytest.mark.gpu
+def test_slider_change_between_launches_runs_at_slider_before_the_tpar_kernel():
+    import zabatch
+    from zajit import noise
+    leaf = "fx_dynkat"
+    meta = zabatch.leaf_meta(leaf)
+    n, frames = 3, 1500
+    x = noise.white_noise(range(n), 2 * frames)
+    rows = np.tile(np.array(meta["default_sliders"], dtype=np.float64), (n, 1))
+    rows2 = rows.copy(); rows2[1, 0] = 0.9; rows2[2, 4] = 4000.0
+    out = {}
+    for label, path in (("tpar", zabatch.ZAB_PATH_FAST), ("generic", zabatch.ZAB_PATH_GENERIC)):
+        with zabatch.Engine(leaf, n, path=path) as e:
+            e.set_sliders(rows); e.prepare()
+            a = e.process_host(x[:, :, :frames], block=256)
+            e.set_sliders(rows2)
+            b = e.process_host(x[:, :, frames:], block=256)
+            out[label] = (np.concatenate([a, b], axis=2), e.read_vars())
+    assert np.abs(out["tpar"][0].astype(np.float64) - out["generic"][0]).max() <= AUDIO_EPS
+    assert np.abs(out["tpar"][1] - out["generic"][1]).max() <= SCALAR_EPS
+    assert not np.array_equal(out["tpar"][0][0, :, frames:], out["tpar"][0][1, :, frames:])

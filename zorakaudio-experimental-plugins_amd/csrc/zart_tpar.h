@@ -1,0 +1,83 @@
+// zart_tpar.h -- wavefront primitives of the time-parallel kernels that zajit/tpar.py generates (one wavefront per
+// instance, lane = frame): DPP moves of doubles, prefix scans of affine maps, lane broadcast.
+//
+// A recurrence y[t] = a[t] y[t-1] + b[t] is the composition of the per-frame maps f_t(y) = a[t] y + b[t]; composition is
+// associative, so the wavefront computes all 64 prefixes f_t o ... o f_0 in six DPP steps (row_shr 1/2/4/8 inside the
+// 16-lane rows, row_bcast15 and row_bcast31 across them -- no LDS, no lane masks). Lanes without a source keep the identity
+// map (a = 1, b = 0), which is what update_dpp's `old` operand is for. The 2 x 2 form serves biquads and other coupled
+// pairs. The scheme is the one of the hand-written DDT kernel (kernels/ddt_fast.hip.h:98-108), generalised from a constant
+// pole to per-frame coefficients so that sample-and-hold (a in {0, 1}), gated integrators and smoothed coefficients scan too.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define ZT_ROW_SHR(n) (0x110 | (n))
+#define ZT_WAVE_SHR1 0x138
+#define ZT_ROW_BCAST15 0x142
+#define ZT_ROW_BCAST31 0x143
+
+__device__ __forceinline__ double zt_readlane(double v, int l) {      // l must be wave-uniform
+  int2 t = __builtin_bit_cast(int2, v);
+  t.x = __builtin_amdgcn_readlane(t.x, l);
+  t.y = __builtin_amdgcn_readlane(t.y, l);
+  return __builtin_bit_cast(double, t);
+}
+
+// lanes selected by ROWS that have a source lane under CTRL receive its value; every other lane receives `keep`
+template <int CTRL, int ROWS>
+__device__ __forceinline__ double zt_dpp(double v, double keep) {
+  int2 t = __builtin_bit_cast(int2, v);
+  const int2 k = __builtin_bit_cast(int2, keep);
+  t.x = __builtin_amdgcn_update_dpp(k.x, t.x, CTRL, ROWS, 0xF, false);
+  t.y = __builtin_amdgcn_update_dpp(k.y, t.y, CTRL, ROWS, 0xF, false);
+  return __builtin_bit_cast(double, t);
+}
+
+// value of the previous lane; lane 0 receives `first` (the value carried in from the previous chunk)
+__device__ __forceinline__ double zt_shift1(double v, double first) { return zt_dpp<ZT_WAVE_SHR1, 0xF>(v, first); }
+
+// ---- y[t] = a[t] y[t-1] + b[t]: on return (a, b) of lane t is the map from the state before the chunk to the state after
+// frame t, i.e. y[t] = a * y_in + b --------------------------------------------------------------------------------------
+#define ZT_SCAN1_STEP(CTRL, ROWS)                                \
+  {                                                              \
+    const double as_ = zt_dpp<CTRL, ROWS>(a, 1.0);               \
+    const double bs_ = zt_dpp<CTRL, ROWS>(b, 0.0);               \
+    b = __builtin_fma(a, bs_, b);                                \
+    a = a * as_;                                                 \
+  }
+__device__ __forceinline__ void zt_scan1(double& a, double& b) {
+  ZT_SCAN1_STEP(ZT_ROW_SHR(1), 0xF)
+  ZT_SCAN1_STEP(ZT_ROW_SHR(2), 0xF)
+  ZT_SCAN1_STEP(ZT_ROW_SHR(4), 0xF)
+  ZT_SCAN1_STEP(ZT_ROW_SHR(8), 0xF)
+  ZT_SCAN1_STEP(ZT_ROW_BCAST15, 0xA)
+  ZT_SCAN1_STEP(ZT_ROW_BCAST31, 0xC)
+}
+#undef ZT_SCAN1_STEP
+
+// ---- two coupled states: y[t] = A[t] y[t-1] + b[t], A = [a00 a01; a10 a11] ---------------------------------------------
+struct ZtMap2 { double a00, a01, a10, a11, b0, b1; };
+#define ZT_SCAN2_STEP(CTRL, ROWS)                                                             \
+  {                                                                                           \
+    const double s00 = zt_dpp<CTRL, ROWS>(m.a00, 1.0), s01 = zt_dpp<CTRL, ROWS>(m.a01, 0.0);   \
+    const double s10 = zt_dpp<CTRL, ROWS>(m.a10, 0.0), s11 = zt_dpp<CTRL, ROWS>(m.a11, 1.0);   \
+    const double t0 = zt_dpp<CTRL, ROWS>(m.b0, 0.0), t1 = zt_dpp<CTRL, ROWS>(m.b1, 0.0);       \
+    ZtMap2 r;                                                                                 \
+    r.a00 = __builtin_fma(m.a00, s00, m.a01 * s10);                                           \
+    r.a01 = __builtin_fma(m.a00, s01, m.a01 * s11);                                           \
+    r.a10 = __builtin_fma(m.a10, s00, m.a11 * s10);                                           \
+    r.a11 = __builtin_fma(m.a10, s01, m.a11 * s11);                                           \
+    r.b0 = __builtin_fma(m.a00, t0, __builtin_fma(m.a01, t1, m.b0));                          \
+    r.b1 = __builtin_fma(m.a10, t0, __builtin_fma(m.a11, t1, m.b1));                          \
+    m = r;                                                                                    \
+  }
+__device__ __forceinline__ void zt_scan2(ZtMap2& m) {
+  ZT_SCAN2_STEP(ZT_ROW_SHR(1), 0xF)
+  ZT_SCAN2_STEP(ZT_ROW_SHR(2), 0xF)
+  ZT_SCAN2_STEP(ZT_ROW_SHR(4), 0xF)
+  ZT_SCAN2_STEP(ZT_ROW_SHR(8), 0xF)
+  ZT_SCAN2_STEP(ZT_ROW_BCAST15, 0xA)
+  ZT_SCAN2_STEP(ZT_ROW_BCAST31, 0xC)
+}
+#undef ZT_SCAN2_STEP

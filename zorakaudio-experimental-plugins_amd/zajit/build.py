@@ -104,10 +104,24 @@ def _hot_calls(prog) -> set:
     return out
 
 
+def tpar_plan(unit: codegen.Unit):
+    """Time-parallel plan of the leaf's @sample (zajit/tpar.py), or (None, reason). Leaves with a hand-written kernel keep it;
+    scripts that raise slider masks need the generic kernel's per-block @slider check."""
+    from . import tpar
+    if os.environ.get("ZA_NO_TPAR"):
+        return None, "disabled (ZA_NO_TPAR)"
+    if unit.prog.name in FAST_KERNELS:
+        return None, "hand-written kernel"
+    if "sliderchange" in unit.features:
+        return None, "script raises slider masks"
+    return tpar.try_plan(unit.prog, int(unit.defines["ZA_NCH"]))
+
+
 def module_source(unit: codegen.Unit) -> str:
     p = unit.prog
     name = p.name
     nch = int(unit.defines["ZA_NCH"])
+    plan, _why = tpar_plan(unit)
     alias = " ".join(f"X({k}, {p.vars[v]})" for k, v in sorted(p.aliases.items()) if v in p.vars)
     lines = [f"// generated by zajit.build for leaf {name}; do not edit", unit.preamble(),
              f"#define ZA_KERNEL(x) zab_{_cid(name)}_##x",
@@ -132,6 +146,12 @@ def module_source(unit: codegen.Unit) -> str:
     fast = FAST_KERNELS.get(name)
     if fast:
         lines.append(f'#include "{fast}"')
+    elif plan is not None:
+        from . import tpar
+        lines.append('#include "zart_tpar.h"')
+        lines.append(tpar.emit_hip(plan, p))
+        lines.append(f'#define ZA_FAST_KERNEL_NAME "zab_{_cid(name)}_tpar"')
+        fast = "tpar"
     names = sorted(p.vars.items(), key=lambda kv: kv[1])
     arr = ", ".join(json.dumps(n) for n, _ in names) or '""'
     lines.append(f"static const char* const za_var_names[] = {{ {arr} }};")
@@ -170,7 +190,7 @@ def build_module(jsfx_path, name: Optional[str] = None, force=False, verbose=Fal
     so = LIB / f"libzab_{prog.name}.so"
     leaf_flags = LEAF_FLAGS.get(prog.name, [])
     text = module_source(unit) + (f"// leaf build flags: {' '.join(leaf_flags)}\n" if leaf_flags else "")
-    deps = [CSRC / "zart.h", CSRC / "zab_generic.hip.h", CSRC / "zab_module.h"]
+    deps = [CSRC / "zart.h", CSRC / "zab_generic.hip.h", CSRC / "zab_module.h", CSRC / "zart_tpar.h"]
     if prog.name in FAST_KERNELS:
         deps.append(CSRC / FAST_KERNELS[prog.name])
     for extra in ("zart_fft.h", "zart_gmem.h", "zart_pool.h", "zart_file.h", "zart_msg.h"):
@@ -190,7 +210,9 @@ def build_module(jsfx_path, name: Optional[str] = None, force=False, verbose=Fal
                        for i, d in prog.slider_decls.items()}
     from .sliders import default_slider_values
     meta["default_sliders"] = [float(x) for x in default_slider_values(prog.slider_decls)]
-    meta["fast_path"] = prog.name in FAST_KERNELS
+    plan, why = tpar_plan(unit)
+    meta["fast_path"] = prog.name in FAST_KERNELS or plan is not None
+    meta["tpar"] = plan.stats if plan is not None else {"unsupported": why}
     (LIB / f"{prog.name}.json").write_text(json.dumps(meta))
     return so
 

@@ -871,3 +871,180 @@ def try_plan(prog: Program, nch: int) -> Tuple[Optional[Plan], str]:
         return build_plan(prog, nch), ""
     except Unsupported as ex:
         return None, str(ex)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# 3. HIP emission (csrc/zart_tpar.h holds the wavefront primitives)
+# ----------------------------------------------------------------------------------------------------------------------
+_INFIX = {"+": "+", "-": "-", "*": "*", "/": "/"}
+_CMP = {"<": "<", "<=": "<=", ">": ">", ">=": ">=", "==": "=="}
+_FN2 = {"^": "pow", "|": "za_or", "&": "za_and", "~": "za_xor", "<<": "za_shl", ">>": "za_shr", "%": "za_mod", "!=": "za_ne",
+        "min": "za_min", "max": "za_max", "pow": "pow", "atan2": "atan2"}
+_FN1 = {"neg": "za_neg", "not": "za_not", "sqr": "za_sqr", "sign": "za_sign", "invsqrt": "za_invsqrt"}
+
+
+def _expr(op: str, a: List[str]) -> str:
+    """Same C++ spelling as zajit/emit.py gives the construct, so both kernels share zart.h's semantics."""
+    if op in _INFIX:
+        return f"({a[0]} {_INFIX[op]} {a[1]})"
+    if op in _CMP:
+        return f"za_b({a[0]} {_CMP[op]} {a[1]})"
+    if op in _FN2:
+        return f"{_FN2[op]}({a[0]}, {a[1]})"
+    if op in _FN1:
+        return f"{_FN1[op]}({a[0]})"
+    if op == "truth":
+        return f"za_b(za_truthy({a[0]}))"
+    if op == "land":
+        return f"za_b(za_truthy({a[0]}) && za_truthy({a[1]}))"
+    if op == "lor":
+        return f"za_b(za_truthy({a[0]}) || za_truthy({a[1]}))"
+    if op == "sel":
+        return f"(za_truthy({a[0]}) ? {a[1]} : {a[2]})"
+    if op in PURE_MATH1:
+        return f"{PURE_MATH1[op]}({a[0]})"
+    raise AssertionError(op)
+
+
+def emit_hip(plan: Plan, prog: Program, kernel_macro: str = "ZA_KERNEL(tpar)") -> str:
+    """Kernel + launcher text, appended to a leaf module after zab_generic.hip.h (which defines ZabBatch / ZabAudio)."""
+    g = plan.g
+    L: List[str] = []
+
+    def ref(n: N) -> str:
+        if n.kind == "const":
+            return c_double(n.val)
+        return (f"u{n.i}" if n.uniform else f"n{n.i}")
+
+    def inv_src(name: str) -> str:
+        k = is_slider_name(name)
+        if k is not None:
+            return f"b.sliders[{k - 1} * b.sl_se + inst * b.sl_si]"
+        if name == "srate":
+            return "b.srate"
+        if name in ("midi_bus", "ext_midi_bus"):
+            return "0.0"
+        k = is_spl_name(name)
+        if k is not None:
+            return f"b.spl[{k} * b.sl_se + inst * b.sl_si]"
+        return f"b.vars[{prog.vars[name]} * b.var_se + inst * b.var_si]"
+
+    def dst(name: str) -> str:
+        k = is_spl_name(name)
+        if k is not None:
+            return f"b.spl[{k} * b.sl_se + inst * b.sl_si]"
+        return f"b.vars[{prog.vars[name]} * b.var_se + inst * b.var_si]"
+
+    cname = {name: f"c{k}" for k, name in enumerate(plan.st)}
+    L.append("// ---- time-parallel kernel: one wavefront per instance, lane = frame (generated by zajit/tpar.py) ----")
+    L.append(f"// schedule: {plan.stats}")
+    L.append(f'extern "C" __global__ void __launch_bounds__(64) {kernel_macro}(ZabBatch b, ZabAudio a) {{')
+    L.append("  const int lane = threadIdx.x;")
+    L.append("  const int64_t inst = blockIdx.x;")
+    L.append("  const int64_t frames = a.frames;")
+    L.append("  if (frames <= 0 || inst >= b.n_inst) return;")
+    L.append("  // per launch: invariants and everything that depends on them only")
+    for n in plan.uniform:
+        if n.kind == "const":
+            continue
+        if n.kind == "inv":
+            L.append(f"  const double u{n.i} = {inv_src(n.name)};   // {n.name}")
+        else:
+            L.append(f"  const double u{n.i} = {_expr(n.op, [ref(x) for x in n.args])};")
+    L.append("  // state carried from frame to frame (wave-uniform)")
+    for name, c in cname.items():
+        L.append(f"  double {c} = {inv_src(name)};   // {name}")
+    L.append(f"  const float* const in_ = a.in + inst * {plan.nch} * a.frame_stride;")
+    L.append(f"  float* const out_ = a.out + inst * {plan.nch} * a.frame_stride;")
+    L.append("  for (int64_t f0 = 0; f0 < frames; f0 += 64) {")
+    L.append("    const int tn = (int)(frames - f0 < 64 ? frames - f0 : 64);")
+    L.append("    const int last = tn - 1;")
+    L.append("    const bool valid = lane < tn;")
+    for n in plan.inputs:
+        L.append(f"    const double n{n.i} = valid ? (double)in_[{int(n.val)} * a.frame_stride + f0 + lane] : 0.0;")
+    for it in plan.items:
+        kind = it[0]
+        if kind == "par":
+            n = it[1]
+            L.append(f"    const double n{n.i} = {_expr(n.op, [ref(x) for x in n.args])};")
+        elif kind == "shift":
+            name = it[1]
+            L.append(f"    const double n{plan.st[name].i} = zt_shift1({ref(plan.outs[name])}, {cname[name]});   // {name}[t-1]")
+        elif kind == "scan":
+            c: Component = it[1]
+            if len(c.names) == 1:
+                nm = c.names[0]
+                s = plan.st[nm].i
+                L.append(f"    double sa{s} = {ref(c.A[0][0])}, sb{s} = {ref(c.b[0])};   // {nm}: affine recurrence")
+                L.append(f"    zt_scan1(sa{s}, sb{s});")
+                L.append(f"    const double n{s} = zt_shift1(__builtin_fma(sa{s}, {cname[nm]}, sb{s}), {cname[nm]});")
+            else:
+                n0, n1 = c.names
+                s0, s1 = plan.st[n0].i, plan.st[n1].i
+                L.append(f"    ZtMap2 sm{s0} = {{{ref(c.A[0][0])}, {ref(c.A[0][1])}, {ref(c.A[1][0])}, {ref(c.A[1][1])}, {ref(c.b[0])}, {ref(c.b[1])}}};   // {n0}, {n1}: coupled affine pair")
+                L.append(f"    zt_scan2(sm{s0});")
+                L.append(f"    const double n{s0} = zt_shift1(__builtin_fma(sm{s0}.a00, {cname[n0]}, __builtin_fma(sm{s0}.a01, {cname[n1]}, sm{s0}.b0)), {cname[n0]});")
+                L.append(f"    const double n{s1} = zt_shift1(__builtin_fma(sm{s0}.a10, {cname[n0]}, __builtin_fma(sm{s0}.a11, {cname[n1]}, sm{s0}.b1)), {cname[n1]});")
+        elif kind == "serial":
+            comps: List[Component] = it[1]
+            names = [nm for c in comps for nm in c.names]
+            L.append(f"    // serial recurrences sharing one loop: {', '.join(names)}")
+            for nm in names:
+                s = plan.st[nm].i
+                L.append(f"    double y{s} = {cname[nm]}, k{s} = {cname[nm]};")
+            L.append("    for (int t = 0; t < tn; ++t) {")
+            L.append("      const bool me = lane == t;")
+            seen_ext = set()
+            for c in comps:
+                mem = {m.i for m in c.members}
+                for nm in c.names:
+                    s = plan.st[nm].i
+                    L.append(f"      k{s} = me ? y{s} : k{s};")
+                for x in c.ext:
+                    if not x.uniform and x.kind != "const" and x.i not in seen_ext:
+                        seen_ext.add(x.i)
+                        L.append(f"      const double e{x.i} = zt_readlane(n{x.i}, t);")
+
+                def sref(x: N) -> str:
+                    if x.kind == "st" and x.i in mem:
+                        return f"y{x.i}"
+                    if x.i in mem:
+                        return f"m{x.i}"
+                    if x.kind == "const" or x.uniform:
+                        return ref(x)
+                    return f"e{x.i}"
+
+                for m in c.members:
+                    if m.kind == "st":
+                        continue
+                    L.append(f"      const double m{m.i} = {_expr(m.op, [sref(x) for x in m.args])};")
+                for nm in c.names:            # all new states are computed from the old ones before any is replaced
+                    L.append(f"      const double q{plan.st[nm].i} = {sref(plan.outs[nm])};")
+                for nm in c.names:
+                    L.append(f"      y{plan.st[nm].i} = q{plan.st[nm].i};")
+            L.append("    }")
+            for nm in names:
+                s = plan.st[nm].i
+                L.append(f"    const double n{s} = k{s};")
+        else:
+            raise AssertionError(kind)
+    L.append("    if (valid) {")
+    for ch in range(plan.nch):
+        L.append(f"      out_[{ch} * a.frame_stride + f0 + lane] = (float){ref(plan.spl_out[ch])};")
+    L.append("    }")
+    for name, c in cname.items():
+        o = plan.outs[name]
+        L.append(f"    {c} = {ref(o) if (o.uniform or o.kind == 'const') else f'zt_readlane(n{o.i}, last)'};")
+    L.append("    if (f0 + 64 >= frames && lane == last) {   // the launch's last frame: leave every written variable as the script would")
+    finals = list(plan.outs.items()) + [(f"spl{ch}", plan.spl_out[ch]) for ch in range(plan.nch) if f"spl{ch}" not in plan.outs]
+    for name, o in finals:
+        L.append(f"      {dst(name)} = {ref(o)};")
+    L.append("    }")
+    L.append("  }")
+    L.append("}")
+    L.append("static int32_t za_fast_applies(const ZabBatch* b, const ZabAudio* a) { (void)b; return a->frames > 0 ? 1 : 0; }")
+    L.append("static hipError_t za_launch_fast(const ZabBatch* b, const ZabAudio* a, hipStream_t st) {")
+    L.append(f"  hipLaunchKernelGGL({kernel_macro}, dim3(b->n_inst), dim3(64), 0, st, *b, *a);")
+    L.append("  return hipGetLastError();")
+    L.append("}")
+    return "\n".join(L) + "\n"
