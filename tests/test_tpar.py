@@ -42,18 +42,34 @@ def test_recurrence_zoo_classification():
     for it in plan.items:
         if it[0] == "scan":
             kinds[tuple(it[1].names)] = "scan"
-        elif it[0] == "serial":
+        elif it[0] in ("serial", "spec"):
             for c in it[1]:
-                kinds[tuple(c.names)] = "serial"
+                kinds[tuple(c.names)] = it[0]
         elif it[0] == "shift":
             kinds[(it[1],)] = "shift"
     assert kinds[("xpL",)] == kinds[("xpR",)] == kinds[("lastsign",)] == "shift"               # delayed signals
     for one in ("dcL", "dcR", "lpL", "lpR", "cnt", "flips", "heldv", "acc", "tv"):            # affine, one state
         assert kinds[(one,)] == "scan", one
     assert kinds[("z1", "z2")] == "scan" and kinds[("swa", "swb")] == "scan"                    # coupled affine pairs
-    for one in ("gr", "pk", "hold", "ph", "__fnlocal__sample__follow__e"):                    # state-dependent coefficients
-        assert kinds[(one,)] == "serial", one
-    assert plan.stats["serial_loops"] == 2          # five chains share two loops
+    for one in ("gr", "pk", "hold", "ph", "__fnlocal__sample__follow__e"):                    # state-dependent conditions
+        assert kinds[(one,)] == "spec", one
+    assert plan.stats["spec_loops"] == 2            # five chains share two iterations
+    assert plan.stats["serial_loops"] == 0
+
+
+def test_switched_recurrences_fall_back_to_the_serial_loop(monkeypatch):
+    """With the iteration budget cut to one pass most chunks of the phase accumulator do not reach their fixed point; the
+    serial loop takes over for those chunks and the result is unchanged."""
+    from zajit import tpar
+    plan, _ = _plan("fx_dynkat")
+    g = load_golden("fx_dynkat_default")
+    names = [str(s) for s in g["var_names"]]
+    v0 = {n: (0.0 if np.isnan(v) else float(v)) for n, v in zip(names, g["vars_prepared"])}
+    monkeypatch.setattr(tpar, "SPEC_MAX", 1)
+    y, va, _ = plan.simulate(v0, golden_input(g), sliders=g["sliders"], srate=float(g["srate"]))
+    assert any(not ok for _, _, ok in plan.spec_log) and any(ok for _, _, ok in plan.spec_log)
+    assert np.abs(y.astype(np.float64) - g["out"]).max() <= AUDIO_EPS
+    assert_state_close(names, [va.get(n, 0.0) for n in names], g["vars"], what="vars")
 
 
 def test_unsupported_scripts_keep_the_generic_kernel_only():
@@ -185,3 +201,23 @@ def test_slider_change_between_launches_runs_at_slider_before_the_tpar_kernel():
     assert np.abs(out["tpar"][0].astype(np.float64) - out["generic"][0]).max() <= AUDIO_EPS
     assert np.abs(out["tpar"][1] - out["generic"][1]).max() <= SCALAR_EPS
     assert not np.array_equal(out["tpar"][0][0, :, frames:], out["tpar"][0][1, :, frames:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["fx_dynkat_default", "fx_dynkat_hot"])
+def test_tpar_kernel_serial_fallback_of_switched_recurrences(case):
+    """fx_dynkat_s1 = the same script built with an iteration budget of one (-DZT_SPEC_MAX=1): chunks whose condition pattern
+    is not right at the first guess run the serial loop instead. Same golden vectors."""
+    import zabatch
+    leaf = "fx_dynkat_s1"
+    if not zabatch.module_path(leaf).exists():
+        pytest.skip(f"module for {leaf} not built")
+    g = load_golden(case)
+    x = np.repeat(golden_input(g)[None], 3, axis=0)
+    with zabatch.Engine(leaf, 3, srate=float(g["srate"]), path=zabatch.ZAB_PATH_FAST) as e:
+        e.set_sliders(g["sliders"]); e.prepare()
+        names = e.var_names()
+        y = e.process_host(x, block=int(g["block"]))
+        v = e.read_vars()
+    assert np.abs(y.astype(np.float64) - g["out"].astype(np.float64)[None]).max() <= AUDIO_EPS
+    assert_state_close(names, v[2], g["vars"], what=f"{case} vars")

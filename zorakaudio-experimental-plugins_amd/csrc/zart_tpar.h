@@ -24,6 +24,15 @@ __device__ __forceinline__ double zt_readlane(double v, int l) {      // l must 
   return __builtin_bit_cast(double, t);
 }
 
+// A value every lane computed identically, declared wave-uniform: it can live in scalar registers (or, spilled, in single
+// lanes of a vector register) instead of occupying a vector register pair in all 64 lanes.
+__device__ __forceinline__ double zt_uniform(double v) {
+  int2 t = __builtin_bit_cast(int2, v);
+  t.x = __builtin_amdgcn_readfirstlane(t.x);
+  t.y = __builtin_amdgcn_readfirstlane(t.y);
+  return __builtin_bit_cast(double, t);
+}
+
 // lanes selected by ROWS that have a source lane under CTRL receive its value; every other lane receives `keep`
 template <int CTRL, int ROWS>
 __device__ __forceinline__ double zt_dpp(double v, double keep) {

@@ -42,7 +42,8 @@ FAST_KERNELS = {"DDT": "kernels/ddt_fast.hip.h"}
 # Per-leaf code-shape choices measured on MI355X (tools/catalog_sweep.py, 1024 instances). zart.h's arena
 # load is branch-free by default (better or equal on 20 leaves, up to 14 %); these four delay-line / FIR style scripts run
 # faster with the bounds check as a branch around the load (Roomalizer 1.76x, TSEQ 1.07x, DOT 1.05x, DPT 1.03x).
-LEAF_FLAGS = {"Roomalizer": ["-DZA_LD_BRANCH"], "TSEQ": ["-DZA_LD_BRANCH"], "DOT": ["-DZA_LD_BRANCH"], "DPT": ["-DZA_LD_BRANCH"]}
+LEAF_FLAGS = {"fx_dynkat_s1": ["-DZT_SPEC_MAX=1"],       # test variant: switched recurrences mostly fall back to their serial loop
+              "Roomalizer": ["-DZA_LD_BRANCH"], "TSEQ": ["-DZA_LD_BRANCH"], "DOT": ["-DZA_LD_BRANCH"], "DPT": ["-DZA_LD_BRANCH"]}
 # leaves whose state the hand-written kernel wants contiguous per instance
 INSTANCE_MAJOR = {"DDT"}
 

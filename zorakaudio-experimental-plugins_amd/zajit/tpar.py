@@ -31,6 +31,7 @@ the analysis itself -- classification, coefficients, carries, partial chunks -- 
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -331,10 +332,18 @@ class Component:
     def __init__(self, names, members):
         self.names: List[str] = names            # state variables, order = order of first write in the frame
         self.members: List[N] = members          # nodes on the cycle(s), topological order within the frame
-        self.kind = "serial"                     # "scan" when affine with at most 2 states
-        self.A: List[List[N]] = []               # scan: y[t] = A y[t-1] + b  (nodes free of the component's states)
+        self.kind = "serial"                     # "scan": affine, at most 2 states; "spec": affine once its switches are fixed
+        self.A: List[List[N]] = []               # scan / spec: y[t] = A y[t-1] + b  (nodes free of the component's states)
         self.b: List[N] = []
         self.ext: List[N] = []                   # non-member operands of the members (varying ones are broadcast per step)
+        # spec: switches = conditions (of ?:, min, max, abs) that depend on the component's own states. With every switch
+        # fixed the recurrence is affine, so a guessed switch pattern gives the states by one scan; the states give the
+        # pattern back; a pattern that reproduces itself is the serial solution (induction over the frames).
+        self.conds: List[N] = []                 # condition node of each switch (member or synthetic compare of members)
+        self.gnodes: List[N] = []                # its placeholder ("guess") in A / b
+        self.gdep: List[N] = []                  # nodes of A / b that depend on a placeholder, topological order
+        self.slice: List[N] = []                 # nodes needed to evaluate the conditions from the states, topological order
+        self.inputs: List[N] = []                # everything outside that the unit reads
 
 
 class Plan:
@@ -353,6 +362,31 @@ class Plan:
     # ------------------------------------------------------------------------------------------------------------------
     # numpy restatement of the staged algorithm (tests)
     # ------------------------------------------------------------------------------------------------------------------
+    def _sim_serial(self, comp: "Component", val, carry, tn):
+        cur = {nm: carry[nm] for nm in comp.names}
+        caps = {nm: np.zeros(WAVE) for nm in comp.names}
+        for t in range(tn):
+            loc: Dict[int, np.float64] = {}
+            for nm in comp.names:
+                caps[nm][t] = cur[nm]
+                loc[self.st[nm].i] = cur[nm]
+            for m in comp.members:
+                if m.kind == "st":
+                    continue
+                ops = []
+                for a in m.args:
+                    if a.i in loc:
+                        ops.append(loc[a.i])
+                    else:
+                        v = val[a.i]
+                        ops.append(v if np.ndim(v) == 0 else v[t])
+                loc[m.i] = np.float64(_np_op(m.op, ops))
+            for nm in comp.names:
+                cur[nm] = loc[self.outs[nm].i]
+        for nm in comp.names:
+            caps[nm][tn:] = cur[nm]
+            val[self.st[nm].i] = caps[nm]
+
     def simulate(self, vars0: Dict[str, float], x: np.ndarray, sliders=None, srate=48000.0, spl0=None):
         """x: [nch, frames] float32. vars0: name -> value before the launch (missing names are 0).
         Returns (y float32 [nch, frames], vars after {name: value}, spl after {k: value})."""
@@ -375,6 +409,7 @@ class Plan:
             return float(vars0.get(name, 0.0))
 
         val: Dict[int, np.ndarray] = {}
+        self.spec_log = []                     # (states, iterations, converged) per switched recurrence and chunk
         with np.errstate(all="ignore"):
             for n in self.uniform:
                 if n.kind == "const":
@@ -412,48 +447,45 @@ class Plan:
                         A = np.stack([np.stack([np.broadcast_to(val[comp.A[r][c].i], (WAVE,)) for c in range(d)]) for r in range(d)])
                         b = np.stack([np.broadcast_to(val[comp.b[r].i], (WAVE,)) for r in range(d)])
                         A, b = A.astype(np.float64).copy(), b.astype(np.float64).copy()          # [d,d,64], [d,64]
-                        s = 1
-                        while s < WAVE:                   # Kogge-Stone, element = map y -> A y + b; (cur o earlier)
-                            A2, b2 = A.copy(), b.copy()
-                            for t in range(s, WAVE):
-                                A2[:, :, t] = A[:, :, t] @ A[:, :, t - s]
-                                b2[:, t] = A[:, :, t] @ b[:, t - s] + b[:, t]
-                            A, b = A2, b2
-                            s *= 2
-                        c0 = np.array([carry[nm] for nm in comp.names])
-                        yinc = np.einsum("rct,c->rt", A, c0) + b         # state after frame t
+                        states = _scan_exclusive(A, b, np.array([carry[nm] for nm in comp.names]))
                         for r, nm in enumerate(comp.names):
-                            sh = np.empty(WAVE)
-                            sh[0] = carry[nm]
-                            sh[1:] = yinc[r, :-1]
-                            val[self.st[nm].i] = sh
+                            val[self.st[nm].i] = states[r]
                     elif kind == "serial":
-                        comps: List[Component] = it[1]
-                        for comp in comps:
-                            cur = {nm: carry[nm] for nm in comp.names}
-                            caps = {nm: np.zeros(WAVE) for nm in comp.names}
-                            for t in range(tn):
-                                loc: Dict[int, np.float64] = {}
-                                for nm in comp.names:
-                                    caps[nm][t] = cur[nm]
-                                    loc[self.st[nm].i] = cur[nm]
-                                for m in comp.members:
-                                    if m.kind == "st":
-                                        continue
-                                    ops = []
-                                    for a in m.args:
-                                        if a.i in loc:
-                                            ops.append(loc[a.i])
-                                        else:
-                                            v = val[a.i]
-                                            ops.append(v if np.ndim(v) == 0 else v[t])
-                                    loc[m.i] = np.float64(_np_op(m.op, ops))
-                                for nm in comp.names:
-                                    o = self.outs[nm]
-                                    cur[nm] = loc[o.i] if o.i in loc else (val[o.i] if np.ndim(val[o.i]) == 0 else val[o.i][t])
-                            for nm in comp.names:
-                                caps[nm][tn:] = cur[nm]
-                                val[self.st[nm].i] = caps[nm]
+                        for comp in it[1]:
+                            self._sim_serial(comp, val, carry, tn)
+                    elif kind == "spec":
+                        for comp in it[1]:
+                            d = len(comp.names)
+
+                            def conds_from(states):
+                                loc = {self.st[nm].i: states[r] for r, nm in enumerate(comp.names)}
+                                for m in comp.slice:
+                                    loc[m.i] = np.broadcast_to(_np_op(m.op, [loc[a.i] if a.i in loc else val[a.i] for a in m.args]), (WAVE,))
+                                return [_truthy(np.broadcast_to(loc[c.i] if c.i in loc else val[c.i], (WAVE,))) for c in comp.conds]
+
+                            gs = conds_from([np.full(WAVE, carry[nm]) for nm in comp.names])
+                            converged, iters = False, 0
+                            while iters < SPEC_MAX:
+                                iters += 1
+                                loc = {gn.i: np.where(gs[k], 1.0, 0.0) for k, gn in enumerate(comp.gnodes)}
+                                for n in comp.gdep:
+                                    loc[n.i] = _np_op(n.op, [loc[a.i] if a.i in loc else val[a.i] for a in n.args])
+                                gv = lambda n: np.broadcast_to(loc[n.i] if n.i in loc else val[n.i], (WAVE,)).astype(np.float64)
+                                A = np.stack([np.stack([gv(comp.A[r][c]) for c in range(d)]) for r in range(d)]).copy()
+                                b = np.stack([gv(comp.b[r]) for r in range(d)]).copy()
+                                states = _scan_exclusive(A, b, np.array([carry[nm] for nm in comp.names]))
+                                ng = conds_from(states)
+                                changed = any(bool(np.any(x[:tn] != y[:tn])) for x, y in zip(ng, gs))
+                                gs = ng
+                                if not changed:
+                                    converged = True
+                                    break
+                            self.spec_log.append((tuple(comp.names), iters, converged))
+                            if converged:
+                                for r, nm in enumerate(comp.names):
+                                    val[self.st[nm].i] = states[r]
+                            else:
+                                self._sim_serial(comp, val, carry, tn)
                     else:
                         raise AssertionError(kind)
                 for ch in range(self.nch):
@@ -475,6 +507,28 @@ class Plan:
             else:
                 vars_after[name] = v
         return y, vars_after, spl_after
+
+
+SPEC_MAX = 8          # iterations of a switched recurrence before the chunk falls back to its serial loop (ZT_SPEC_MAX)
+
+
+def _scan_exclusive(A, b, c0):
+    """Kogge-Stone over the lanes, element = the map y -> A y + b, combined as (current o earlier); returns the state BEFORE
+    each frame given the state c0 before the chunk. A: [d, d, 64], b: [d, 64]."""
+    A, b = A.copy(), b.copy()
+    s = 1
+    while s < WAVE:
+        A2, b2 = A.copy(), b.copy()
+        for t in range(s, WAVE):
+            A2[:, :, t] = A[:, :, t] @ A[:, :, t - s]
+            b2[:, t] = A[:, :, t] @ b[:, t - s] + b[:, t]
+        A, b = A2, b2
+        s *= 2
+    yinc = np.einsum("rct,c->rt", A, c0) + b
+    out = np.empty_like(yinc)
+    out[:, 0] = c0
+    out[:, 1:] = yinc[:, :-1]
+    return out
 
 
 def _truthy(a):
@@ -681,14 +735,21 @@ def build_plan(prog: Program, nch: int) -> Plan:
         else:
             n.uniform = all(a.uniform for a in n.args) and n.i not in comp_of
     # affine forms
-    for c in components:
-        _classify(g, plan, c, comp_of)
-    # nodes created by the affine analysis: find liveness / uniformity of the new coefficient nodes
+    import os
+    for ci, c in enumerate(components):
+        _classify(g, plan, c, comp_of, ci)
+        if c.kind == "spec" and os.environ.get("ZA_TPAR_NO_SPEC"):
+            c.kind = "serial"
+    # nodes created by the affine analysis: liveness / uniformity of the new coefficient nodes. Placeholder-dependent nodes
+    # and the synthetic compares live inside their unit only.
+    inside = {x.i for c in components if c.kind == "spec" for x in c.gdep + c.gnodes + c.slice}
     extra: Dict[int, N] = {}
-    todo = [x for c in components if c.kind == "scan" for row in c.A for x in row] + [x for c in components if c.kind == "scan" for x in c.b]
+    todo = [x for c in components if c.kind in ("scan", "spec") for row in c.A for x in row]
+    todo += [x for c in components if c.kind in ("scan", "spec") for x in c.b]
+    todo += [a for c in components if c.kind == "spec" for x in c.gdep + c.slice for a in x.args]
     while todo:
         n = todo.pop()
-        if n.i in live or n.i in extra:
+        if n.i in live or n.i in extra or n.i in inside:
             continue
         extra[n.i] = n
         todo.extend(n.args)
@@ -708,9 +769,7 @@ def build_plan(prog: Program, nch: int) -> Plan:
     items: List[tuple] = []
 
     def comp_inputs(c: Component) -> List[N]:
-        if c.kind == "scan":
-            return [x for row in c.A for x in row] + list(c.b)
-        return c.ext
+        return c.inputs
 
     for c in components:
         mem = {m.i for m in c.members}
@@ -721,6 +780,18 @@ def build_plan(prog: Program, nch: int) -> Plan:
                     seen.add(a.i)
                     ext.append(a)
         c.ext = ext
+        if c.kind == "scan":
+            c.inputs = [x for row in c.A for x in row] + list(c.b)
+        elif c.kind == "spec":
+            own = {x.i for x in c.gdep + c.gnodes + c.slice} | mem
+            ins, seen = list(ext), {x.i for x in ext}
+            for x in [y for row in c.A for y in row] + list(c.b) + [a for y in c.gdep + c.slice for a in y.args]:
+                if x.i not in own and x.i not in seen:
+                    seen.add(x.i)
+                    ins.append(x)
+            c.inputs = ins
+        else:
+            c.inputs = ext
 
     remaining = list(pending_nodes)
     guard = 0
@@ -761,11 +832,14 @@ def build_plan(prog: Program, nch: int) -> Plan:
                 progressed = True
         if progressed:
             continue
-        # only serial recurrences can move now: every one that is ready shares one loop
-        ready = [ci for ci, c in enumerate(components) if not comp_done[ci] and c.kind == "serial" and all(x.i in done for x in c.ext)]
+        # only switched / serial recurrences can move now: every one of a kind that is ready shares one loop
+        for kind in ("spec", "serial"):
+            ready = [ci for ci, c in enumerate(components) if not comp_done[ci] and c.kind == kind and all(x.i in done for x in c.inputs)]
+            if ready:
+                break
         if not ready:
             raise AssertionError("dependency cycle outside the recurrences")
-        items.append(("serial", [components[ci] for ci in ready]))
+        items.append((kind, [components[ci] for ci in ready]))
         for ci in ready:
             comp_done[ci] = True
     plan.items = items
@@ -774,6 +848,9 @@ def build_plan(prog: Program, nch: int) -> Plan:
         "shift": sum(1 for it in items if it[0] == "shift"),
         "scan1": sum(1 for it in items if it[0] == "scan" and len(it[1].names) == 1),
         "scan2": sum(1 for it in items if it[0] == "scan" and len(it[1].names) == 2),
+        "spec_loops": sum(1 for it in items if it[0] == "spec"),
+        "spec_chains": sum(len(it[1]) for it in items if it[0] == "spec"),
+        "spec_switches": sum(len(c.conds) for it in items if it[0] == "spec" for c in it[1]),
         "serial_loops": sum(1 for it in items if it[0] == "serial"),
         "serial_chains": sum(len(it[1]) for it in items if it[0] == "serial"),
         "serial_ops": sum(len([m for m in c.members if m.kind != "st"]) for it in items if it[0] == "serial" for c in it[1]),
@@ -782,14 +859,14 @@ def build_plan(prog: Program, nch: int) -> Plan:
     return plan
 
 
-def _classify(g: FrameGraph, plan: Plan, c: Component, comp_of: Dict[int, int]):
-    """Affine in the component's own states, with coefficients that do not depend on them? -> scan."""
+def _classify(g: FrameGraph, plan: Plan, c: Component, comp_of: Dict[int, int], ci: int = 0):
+    """Affine in the component's own states, with coefficients that do not depend on them? -> "scan".
+    Affine once the state-dependent conditions (switches) are fixed? -> "spec". Otherwise it stays "serial"."""
     mem = {m.i for m in c.members}
     names = c.names
     d = len(names)
     if d > 2:
         return
-    memo: Dict[int, Optional[tuple]] = {}
 
     def add(a: N, b: N) -> N:
         if a is g.ZERO:
@@ -814,56 +891,123 @@ def _classify(g: FrameGraph, plan: Plan, c: Component, comp_of: Dict[int, int]):
             return a
         return g.op("*", a, b)
 
-    def aff(n: N):
-        if n.i not in mem:
-            return ({}, n)
-        if n.i in memo:
-            return memo[n.i]
-        r = None
-        if n.kind == "st":
-            r = ({n.name: g.ONE}, g.ZERO)
-        elif n.kind == "op":
-            op = n.op
-            if op in ("+", "-"):
-                a, b = aff(n.args[0]), aff(n.args[1])
-                if a and b:
-                    f = add if op == "+" else sub
-                    co = {k: f(a[0].get(k, g.ZERO), b[0].get(k, g.ZERO)) for k in set(a[0]) | set(b[0])}
-                    r = (co, f(a[1], b[1]))
-            elif op == "neg":
-                a = aff(n.args[0])
-                if a:
-                    r = ({k: sub(g.ZERO, v) for k, v in a[0].items()}, sub(g.ZERO, a[1]))
-            elif op == "*":
-                a, b = aff(n.args[0]), aff(n.args[1])
-                if a and b:
-                    if not a[0]:
-                        r = ({k: mul(a[1], v) for k, v in b[0].items()}, mul(a[1], b[1]))
-                    elif not b[0]:
-                        r = ({k: mul(v, b[1]) for k, v in a[0].items()}, mul(a[1], b[1]))
-            elif op == "/":
-                a, b = aff(n.args[0]), aff(n.args[1])
-                if a and b and not b[0]:
-                    r = ({k: g.op("/", v, b[1]) for k, v in a[0].items()}, g.op("/", a[1], b[1]) if a[1] is not g.ZERO else g.ZERO)
-            elif op == "sel":
-                cnd = n.args[0]
-                if cnd.i not in mem:
-                    a, b = aff(n.args[1]), aff(n.args[2])
-                    if a and b:
-                        co = {k: g.sel(cnd, a[0].get(k, g.ZERO), b[0].get(k, g.ZERO)) for k in set(a[0]) | set(b[0])}
-                        r = (co, g.sel(cnd, a[1], b[1]))
-        memo[n.i] = r
-        return r
+    def attempt(allow_guess: bool):
+        memo: Dict[int, Optional[tuple]] = {}
+        conds: List[N] = []
+        gnodes: List[N] = []
 
-    rows = []
-    for nm in names:
-        r = aff(plan.outs[nm])
-        if r is None:
+        def guess_for(cond: N) -> N:
+            for k, x in enumerate(conds):
+                if x is cond:
+                    return gnodes[k]
+            conds.append(cond)
+            gn = g.mk("guess", name=f"{ci}", val=len(gnodes))
+            gnodes.append(gn)
+            return gn
+
+        def pick(cnd: N, a, b):
+            co = {k: g.sel(cnd, a[0].get(k, g.ZERO), b[0].get(k, g.ZERO)) for k in set(a[0]) | set(b[0])}
+            return (co, g.sel(cnd, a[1], b[1]))
+
+        def aff(n: N):
+            if n.i not in mem:
+                return ({}, n)
+            if n.i in memo:
+                return memo[n.i]
+            r = None
+            if n.kind == "st":
+                r = ({n.name: g.ONE}, g.ZERO)
+            elif n.kind == "op":
+                op = n.op
+                if op in ("+", "-"):
+                    a, b = aff(n.args[0]), aff(n.args[1])
+                    if a and b:
+                        f = add if op == "+" else sub
+                        co = {k: f(a[0].get(k, g.ZERO), b[0].get(k, g.ZERO)) for k in set(a[0]) | set(b[0])}
+                        r = (co, f(a[1], b[1]))
+                elif op == "neg":
+                    a = aff(n.args[0])
+                    if a:
+                        r = ({k: sub(g.ZERO, v) for k, v in a[0].items()}, sub(g.ZERO, a[1]))
+                elif op == "*":
+                    a, b = aff(n.args[0]), aff(n.args[1])
+                    if a and b:
+                        if not a[0]:
+                            r = ({k: mul(a[1], v) for k, v in b[0].items()}, mul(a[1], b[1]))
+                        elif not b[0]:
+                            r = ({k: mul(v, b[1]) for k, v in a[0].items()}, mul(a[1], b[1]))
+                elif op == "/":
+                    a, b = aff(n.args[0]), aff(n.args[1])
+                    if a and b and not b[0]:
+                        r = ({k: g.op("/", v, b[1]) for k, v in a[0].items()}, g.op("/", a[1], b[1]) if a[1] is not g.ZERO else g.ZERO)
+                elif op == "sel":
+                    cnd = n.args[0]
+                    if cnd.i not in mem or allow_guess:
+                        a, b = aff(n.args[1]), aff(n.args[2])
+                        if a and b:
+                            r = pick(cnd if cnd.i not in mem else guess_for(cnd), a, b)
+                elif op in ("min", "max") and allow_guess:      # za_min(a, b) = a < b ? a : b,  za_max(a, b) = a > b ? a : b
+                    a, b = aff(n.args[0]), aff(n.args[1])
+                    if a and b:
+                        r = pick(guess_for(g.op("<" if op == "min" else ">", n.args[0], n.args[1])), a, b)
+                elif op == "fabs" and allow_guess:                # |x| = x < 0 ? -x : x
+                    a = aff(n.args[0])
+                    if a:
+                        neg = ({k: sub(g.ZERO, v) for k, v in a[0].items()}, sub(g.ZERO, a[1]))
+                        r = pick(guess_for(g.op("<", n.args[0], g.ZERO)), neg, a)
+            memo[n.i] = r
+            return r
+
+        rows = []
+        for nm in names:
+            r = aff(plan.outs[nm])
+            if r is None:
+                return None
+            rows.append(r)
+        return rows, conds, gnodes
+
+    res = attempt(False)
+    if res is not None:
+        c.kind = "scan"
+    else:
+        res = attempt(True)
+        if res is None:
             return
-        rows.append(r)
-    c.kind = "scan"
+        c.kind = "spec"
+    rows, c.conds, c.gnodes = res
     c.A = [[rows[r][0].get(names[k], g.ZERO) for k in range(d)] for r in range(d)]
     c.b = [rows[r][1] for r in range(d)]
+    if c.kind == "spec":
+        # coefficient nodes that depend on a placeholder (evaluated inside the iteration), topological = creation order
+        dep: Dict[int, bool] = {}
+
+        def gd(n: N) -> bool:
+            if n.i in dep:
+                return dep[n.i]
+            r = n.kind == "guess" or any(gd(x) for x in n.args)
+            dep[n.i] = r
+            return r
+
+        seen: Dict[int, N] = {}
+        todo = [x for row in c.A for x in row] + list(c.b)
+        while todo:
+            n = todo.pop()
+            if n.i in seen or not gd(n):
+                continue
+            seen[n.i] = n
+            todo.extend(n.args)
+        c.gdep = [seen[i] for i in sorted(seen) if seen[i].kind != "guess"]
+        # nodes needed to evaluate the conditions from the states: members (and the synthetic compares) only
+        sl: Dict[int, N] = {}
+        todo = list(c.conds)
+        synth = {x.i for x in c.conds if x.i not in mem}
+        while todo:
+            n = todo.pop()
+            if n.i in sl or (n.i not in mem and n.i not in synth):
+                continue
+            sl[n.i] = n
+            todo.extend(n.args)
+        c.slice = [sl[i] for i in sorted(sl) if sl[i].kind != "st"]
 
 
 def try_plan(prog: Program, nch: int) -> Tuple[Optional[Plan], str]:
@@ -880,6 +1024,7 @@ _INFIX = {"+": "+", "-": "-", "*": "*", "/": "/"}
 _CMP = {"<": "<", "<=": "<=", ">": ">", ">=": ">=", "==": "=="}
 _FN2 = {"^": "pow", "|": "za_or", "&": "za_and", "~": "za_xor", "<<": "za_shl", ">>": "za_shr", "%": "za_mod", "!=": "za_ne",
         "min": "za_min", "max": "za_max", "pow": "pow", "atan2": "atan2"}
+_POW_BASE = {"10.0": "exp10", "2.0": "exp2", c_double(math.e): "exp"}
 _FN1 = {"neg": "za_neg", "not": "za_not", "sqr": "za_sqr", "sign": "za_sign", "invsqrt": "za_invsqrt"}
 
 
@@ -889,6 +1034,10 @@ def _expr(op: str, a: List[str]) -> str:
         return f"({a[0]} {_INFIX[op]} {a[1]})"
     if op in _CMP:
         return f"za_b({a[0]} {_CMP[op]} {a[1]})"
+    if op in ("^", "pow") and a[0] in _POW_BASE and not os.environ.get("ZA_TPAR_PLAIN_POW"):
+        # constant base: the dedicated exponential (68 instructions on gfx950) instead of the general pow (240); both are
+        # accurate to the last bits, so results agree to ~4e-16 relative -- 10^(dB/20) is the commonest libm call in the catalog
+        return f"{_POW_BASE[a[0]]}({a[1]})"
     if op in _FN2:
         return f"{_FN2[op]}({a[0]}, {a[1]})"
     if op in _FN1:
@@ -938,6 +1087,12 @@ def emit_hip(plan: Plan, prog: Program, kernel_macro: str = "ZA_KERNEL(tpar)") -
     cname = {name: f"c{k}" for k, name in enumerate(plan.st)}
     L.append("// ---- time-parallel kernel: one wavefront per instance, lane = frame (generated by zajit/tpar.py) ----")
     L.append(f"// schedule: {plan.stats}")
+    L.append("#ifndef ZT_SPEC_MAX")
+    L.append(f"#define ZT_SPEC_MAX {SPEC_MAX}")
+    L.append("#endif")
+    L.append("#ifndef ZT_UNI")
+    L.append("#define ZT_UNI(x) zt_uniform(x)")
+    L.append("#endif")
     L.append(f'extern "C" __global__ void __launch_bounds__(64) {kernel_macro}(ZabBatch b, ZabAudio a) {{')
     L.append("  const int lane = threadIdx.x;")
     L.append("  const int64_t inst = blockIdx.x;")
@@ -950,7 +1105,7 @@ def emit_hip(plan: Plan, prog: Program, kernel_macro: str = "ZA_KERNEL(tpar)") -
         if n.kind == "inv":
             L.append(f"  const double u{n.i} = {inv_src(n.name)};   // {n.name}")
         else:
-            L.append(f"  const double u{n.i} = {_expr(n.op, [ref(x) for x in n.args])};")
+            L.append(f"  const double u{n.i} = ZT_UNI({_expr(n.op, [ref(x) for x in n.args])});")
     L.append("  // state carried from frame to frame (wave-uniform)")
     for name, c in cname.items():
         L.append(f"  double {c} = {inv_src(name)};   // {name}")
@@ -962,7 +1117,46 @@ def emit_hip(plan: Plan, prog: Program, kernel_macro: str = "ZA_KERNEL(tpar)") -
     L.append("    const bool valid = lane < tn;")
     for n in plan.inputs:
         L.append(f"    const double n{n.i} = valid ? (double)in_[{int(n.val)} * a.frame_stride + f0 + lane] : 0.0;")
-    for it in plan.items:
+
+    def serial_loop(comps: List[Component], ind: str):
+        """64 uniform steps; leaves the state before each frame in k<st> of that frame's lane."""
+        for c in comps:
+            for nm in c.names:
+                s = plan.st[nm].i
+                L.append(f"{ind}double y{s} = {cname[nm]}, k{s} = {cname[nm]};")
+        L.append(f"{ind}for (int t = 0; t < tn; ++t) {{")
+        L.append(f"{ind}  const bool me = lane == t;")
+        seen_ext = set()
+        for c in comps:
+            mem = {m.i for m in c.members}
+            for nm in c.names:
+                s = plan.st[nm].i
+                L.append(f"{ind}  k{s} = me ? y{s} : k{s};")
+            for x in c.ext:
+                if not x.uniform and x.kind != "const" and x.i not in seen_ext:
+                    seen_ext.add(x.i)
+                    L.append(f"{ind}  const double e{x.i} = zt_readlane(n{x.i}, t);")
+
+            def sref(x: N, mem=mem) -> str:
+                if x.kind == "st" and x.i in mem:
+                    return f"y{x.i}"
+                if x.i in mem:
+                    return f"m{x.i}"
+                if x.kind == "const" or x.uniform:
+                    return ref(x)
+                return f"e{x.i}"
+
+            for m in c.members:
+                if m.kind == "st":
+                    continue
+                L.append(f"{ind}  const double m{m.i} = {_expr(m.op, [sref(x) for x in m.args])};")
+            for nm in c.names:            # all new states are computed from the old ones before any is replaced
+                L.append(f"{ind}  const double q{plan.st[nm].i} = {sref(plan.outs[nm])};")
+            for nm in c.names:
+                L.append(f"{ind}  y{plan.st[nm].i} = q{plan.st[nm].i};")
+        L.append(f"{ind}}}")
+
+    for gid, it in enumerate(plan.items):
         kind = it[0]
         if kind == "par":
             n = it[1]
@@ -986,46 +1180,82 @@ def emit_hip(plan: Plan, prog: Program, kernel_macro: str = "ZA_KERNEL(tpar)") -
                 L.append(f"    const double n{s0} = zt_shift1(__builtin_fma(sm{s0}.a00, {cname[n0]}, __builtin_fma(sm{s0}.a01, {cname[n1]}, sm{s0}.b0)), {cname[n0]});")
                 L.append(f"    const double n{s1} = zt_shift1(__builtin_fma(sm{s0}.a10, {cname[n0]}, __builtin_fma(sm{s0}.a11, {cname[n1]}, sm{s0}.b1)), {cname[n1]});")
         elif kind == "serial":
-            comps: List[Component] = it[1]
-            names = [nm for c in comps for nm in c.names]
+            names = [nm for c in it[1] for nm in c.names]
             L.append(f"    // serial recurrences sharing one loop: {', '.join(names)}")
-            for nm in names:
-                s = plan.st[nm].i
-                L.append(f"    double y{s} = {cname[nm]}, k{s} = {cname[nm]};")
-            L.append("    for (int t = 0; t < tn; ++t) {")
-            L.append("      const bool me = lane == t;")
-            seen_ext = set()
-            for c in comps:
-                mem = {m.i for m in c.members}
-                for nm in c.names:
-                    s = plan.st[nm].i
-                    L.append(f"      k{s} = me ? y{s} : k{s};")
-                for x in c.ext:
-                    if not x.uniform and x.kind != "const" and x.i not in seen_ext:
-                        seen_ext.add(x.i)
-                        L.append(f"      const double e{x.i} = zt_readlane(n{x.i}, t);")
-
-                def sref(x: N) -> str:
-                    if x.kind == "st" and x.i in mem:
-                        return f"y{x.i}"
-                    if x.i in mem:
-                        return f"m{x.i}"
-                    if x.kind == "const" or x.uniform:
-                        return ref(x)
-                    return f"e{x.i}"
-
-                for m in c.members:
-                    if m.kind == "st":
-                        continue
-                    L.append(f"      const double m{m.i} = {_expr(m.op, [sref(x) for x in m.args])};")
-                for nm in c.names:            # all new states are computed from the old ones before any is replaced
-                    L.append(f"      const double q{plan.st[nm].i} = {sref(plan.outs[nm])};")
-                for nm in c.names:
-                    L.append(f"      y{plan.st[nm].i} = q{plan.st[nm].i};")
-            L.append("    }")
+            serial_loop(it[1], "    ")
             for nm in names:
                 s = plan.st[nm].i
                 L.append(f"    const double n{s} = k{s};")
+        elif kind == "spec":
+            comps: List[Component] = it[1]
+            names = [nm for c in comps for nm in c.names]
+            L.append(f"    // switched recurrences (affine once their state-dependent conditions are fixed), solved by iterating the")
+            L.append(f"    // condition pattern to its fixed point: {', '.join(names)}")
+            for nm in names:
+                L.append(f"    double s{plan.st[nm].i} = {cname[nm]};")
+            gname = {}
+            for c in comps:
+                for k, gn in enumerate(c.gnodes):
+                    gname[gn.i] = f"g{gn.name}_{k}"
+                    L.append(f"    bool {gname[gn.i]};")
+
+            def xref(x: N, loc: Dict[int, str]) -> str:
+                if x.i in loc:
+                    return loc[x.i]
+                if x.kind == "guess":
+                    return f"({gname[x.i]} ? 1.0 : 0.0)"
+                return ref(x)
+
+            def slice_eval(c: Component, ind: str, out_prefix: str):
+                loc = {plan.st[nm].i: f"s{plan.st[nm].i}" for nm in c.names}
+                for m in c.slice:
+                    loc[m.i] = f"v{m.i}"
+                    L.append(f"{ind}const double v{m.i} = {_expr(m.op, [xref(x, loc) for x in m.args])};")
+                for k, (cn, gn) in enumerate(zip(c.conds, c.gnodes)):
+                    L.append(f"{ind}{out_prefix}{gname[gn.i]} = za_truthy({xref(cn, loc)});")
+
+            L.append("    {   // first pattern: the states taken to stay at their carried values")
+            for c in comps:
+                slice_eval(c, "      ", "")
+            L.append("    }")
+            L.append(f"    bool sch{gid}; int sit{gid} = 0;")
+            L.append("    do {")
+            for c in comps:
+                loc: Dict[int, str] = {}
+                for n in c.gdep:
+                    loc[n.i] = f"d{n.i}"
+                    L.append(f"      const double d{n.i} = {_expr(n.op, [xref(x, loc) for x in n.args])};")
+                if len(c.names) == 1:
+                    nm = c.names[0]
+                    s = plan.st[nm].i
+                    L.append(f"      double sa{s} = {xref(c.A[0][0], loc)}, sb{s} = {xref(c.b[0], loc)};")
+                    L.append(f"      zt_scan1(sa{s}, sb{s});")
+                    L.append(f"      s{s} = zt_shift1(__builtin_fma(sa{s}, {cname[nm]}, sb{s}), {cname[nm]});")
+                else:
+                    n0, n1 = c.names
+                    s0, s1 = plan.st[n0].i, plan.st[n1].i
+                    L.append(f"      ZtMap2 sm{s0} = {{{xref(c.A[0][0], loc)}, {xref(c.A[0][1], loc)}, {xref(c.A[1][0], loc)}, {xref(c.A[1][1], loc)}, {xref(c.b[0], loc)}, {xref(c.b[1], loc)}}};")
+                    L.append(f"      zt_scan2(sm{s0});")
+                    L.append(f"      s{s0} = zt_shift1(__builtin_fma(sm{s0}.a00, {cname[n0]}, __builtin_fma(sm{s0}.a01, {cname[n1]}, sm{s0}.b0)), {cname[n0]});")
+                    L.append(f"      s{s1} = zt_shift1(__builtin_fma(sm{s0}.a10, {cname[n0]}, __builtin_fma(sm{s0}.a11, {cname[n1]}, sm{s0}.b1)), {cname[n1]});")
+            L.append("      // the pattern these states imply")
+            for c in comps:
+                slice_eval(c, "      ", "const bool h")
+            diffs = " || ".join(f"(h{gname[gn.i]} != {gname[gn.i]})" for c in comps for gn in c.gnodes)
+            L.append(f"      sch{gid} = __ballot(valid && ({diffs})) != 0ull;")
+            for c in comps:
+                for gn in c.gnodes:
+                    L.append(f"      {gname[gn.i]} = h{gname[gn.i]};")
+            L.append(f"    }} while (sch{gid} && ++sit{gid} < ZT_SPEC_MAX);")
+            L.append(f"    if (sch{gid}) {{   // no fixed point within the budget (a pattern that keeps moving along the chunk): the serial loop")
+            serial_loop(comps, "      ")
+            for nm in names:
+                s = plan.st[nm].i
+                L.append(f"      s{s} = k{s};")
+            L.append("    }")
+            for nm in names:
+                s = plan.st[nm].i
+                L.append(f"    const double n{s} = s{s};")
         else:
             raise AssertionError(kind)
     L.append("    if (valid) {")
