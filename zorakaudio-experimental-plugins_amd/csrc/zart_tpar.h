@@ -90,3 +90,73 @@ __device__ __forceinline__ void zt_scan2(ZtMap2& m) {
   ZT_SCAN2_STEP(ZT_ROW_BCAST31, 0xC)
 }
 #undef ZT_SCAN2_STEP
+
+// ---- rand(): MT19937 as za_mt_next (zart.h) runs it, readable at any position of a chunk ----------------------------------
+// A launch keeps two generations of the generator side by side in LDS (mt[0..624) = the instance's current table, mt[624..1248)
+// = the next one). The word for the k-th call of the launch sits at position pos0 + k of that pair, so every lane can fetch the
+// words of its frame once the per-lane call counts are known (they are an ordinary prefix sum). A new generation is produced
+// by the whole wavefront in three lane-parallel phases: element k needs new[k - 227] from k = 227 on, so [0, 227), [227, 454)
+// and [454, 623) are each parallel inside; element 623 closes the ring. At most 624 words may be consumed per chunk.
+#define ZT_MT_N 624
+#define ZT_MT_M 397
+__device__ __forceinline__ uint32_t zt_mt_tw(uint32_t a, uint32_t b) {
+  const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+  return (y >> 1) ^ ((y & 1u) ? 0x9908B0DFu : 0u);
+}
+__device__ __forceinline__ void zt_mt_twist(const uint32_t* cur, uint32_t* nxt, int lane) {
+  for (int k = lane; k < 227; k += 64) nxt[k] = cur[k + ZT_MT_M] ^ zt_mt_tw(cur[k], cur[k + 1]);
+  __syncthreads();
+  for (int k = 227 + lane; k < 454; k += 64) nxt[k] = nxt[k - 227] ^ zt_mt_tw(cur[k], cur[k + 1]);
+  __syncthreads();
+  for (int k = 454 + lane; k < 623; k += 64) nxt[k] = nxt[k - 227] ^ zt_mt_tw(cur[k], cur[k + 1]);
+  __syncthreads();
+  if (lane == 0) nxt[623] = nxt[396] ^ zt_mt_tw(cur[623], nxt[0]);
+  __syncthreads();
+}
+// Start of a launch: returns pos0, the position of the launch's first word. An instance that never called rand() (index 0) is
+// seeded here the way za_mt_next seeds it on first use, positioned at the end of that generation.
+__device__ __forceinline__ int zt_mt_begin(uint32_t* mt, const uint32_t* gmt, int64_t gstride, uint32_t gindex, int lane) {
+  int pos0;
+  if (gindex == 0) {
+    if (lane == 0) {
+      uint32_t prev = 0x4141F00Du;
+      mt[0] = prev;
+      for (int k = 1; k < ZT_MT_N; ++k) { prev = 1812433253u * (prev ^ (prev >> 30)) + (uint32_t)k; mt[k] = prev; }
+    }
+    pos0 = ZT_MT_N;
+  } else {
+    for (int k = lane; k < ZT_MT_N; k += 64) mt[k] = gmt[k * gstride];
+    pos0 = (int)gindex;
+  }
+  __syncthreads();
+  zt_mt_twist(mt, mt + ZT_MT_N, lane);
+  return pos0;
+}
+__device__ __forceinline__ double zt_mt_word(const uint32_t* mt, int pos0, double index) {
+  int p = pos0 + (int)index;
+  p = p < 0 ? 0 : (p > 2 * ZT_MT_N - 1 ? 2 * ZT_MT_N - 1 : p);      // (lanes past the end of a launch hold arbitrary counts)
+  uint32_t y = mt[p];
+  y ^= y >> 11;
+  y ^= (y << 7) & 0x9D2C5680u;
+  y ^= (y << 15) & 0xEFC60000u;
+  y ^= y >> 18;
+  return (double)y;
+}
+// End of a chunk, `total` words consumed so far in the launch (wave-uniform): once the last consumed word lies in the next
+// generation that one becomes current and its successor is produced.
+__device__ __forceinline__ void zt_mt_retire(uint32_t* mt, int& pos0, int total, int lane) {
+  if (pos0 + total > ZT_MT_N) {
+    __syncthreads();
+    for (int k = lane; k < ZT_MT_N; k += 64) mt[k] = mt[ZT_MT_N + k];
+    __syncthreads();
+    zt_mt_twist(mt, mt + ZT_MT_N, lane);
+    pos0 -= ZT_MT_N;
+  }
+}
+// End of the launch: what za_mt_next would have left -- the generation of the last consumed word and the index after it; an
+// instance that consumed nothing keeps its table (and stays unseeded if it was).
+__device__ __forceinline__ void zt_mt_end(const uint32_t* mt, int pos0, int total, uint32_t* gmt, int64_t gstride, uint32_t* gindex, int lane) {
+  if (total <= 0) return;
+  for (int k = lane; k < ZT_MT_N; k += 64) gmt[k * gstride] = mt[k];
+  if (lane == 0) *gindex = (uint32_t)(pos0 + total);
+}

@@ -41,6 +41,7 @@ from .emit import NOOP_CALLS, PURE_MATH1, PURE_MATH2, c_double
 from .program import Program, is_slider_name, is_spl_name
 
 WAVE = 64
+RNG_INDEX = "rand#index"      # hidden state: MT19937 outputs consumed since the start of the launch
 
 
 class Unsupported(Exception):
@@ -64,6 +65,7 @@ class N:
 
 BIN_OPS = {"+", "-", "*", "/", "<", "<=", ">", ">=", "==", "!=", "^", "|", "&", "~", "<<", ">>", "%"}
 CALL1 = set(PURE_MATH1) | {"sqr", "sign", "invsqrt"}
+MT_N, MT_M = 624, 397
 CALL2 = set(PURE_MATH2) | {"min", "max"}
 
 
@@ -80,6 +82,7 @@ class FrameGraph:
         self.written: List[str] = []
         self.scope: List[Dict[str, str]] = []
         self.depth = 0
+        self.rand_sites = 0
         self.ZERO, self.ONE = self.const(0.0), self.const(1.0)
 
     # -- node construction -------------------------------------------------------------------------------------------------
@@ -125,7 +128,7 @@ class FrameGraph:
         elif key == "samplesblock":
             raise Unsupported("@sample reads samplesblock (per host block)")
         else:
-            if (is_slider_name(key) is None and key not in ("srate", "midi_bus", "ext_midi_bus") and key not in self.p.vars):
+            if (is_slider_name(key) is None and key not in ("srate", "midi_bus", "ext_midi_bus", RNG_INDEX) and key not in self.p.vars):
                 raise Unsupported(f"unknown variable {key}")
             n = self.mk("var", name=key)
         self.varnodes[key] = n
@@ -141,7 +144,7 @@ class FrameGraph:
             k = is_spl_name(key)
             if k is not None and not 0 <= k < 64:
                 raise Unsupported("spl index out of range")
-            if k is None and key not in self.p.vars:
+            if k is None and key not in self.p.vars and key != RNG_INDEX:
                 raise Unsupported(f"unknown variable {key}")
             if key not in self.written:
                 self.written.append(key)
@@ -320,6 +323,17 @@ class FrameGraph:
             return self.op(fn, a, b)
         if fn == "__memtop" and not n.args:
             return self.const(float(self.p.memtop))
+        if fn == "rand" and len(n.args) <= 1:
+            # za_rand (csrc/zart.h): ((double)next_word * (1 / 4294967295)) * max(1, floor(arg)). The generator's position is a
+            # state like any other: the hidden counter RNG_INDEX = outputs consumed so far in this launch, stepped by every call
+            # that executes (if-conversion makes the step conditional); the word itself is a pure function of the position.
+            arg = self.ev(n.args[0]) if n.args else self.ONE
+            idx = self.read(RNG_INDEX)
+            self.write(RNG_INDEX, self.op("+", idx, self.ONE))
+            self.rand_sites += 1
+            fl = self.op("floor", arg)
+            m = self.sel(self.op("<", fl, self.ONE), self.ONE, fl)
+            return self.op("*", self.op("*", self.op("mtout", idx), self.const(1.0 / 4294967295.0)), m)
         raise Unsupported(f"builtin {fn} in @sample")
 
 
@@ -358,6 +372,7 @@ class Plan:
         self.invariants: List[N] = []
         self.inputs: List[N] = []
         self.stats: Dict[str, int] = {}
+        self.uses_rand = False
 
     # ------------------------------------------------------------------------------------------------------------------
     # numpy restatement of the staged algorithm (tests)
@@ -387,9 +402,12 @@ class Plan:
             caps[nm][tn:] = cur[nm]
             val[self.st[nm].i] = caps[nm]
 
-    def simulate(self, vars0: Dict[str, float], x: np.ndarray, sliders=None, srate=48000.0, spl0=None):
-        """x: [nch, frames] float32. vars0: name -> value before the launch (missing names are 0).
+    def simulate(self, vars0: Dict[str, float], x: np.ndarray, sliders=None, srate=48000.0, spl0=None, mt=None):
+        """x: [nch, frames] float32. vars0: name -> value before the launch (missing names are 0). mt: (randMT[624], randIndex)
+        before the launch for scripts that call rand(); self.mt_after holds the pair after it.
         Returns (y float32 [nch, frames], vars after {name: value}, spl after {k: value})."""
+        stream = MtStream(*(mt if mt is not None else (None, 0))) if self.uses_rand else None
+        _MT_CTX[0] = stream
         x = np.asarray(x, dtype=np.float32)
         frames = x.shape[1]
         sliders = np.zeros(64) if sliders is None else np.asarray(sliders, dtype=np.float64)
@@ -401,7 +419,7 @@ class Plan:
                 return float(sliders[k - 1])
             if name == "srate":
                 return float(srate)
-            if name in ("midi_bus", "ext_midi_bus"):
+            if name in ("midi_bus", "ext_midi_bus", RNG_INDEX):
                 return 0.0
             k = is_spl_name(name)
             if k is not None:
@@ -463,7 +481,8 @@ class Plan:
                                     loc[m.i] = np.broadcast_to(_np_op(m.op, [loc[a.i] if a.i in loc else val[a.i] for a in m.args]), (WAVE,))
                                 return [_truthy(np.broadcast_to(loc[c.i] if c.i in loc else val[c.i], (WAVE,))) for c in comp.conds]
 
-                            gs = conds_from([np.full(WAVE, carry[nm]) for nm in comp.names])
+                            prev = [np.full(WAVE, carry[nm]) for nm in comp.names]
+                            gs = conds_from(prev)
                             converged, iters = False, 0
                             while iters < SPEC_MAX:
                                 iters += 1
@@ -476,8 +495,12 @@ class Plan:
                                 states = _scan_exclusive(A, b, np.array([carry[nm] for nm in comp.names]))
                                 ng = conds_from(states)
                                 changed = any(bool(np.any(x[:tn] != y[:tn])) for x, y in zip(ng, gs))
-                                gs = ng
-                                if not changed:
+                                # a pattern that only still moves where both of its branches agree (a smoother sitting on its
+                                # target, a value on its clamp) leaves the states where they were: that is converged too
+                                moved = any(bool(np.any(np.abs(a[:tn] - b[:tn]) > SPEC_TOL * np.maximum(np.abs(a[:tn]), np.abs(b[:tn]))))
+                                            for a, b in zip(states, prev))
+                                gs, prev = ng, states
+                                if not (changed and moved):
                                     converged = True
                                     break
                             self.spec_log.append((tuple(comp.names), iters, converged))
@@ -494,12 +517,16 @@ class Plan:
                 for name in self.st:
                     v = val[self.outs[name].i]
                     carry[name] = np.float64(v if np.ndim(v) == 0 else v[last])
+                if stream is not None:
+                    stream.end_chunk(int(carry[RNG_INDEX]))
                 if f0 + WAVE >= frames:
                     for name, o in list(self.outs.items()) + [(f"spl{ch}", self.spl_out[ch]) for ch in range(self.nch)]:
                         v = val[o.i]
                         final_vals[name] = float(v if np.ndim(v) == 0 else v[last])
         vars_after = dict(vars0)
         spl_after = dict(spl_state)
+        self.mt_after = stream.state(int(final_vals.get(RNG_INDEX, 0))) if stream is not None else mt
+        final_vals.pop(RNG_INDEX, None)
         for name, v in final_vals.items():
             k = is_spl_name(name)
             if k is not None:
@@ -509,6 +536,69 @@ class Plan:
         return y, vars_after, spl_after
 
 
+class MtStream:
+    """MT19937 as za_mt_next (csrc/zart.h) runs it, in the form the kernels use: two generations side by side, the next one
+    produced from the current one in three lane-parallel phases (element k of a new generation needs new[k - 227] from
+    k = 227 on, so [0, 227), [227, 454) and [454, 623) are each parallel inside; element 623 closes the ring)."""
+
+    def __init__(self, table=None, mti: int = 0):
+        self.seeded_here = mti == 0
+        if mti == 0:                       # first use: seed, position at the end -> the first word comes from the next generation
+            t = np.zeros(MT_N, dtype=np.uint64)
+            prev = 0x4141F00D
+            t[0] = prev
+            for k in range(1, MT_N):
+                prev = (1812433253 * (prev ^ (prev >> 30)) + k) & 0xFFFFFFFF
+                t[k] = prev
+            self.cur, self.pos0 = t, MT_N
+        else:
+            self.cur, self.pos0 = np.asarray(table, dtype=np.uint64).copy(), int(mti)
+        self.orig = (None if table is None else np.asarray(table).copy(), int(mti))
+        self.nxt = self.twist(self.cur)
+
+    @staticmethod
+    def twist(cur):
+        nxt = np.zeros(MT_N, dtype=np.uint64)
+
+        def tw(a, b):
+            y = (a & 0x80000000) | (b & 0x7FFFFFFF)
+            return (y >> 1) ^ np.where(y & 1, 0x9908B0DF, 0).astype(np.uint64)
+
+        k = np.arange(0, 227)
+        nxt[k] = cur[k + MT_M] ^ tw(cur[k], cur[k + 1])
+        k = np.arange(227, 454)
+        nxt[k] = nxt[k - 227] ^ tw(cur[k], cur[k + 1])
+        k = np.arange(454, 623)
+        nxt[k] = nxt[k - 227] ^ tw(cur[k], cur[k + 1])
+        nxt[623] = nxt[396] ^ tw(cur[623:624], nxt[0:1])[0]
+        return nxt
+
+    def word(self, idx):
+        pos = self.pos0 + np.asarray(idx, dtype=np.int64)
+        pos = np.clip(pos, 0, 2 * MT_N - 1)
+        y = np.where(pos < MT_N, self.cur[np.minimum(pos, MT_N - 1)], self.nxt[np.maximum(pos - MT_N, 0)]).astype(np.uint64)
+        y ^= y >> 11
+        y ^= (y << 7) & 0x9D2C5680
+        y ^= (y << 15) & 0xEFC60000
+        y ^= y >> 18
+        return (y & 0xFFFFFFFF).astype(np.float64)
+
+    def end_chunk(self, total: int):
+        """`total` words consumed so far: retire a generation once the last consumed word lies in the next one."""
+        if self.pos0 + total > MT_N:
+            self.cur = self.nxt
+            self.nxt = self.twist(self.cur)
+            self.pos0 -= MT_N
+
+    def state(self, total: int):
+        if total <= 0:
+            return self.orig
+        return self.cur.astype(np.uint32), self.pos0 + total
+
+
+_MT_CTX: List[Optional[MtStream]] = [None]
+
+SPEC_TOL = 1.0e-13    # relative change of a state between two iterations below which it counts as settled (ZT_SPEC_TOL)
 SPEC_MAX = 8          # iterations of a switched recurrence before the chunk falls back to its serial loop (ZT_SPEC_MAX)
 
 
@@ -609,6 +699,8 @@ def _np_op(op, a):
         return y0 * (1.5 - (0.5 * a[0]) * (y0 * y0))
     if op == "atan2":
         return np.arctan2(a[0], a[1])
+    if op == "mtout":
+        return _MT_CTX[0].word(np.asarray(a[0]))
     if op in PURE_MATH1:
         f = {"sin": np.sin, "cos": np.cos, "sqrt": np.sqrt, "fabs": np.fabs, "floor": np.floor, "ceil": np.ceil, "asin": np.arcsin,
              "acos": np.arccos, "atan": np.arctan, "exp": np.exp, "log": np.log, "tan": np.tan, "log10": np.log10}[op]
@@ -673,6 +765,8 @@ def build_plan(prog: Program, nch: int) -> Plan:
         g.ev(st)
     if g.scope:
         raise AssertionError("scope leak")
+    if g.rand_sites * WAVE > MT_N:
+        raise Unsupported("more rand() calls per chunk than one generation of the generator holds")
     plan = Plan()
     plan.g, plan.nch = g, nch
     written = list(g.written)
@@ -843,6 +937,7 @@ def build_plan(prog: Program, nch: int) -> Plan:
         for ci in ready:
             comp_done[ci] = True
     plan.items = items
+    plan.uses_rand = RNG_INDEX in plan.outs
     plan.stats = {
         "nodes": len(order), "uniform": len(plan.uniform), "par": sum(1 for it in items if it[0] == "par"),
         "shift": sum(1 for it in items if it[0] == "shift"),
@@ -854,7 +949,7 @@ def build_plan(prog: Program, nch: int) -> Plan:
         "serial_loops": sum(1 for it in items if it[0] == "serial"),
         "serial_chains": sum(len(it[1]) for it in items if it[0] == "serial"),
         "serial_ops": sum(len([m for m in c.members if m.kind != "st"]) for it in items if it[0] == "serial" for c in it[1]),
-        "states": len(plan.st), "written": len(plan.outs),
+        "states": len(plan.st), "written": len(plan.outs), "rand_sites": g.rand_sites,
     }
     return plan
 
@@ -1052,6 +1147,8 @@ def _expr(op: str, a: List[str]) -> str:
         return f"(za_truthy({a[0]}) ? {a[1]} : {a[2]})"
     if op in PURE_MATH1:
         return f"{PURE_MATH1[op]}({a[0]})"
+    if op == "mtout":
+        return f"zt_mt_word(zt_mt, zt_pos0, {a[0]})"
     raise AssertionError(op)
 
 
@@ -1071,7 +1168,7 @@ def emit_hip(plan: Plan, prog: Program, kernel_macro: str = "ZA_KERNEL(tpar)") -
             return f"b.sliders[{k - 1} * b.sl_se + inst * b.sl_si]"
         if name == "srate":
             return "b.srate"
-        if name in ("midi_bus", "ext_midi_bus"):
+        if name in ("midi_bus", "ext_midi_bus", RNG_INDEX):
             return "0.0"
         k = is_spl_name(name)
         if k is not None:
@@ -1090,6 +1187,7 @@ def emit_hip(plan: Plan, prog: Program, kernel_macro: str = "ZA_KERNEL(tpar)") -
     L.append("#ifndef ZT_SPEC_MAX")
     L.append(f"#define ZT_SPEC_MAX {SPEC_MAX}")
     L.append("#endif")
+    L.append(f"#define ZT_SPEC_TOL {SPEC_TOL!r}")
     L.append("#ifndef ZT_UNI")
     L.append("#define ZT_UNI(x) zt_uniform(x)")
     L.append("#endif")
@@ -1098,6 +1196,10 @@ def emit_hip(plan: Plan, prog: Program, kernel_macro: str = "ZA_KERNEL(tpar)") -
     L.append("  const int64_t inst = blockIdx.x;")
     L.append("  const int64_t frames = a.frames;")
     L.append("  if (frames <= 0 || inst >= b.n_inst) return;")
+    if plan.uses_rand:
+        L.append("  __shared__ uint32_t zt_mt[2 * ZT_MT_N];      // rand(): current and next generation of the instance's MT19937")
+        L.append("  uint32_t* const zt_gmt = b.mt + inst * b.mt_si;")
+        L.append("  int zt_pos0 = zt_mt_begin(zt_mt, zt_gmt, b.mt_se, b.mti[inst], lane);")
     L.append("  // per launch: invariants and everything that depends on them only")
     for n in plan.uniform:
         if n.kind == "const":
@@ -1192,7 +1294,7 @@ def emit_hip(plan: Plan, prog: Program, kernel_macro: str = "ZA_KERNEL(tpar)") -
             L.append(f"    // switched recurrences (affine once their state-dependent conditions are fixed), solved by iterating the")
             L.append(f"    // condition pattern to its fixed point: {', '.join(names)}")
             for nm in names:
-                L.append(f"    double s{plan.st[nm].i} = {cname[nm]};")
+                L.append(f"    double s{plan.st[nm].i} = {cname[nm]}, p{plan.st[nm].i} = {cname[nm]};")
             gname = {}
             for c in comps:
                 for k, gn in enumerate(c.gnodes):
@@ -1242,10 +1344,14 @@ def emit_hip(plan: Plan, prog: Program, kernel_macro: str = "ZA_KERNEL(tpar)") -
             for c in comps:
                 slice_eval(c, "      ", "const bool h")
             diffs = " || ".join(f"(h{gname[gn.i]} != {gname[gn.i]})" for c in comps for gn in c.gnodes)
-            L.append(f"      sch{gid} = __ballot(valid && ({diffs})) != 0ull;")
+            moved = " || ".join(f"(fabs(s{plan.st[nm].i} - p{plan.st[nm].i}) > ZT_SPEC_TOL * fmax(fabs(s{plan.st[nm].i}), fabs(p{plan.st[nm].i})))" for nm in names)
+            L.append("      // settled = the pattern reproduced itself, or it only still moves where its branches agree (states unchanged)")
+            L.append(f"      sch{gid} = (__ballot(valid && ({diffs})) != 0ull) && (__ballot(valid && ({moved})) != 0ull);")
             for c in comps:
                 for gn in c.gnodes:
                     L.append(f"      {gname[gn.i]} = h{gname[gn.i]};")
+            for nm in names:
+                L.append(f"      p{plan.st[nm].i} = s{plan.st[nm].i};")
             L.append(f"    }} while (sch{gid} && ++sit{gid} < ZT_SPEC_MAX);")
             L.append(f"    if (sch{gid}) {{   // no fixed point within the budget (a pattern that keeps moving along the chunk): the serial loop")
             serial_loop(comps, "      ")
@@ -1265,12 +1371,17 @@ def emit_hip(plan: Plan, prog: Program, kernel_macro: str = "ZA_KERNEL(tpar)") -
     for name, c in cname.items():
         o = plan.outs[name]
         L.append(f"    {c} = {ref(o) if (o.uniform or o.kind == 'const') else f'zt_readlane(n{o.i}, last)'};")
+    if plan.uses_rand:
+        L.append(f"    zt_mt_retire(zt_mt, zt_pos0, (int){cname[RNG_INDEX]}, lane);")
     L.append("    if (f0 + 64 >= frames && lane == last) {   // the launch's last frame: leave every written variable as the script would")
     finals = list(plan.outs.items()) + [(f"spl{ch}", plan.spl_out[ch]) for ch in range(plan.nch) if f"spl{ch}" not in plan.outs]
     for name, o in finals:
-        L.append(f"      {dst(name)} = {ref(o)};")
+        if name != RNG_INDEX:
+            L.append(f"      {dst(name)} = {ref(o)};")
     L.append("    }")
     L.append("  }")
+    if plan.uses_rand:
+        L.append(f"  zt_mt_end(zt_mt, zt_pos0, (int){cname[RNG_INDEX]}, zt_gmt, b.mt_se, b.mti + inst, lane);")
     L.append("}")
     L.append("static int32_t za_fast_applies(const ZabBatch* b, const ZabAudio* a) { (void)b; return a->frames > 0 ? 1 : 0; }")
     L.append("static hipError_t za_launch_fast(const ZabBatch* b, const ZabAudio* a, hipStream_t st) {")
