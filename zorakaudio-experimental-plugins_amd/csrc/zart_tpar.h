@@ -43,11 +43,27 @@ __device__ __forceinline__ double zt_dpp(double v, double keep) {
   return __builtin_bit_cast(double, t);
 }
 
+// the same with every row enabled, lanes without a source receive 0: no `old` value has to be put into the destination first
+template <int CTRL>
+__device__ __forceinline__ double zt_dppz(double v) {
+  int2 t = __builtin_bit_cast(int2, v);
+  t.x = __builtin_amdgcn_mov_dpp(t.x, CTRL, 0xF, 0xF, true);
+  t.y = __builtin_amdgcn_mov_dpp(t.y, CTRL, 0xF, 0xF, true);
+  return __builtin_bit_cast(double, t);
+}
+
 // value of the previous lane; lane 0 receives `first` (the value carried in from the previous chunk)
 __device__ __forceinline__ double zt_shift1(double v, double first) { return zt_dpp<ZT_WAVE_SHR1, 0xF>(v, first); }
 
 // ---- y[t] = a[t] y[t-1] + b[t]: on return (a, b) of lane t is the map from the state before the chunk to the state after
 // frame t, i.e. y[t] = a * y_in + b --------------------------------------------------------------------------------------
+#define ZT_SCAN1_ROW(CTRL)                                        \
+  {                                                              \
+    const double as_ = zt_dpp<CTRL, 0xF>(a, 1.0);                \
+    const double bs_ = zt_dppz<CTRL>(b);                         \
+    b = __builtin_fma(a, bs_, b);                                \
+    a = a * as_;                                                 \
+  }
 #define ZT_SCAN1_STEP(CTRL, ROWS)                                \
   {                                                              \
     const double as_ = zt_dpp<CTRL, ROWS>(a, 1.0);               \
@@ -56,14 +72,49 @@ __device__ __forceinline__ double zt_shift1(double v, double first) { return zt_
     a = a * as_;                                                 \
   }
 __device__ __forceinline__ void zt_scan1(double& a, double& b) {
-  ZT_SCAN1_STEP(ZT_ROW_SHR(1), 0xF)
-  ZT_SCAN1_STEP(ZT_ROW_SHR(2), 0xF)
-  ZT_SCAN1_STEP(ZT_ROW_SHR(4), 0xF)
-  ZT_SCAN1_STEP(ZT_ROW_SHR(8), 0xF)
+  ZT_SCAN1_ROW(ZT_ROW_SHR(1))
+  ZT_SCAN1_ROW(ZT_ROW_SHR(2))
+  ZT_SCAN1_ROW(ZT_ROW_SHR(4))
+  ZT_SCAN1_ROW(ZT_ROW_SHR(8))
   ZT_SCAN1_STEP(ZT_ROW_BCAST15, 0xA)
   ZT_SCAN1_STEP(ZT_ROW_BCAST31, 0xC)
 }
 #undef ZT_SCAN1_STEP
+#undef ZT_SCAN1_ROW
+
+// ---- the same recurrence with a coefficient that is constant over the launch: only b moves through the lanes. The powers
+// a^2, a^4, a^8, a^16 are wave-uniform, the position-dependent weight w = a^((lane & 15) + 1) of the two cross-row steps is a
+// per-lane constant of the coefficient (one LDS row per distinct coefficient, zt_pow_row fills it once per launch). The state
+// carried into the chunk is injected at lane 0 (b[0] += a * y_in), so the scan itself delivers y[t] -- the DDT kernel's scheme.
+struct ZtPow { double a2, a4, a8, a16; };
+__device__ __forceinline__ double zt_pow_row(double a, int lane) {   // a^((lane & 15) + 1)
+  double r = 1.0, p = a;
+  const int e = (lane & 15) + 1;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) { r = ((e >> k) & 1) ? r * p : r; p = p * p; }
+  return r;
+}
+__device__ __forceinline__ double zt_scan1_inv(double b, double a, const ZtPow& q, double w, double y_in, int lane) {
+  b = lane == 0 ? __builtin_fma(a, y_in, b) : b;
+  b = __builtin_fma(a, zt_dppz<ZT_ROW_SHR(1)>(b), b);
+  b = __builtin_fma(q.a2, zt_dppz<ZT_ROW_SHR(2)>(b), b);
+  b = __builtin_fma(q.a4, zt_dppz<ZT_ROW_SHR(4)>(b), b);
+  b = __builtin_fma(q.a8, zt_dppz<ZT_ROW_SHR(8)>(b), b);
+  b = __builtin_fma(w, zt_dpp<ZT_ROW_BCAST15, 0xA>(b, 0.0), b);
+  b = __builtin_fma(lane >= 48 ? w * q.a16 : w, zt_dpp<ZT_ROW_BCAST31, 0xC>(b, 0.0), b);
+  return b;
+}
+// a == 1: a running sum
+__device__ __forceinline__ double zt_scan1_sum(double b, double y_in, int lane) {
+  b = lane == 0 ? b + y_in : b;
+  b += zt_dppz<ZT_ROW_SHR(1)>(b);
+  b += zt_dppz<ZT_ROW_SHR(2)>(b);
+  b += zt_dppz<ZT_ROW_SHR(4)>(b);
+  b += zt_dppz<ZT_ROW_SHR(8)>(b);
+  b += zt_dpp<ZT_ROW_BCAST15, 0xA>(b, 0.0);
+  b += zt_dpp<ZT_ROW_BCAST31, 0xC>(b, 0.0);
+  return b;
+}
 
 // ---- two coupled states: y[t] = A[t] y[t-1] + b[t], A = [a00 a01; a10 a11] ---------------------------------------------
 struct ZtMap2 { double a00, a01, a10, a11, b0, b1; };

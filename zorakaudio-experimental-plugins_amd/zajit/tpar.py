@@ -1208,6 +1208,20 @@ def emit_hip(plan: Plan, prog: Program, kernel_macro: str = "ZA_KERNEL(tpar)") -
             L.append(f"  const double u{n.i} = {inv_src(n.name)};   // {n.name}")
         else:
             L.append(f"  const double u{n.i} = ZT_UNI({_expr(n.op, [ref(x) for x in n.args])});")
+    # recurrences whose coefficient is constant over the launch: one LDS row of per-lane weights per distinct coefficient
+    inv_coefs: List[N] = []
+    for it in plan.items:
+        if it[0] == "scan" and len(it[1].names) == 1:
+            a = it[1].A[0][0]
+            if a.uniform and a.kind != "const" and a not in inv_coefs and not os.environ.get("ZA_TPAR_NO_INVSCAN"):
+                inv_coefs.append(a)
+    if inv_coefs:
+        L.append(f"  __shared__ double zt_w[{len(inv_coefs)} * 64];      // a^((lane & 15) + 1) per launch-constant coefficient")
+        L.append(f"  __shared__ double zt_q[{len(inv_coefs)} * 4];       // a^2, a^4, a^8, a^16")
+        for k, a in enumerate(inv_coefs):
+            L.append(f"  zt_w[{k} * 64 + lane] = zt_pow_row({ref(a)}, lane);")
+            L.append(f"  if (lane == 0) {{ const double p2 = {ref(a)} * {ref(a)}, p4 = p2 * p2, p8 = p4 * p4; zt_q[{k} * 4] = p2; zt_q[{k} * 4 + 1] = p4; zt_q[{k} * 4 + 2] = p8; zt_q[{k} * 4 + 3] = p8 * p8; }}")
+        L.append("  __syncthreads();")
     L.append("  // state carried from frame to frame (wave-uniform)")
     for name, c in cname.items():
         L.append(f"  double {c} = {inv_src(name)};   // {name}")
@@ -1258,8 +1272,59 @@ def emit_hip(plan: Plan, prog: Program, kernel_macro: str = "ZA_KERNEL(tpar)") -
                 L.append(f"{ind}  y{plan.st[nm].i} = q{plan.st[nm].i};")
         L.append(f"{ind}}}")
 
+    # Values leave the registers as early as possible: a state's carry is taken (v_readlane at the chunk's last frame) as soon
+    # as both its recurrence and its new value exist, and the values a launch must leave in vars[] -- needed in the launch's
+    # last chunk only -- are stored in small conditional batches right after they are computed, instead of all living to the
+    # end of the chunk body (144 written variables would be 288 registers per lane there).
+    if inv_coefs:
+        L.append("    int zo; asm volatile(\"s_mov_b32 %0, 0\" : \"=s\"(zo));   // opaque 0: keeps the table reads inside the iteration")
+    L.append("    const bool fin = f0 + 64 >= frames;   // the launch's last chunk: its last frame leaves every written variable as the script would")
+    avail = {n.i for n in plan.inputs}
+    unit_done: set = set()
+    carried: set = set()
+    stored: set = set()
+    finals = [(name, o) for name, o in plan.outs.items() if name != RNG_INDEX]
+    finals += [(f"spl{ch}", plan.spl_out[ch]) for ch in range(plan.nch) if f"spl{ch}" not in plan.outs]
+    pending: List[tuple] = []
+
+    def ready(o: N) -> bool:
+        return o.uniform or o.kind == "const" or o.i in avail
+
+    def retire(final: bool = False):
+        for name, c in cname.items():
+            o = plan.outs[name]
+            if name not in carried and name in unit_done and ready(o):
+                carried.add(name)
+                L.append(f"    {c} = {ref(o) if (o.uniform or o.kind == 'const') else f'zt_readlane(n{o.i}, last)'};")
+        for name, o in finals:
+            if name not in stored and ready(o) and (final or not (o.uniform or o.kind == "const")):
+                stored.add(name)
+                pending.append((name, o))
+        if pending and (final or len(pending) >= 12):
+            L.append("    if (fin && lane == last) {")
+            for name, o in pending:
+                L.append(f"      {dst(name)} = {ref(o)};")
+            L.append("    }")
+            pending.clear()
+
     for gid, it in enumerate(plan.items):
         kind = it[0]
+        if kind == "par":
+            avail.add(it[1].i)
+        elif kind == "shift":
+            avail.add(plan.st[it[1]].i)
+            unit_done.add(it[1])
+        elif kind == "scan":
+            for nm in it[1].names:
+                avail.add(plan.st[nm].i)
+                unit_done.add(nm)
+        else:
+            for c in it[1]:
+                for nm in c.names:
+                    avail.add(plan.st[nm].i)
+                    unit_done.add(nm)
+        if gid:
+            pass
         if kind == "par":
             n = it[1]
             L.append(f"    const double n{n.i} = {_expr(n.op, [ref(x) for x in n.args])};")
@@ -1268,7 +1333,17 @@ def emit_hip(plan: Plan, prog: Program, kernel_macro: str = "ZA_KERNEL(tpar)") -
             L.append(f"    const double n{plan.st[name].i} = zt_shift1({ref(plan.outs[name])}, {cname[name]});   // {name}[t-1]")
         elif kind == "scan":
             c: Component = it[1]
-            if len(c.names) == 1:
+            if len(c.names) == 1 and c.A[0][0].kind == "const" and c.A[0][0].val == 1.0:
+                nm = c.names[0]
+                s = plan.st[nm].i
+                L.append(f"    const double n{s} = zt_shift1(zt_scan1_sum({ref(c.b[0])}, {cname[nm]}, lane), {cname[nm]});   // {nm}: running sum")
+            elif len(c.names) == 1 and c.A[0][0] in inv_coefs:
+                nm = c.names[0]
+                s = plan.st[nm].i
+                k = inv_coefs.index(c.A[0][0])
+                L.append(f"    const ZtPow sq{s} = {{zt_q[{k} * 4 + zo], zt_q[{k} * 4 + 1 + zo], zt_q[{k} * 4 + 2 + zo], zt_q[{k} * 4 + 3 + zo]}};   // {nm}: constant-coefficient recurrence")
+                L.append(f"    const double n{s} = zt_shift1(zt_scan1_inv({ref(c.b[0])}, {ref(c.A[0][0])}, sq{s}, zt_w[{k} * 64 + lane + zo], {cname[nm]}, lane), {cname[nm]});")
+            elif len(c.names) == 1:
                 nm = c.names[0]
                 s = plan.st[nm].i
                 L.append(f"    double sa{s} = {ref(c.A[0][0])}, sb{s} = {ref(c.b[0])};   // {nm}: affine recurrence")
@@ -1364,21 +1439,14 @@ def emit_hip(plan: Plan, prog: Program, kernel_macro: str = "ZA_KERNEL(tpar)") -
                 L.append(f"    const double n{s} = s{s};")
         else:
             raise AssertionError(kind)
+        retire()
+    retire(final=True)
     L.append("    if (valid) {")
     for ch in range(plan.nch):
         L.append(f"      out_[{ch} * a.frame_stride + f0 + lane] = (float){ref(plan.spl_out[ch])};")
     L.append("    }")
-    for name, c in cname.items():
-        o = plan.outs[name]
-        L.append(f"    {c} = {ref(o) if (o.uniform or o.kind == 'const') else f'zt_readlane(n{o.i}, last)'};")
     if plan.uses_rand:
         L.append(f"    zt_mt_retire(zt_mt, zt_pos0, (int){cname[RNG_INDEX]}, lane);")
-    L.append("    if (f0 + 64 >= frames && lane == last) {   // the launch's last frame: leave every written variable as the script would")
-    finals = list(plan.outs.items()) + [(f"spl{ch}", plan.spl_out[ch]) for ch in range(plan.nch) if f"spl{ch}" not in plan.outs]
-    for name, o in finals:
-        if name != RNG_INDEX:
-            L.append(f"      {dst(name)} = {ref(o)};")
-    L.append("    }")
     L.append("  }")
     if plan.uses_rand:
         L.append(f"  zt_mt_end(zt_mt, zt_pos0, (int){cname[RNG_INDEX]}, zt_gmt, b.mt_se, b.mti + inst, lane);")
