@@ -211,3 +211,67 @@ __device__ __forceinline__ void zt_mt_end(const uint32_t* mt, int pos0, int tota
   for (int k = lane; k < ZT_MT_N; k += 64) gmt[k * gstride] = mt[k];
   if (lane == 0) *gindex = (uint32_t)(pos0 + total);
 }
+
+// ---- coupled pair with a matrix that is constant over the launch (biquads): only b moves through the lanes. Per distinct
+// matrix the launch keeps A^2, A^4, A^8 (wave-uniform, 12 doubles of LDS) and two per-lane weight matrices: WA = A^((lane & 15)
+// + 1) for the row_bcast15 step (rows 1 and 3) and WB = A^(lane - 31) for the row_bcast31 step (rows 2 and 3). The state carried
+// into the chunk is injected at lane 0.
+struct ZtMat2 { double m00, m01, m10, m11; };
+__device__ __forceinline__ ZtMat2 zt_mat_mul(const ZtMat2& x, const ZtMat2& y) {
+  ZtMat2 r;
+  r.m00 = __builtin_fma(x.m00, y.m00, x.m01 * y.m10); r.m01 = __builtin_fma(x.m00, y.m01, x.m01 * y.m11);
+  r.m10 = __builtin_fma(x.m10, y.m00, x.m11 * y.m10); r.m11 = __builtin_fma(x.m10, y.m01, x.m11 * y.m11);
+  return r;
+}
+__device__ __forceinline__ ZtMat2 zt_mat_pow(ZtMat2 p, int e) {      // e >= 0
+  ZtMat2 r = {1.0, 0.0, 0.0, 1.0};
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { if ((e >> k) & 1) r = zt_mat_mul(r, p); p = zt_mat_mul(p, p); }
+  return r;
+}
+// fills tab[0..12) with A^2, A^4, A^8 and tab[12 + j * 64 + lane], j = 0..7, with WA (4 rows) and WB (4 rows)
+__device__ __forceinline__ void zt_mat_table(double* tab, const ZtMat2& a, int lane) {
+  const ZtMat2 a2 = zt_mat_mul(a, a), a4 = zt_mat_mul(a2, a2), a8 = zt_mat_mul(a4, a4);
+  if (lane == 0) {
+    tab[0] = a2.m00; tab[1] = a2.m01; tab[2] = a2.m10; tab[3] = a2.m11;
+    tab[4] = a4.m00; tab[5] = a4.m01; tab[6] = a4.m10; tab[7] = a4.m11;
+    tab[8] = a8.m00; tab[9] = a8.m01; tab[10] = a8.m10; tab[11] = a8.m11;
+  }
+  const ZtMat2 wa = zt_mat_pow(a, (lane & 15) + 1), wb = zt_mat_pow(a, lane >= 32 ? lane - 31 : 0);
+  double* t = tab + 12 + lane;
+  t[0] = wa.m00; t[64] = wa.m01; t[128] = wa.m10; t[192] = wa.m11;
+  t[256] = wb.m00; t[320] = wb.m01; t[384] = wb.m10; t[448] = wb.m11;
+}
+#define ZT_MAT_TABLE_DOUBLES (12 + 8 * 64)
+#define ZT_SCAN2I_ROW(CTRL, M)                                                                          \
+  {                                                                                                     \
+    const double t0 = zt_dppz<CTRL>(b0), t1 = zt_dppz<CTRL>(b1);                                        \
+    b0 = __builtin_fma((M).m00, t0, __builtin_fma((M).m01, t1, b0));                                    \
+    b1 = __builtin_fma((M).m10, t0, __builtin_fma((M).m11, t1, b1));                                    \
+  }
+#define ZT_SCAN2I_STEP(CTRL, ROWS, M)                                                                   \
+  {                                                                                                     \
+    const double t0 = zt_dpp<CTRL, ROWS>(b0, 0.0), t1 = zt_dpp<CTRL, ROWS>(b1, 0.0);                    \
+    b0 = __builtin_fma((M).m00, t0, __builtin_fma((M).m01, t1, b0));                                    \
+    b1 = __builtin_fma((M).m10, t0, __builtin_fma((M).m11, t1, b1));                                    \
+  }
+// tab: the matrix's table as filled by zt_mat_table; `zo` = opaque 0 (keeps the reads inside the caller's iteration)
+__device__ __forceinline__ void zt_scan2_inv(double& b0, double& b1, const ZtMat2& a, const double* tab, int zo, double y0_in,
+                                             double y1_in, int lane) {
+  if (lane == 0) {
+    b0 = __builtin_fma(a.m00, y0_in, __builtin_fma(a.m01, y1_in, b0));
+    b1 = __builtin_fma(a.m10, y0_in, __builtin_fma(a.m11, y1_in, b1));
+  }
+  const double* u = tab + zo;
+  const ZtMat2 a2 = {u[0], u[1], u[2], u[3]}, a4 = {u[4], u[5], u[6], u[7]}, a8 = {u[8], u[9], u[10], u[11]};
+  ZT_SCAN2I_ROW(ZT_ROW_SHR(1), a)
+  ZT_SCAN2I_ROW(ZT_ROW_SHR(2), a2)
+  ZT_SCAN2I_ROW(ZT_ROW_SHR(4), a4)
+  ZT_SCAN2I_ROW(ZT_ROW_SHR(8), a8)
+  const double* w = u + 12 + lane;
+  const ZtMat2 wa = {w[0], w[64], w[128], w[192]}, wb = {w[256], w[320], w[384], w[448]};
+  ZT_SCAN2I_STEP(ZT_ROW_BCAST15, 0xA, wa)
+  ZT_SCAN2I_STEP(ZT_ROW_BCAST31, 0xC, wb)
+}
+#undef ZT_SCAN2I_ROW
+#undef ZT_SCAN2I_STEP

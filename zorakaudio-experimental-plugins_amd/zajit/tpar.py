@@ -1215,6 +1215,21 @@ def emit_hip(plan: Plan, prog: Program, kernel_macro: str = "ZA_KERNEL(tpar)") -
             a = it[1].A[0][0]
             if a.uniform and a.kind != "const" and a not in inv_coefs and not os.environ.get("ZA_TPAR_NO_INVSCAN"):
                 inv_coefs.append(a)
+    # coupled pairs with a launch-constant matrix (biquads): one table per distinct matrix, within an LDS budget that still
+    # lets four wavefronts share a CU (one per SIMD, the 1024-instance case)
+    inv_mats: List[tuple] = []
+    budget = 36 * 1024 - len(inv_coefs) * (64 + 4) * 8 - (2 * 624 * 4 if plan.uses_rand else 0)
+    for it in plan.items:
+        if it[0] == "scan" and len(it[1].names) == 2 and not os.environ.get("ZA_TPAR_NO_INVSCAN"):
+            key = tuple(x for row in it[1].A for x in row)
+            if all(x.uniform or x.kind == "const" for x in key) and key not in inv_mats and (len(inv_mats) + 1) * (12 + 8 * 64) * 8 <= budget:
+                inv_mats.append(key)
+    if inv_mats:
+        L.append(f"  __shared__ double zt_m[{len(inv_mats)} * ZT_MAT_TABLE_DOUBLES];      // per launch-constant 2 x 2 matrix: powers and per-lane weights")
+        for k, key in enumerate(inv_mats):
+            L.append(f"  {{ const ZtMat2 am = {{{ref(key[0])}, {ref(key[1])}, {ref(key[2])}, {ref(key[3])}}}; zt_mat_table(zt_m + {k} * ZT_MAT_TABLE_DOUBLES, am, lane); }}")
+        if not inv_coefs:
+            L.append("  __syncthreads();")
     if inv_coefs:
         L.append(f"  __shared__ double zt_w[{len(inv_coefs)} * 64];      // a^((lane & 15) + 1) per launch-constant coefficient")
         L.append(f"  __shared__ double zt_q[{len(inv_coefs)} * 4];       // a^2, a^4, a^8, a^16")
@@ -1227,12 +1242,22 @@ def emit_hip(plan: Plan, prog: Program, kernel_macro: str = "ZA_KERNEL(tpar)") -
         L.append(f"  double {c} = {inv_src(name)};   // {name}")
     L.append(f"  const float* const in_ = a.in + inst * {plan.nch} * a.frame_stride;")
     L.append(f"  float* const out_ = a.out + inst * {plan.nch} * a.frame_stride;")
+    L.append("  // the audio of a chunk is read one iteration ahead, so that its HBM latency is hidden behind the previous chunk's work")
+    for n in plan.inputs:
+        L.append(f"  float x{n.i} = lane < frames ? in_[{int(n.val)} * a.frame_stride + lane] : 0.0f;")
     L.append("  for (int64_t f0 = 0; f0 < frames; f0 += 64) {")
     L.append("    const int tn = (int)(frames - f0 < 64 ? frames - f0 : 64);")
     L.append("    const int last = tn - 1;")
     L.append("    const bool valid = lane < tn;")
     for n in plan.inputs:
-        L.append(f"    const double n{n.i} = valid ? (double)in_[{int(n.val)} * a.frame_stride + f0 + lane] : 0.0;")
+        L.append(f"    const double n{n.i} = (double)x{n.i};")
+    L.append("    if (f0 + 64 + lane < frames) {")
+    for n in plan.inputs:
+        L.append(f"      x{n.i} = in_[{int(n.val)} * a.frame_stride + f0 + 64 + lane];")
+    L.append("    } else {")
+    for n in plan.inputs:
+        L.append(f"      x{n.i} = 0.0f;")
+    L.append("    }")
 
     def serial_loop(comps: List[Component], ind: str):
         """64 uniform steps; leaves the state before each frame in k<st> of that frame's lane."""
@@ -1276,7 +1301,7 @@ def emit_hip(plan: Plan, prog: Program, kernel_macro: str = "ZA_KERNEL(tpar)") -
     # as both its recurrence and its new value exist, and the values a launch must leave in vars[] -- needed in the launch's
     # last chunk only -- are stored in small conditional batches right after they are computed, instead of all living to the
     # end of the chunk body (144 written variables would be 288 registers per lane there).
-    if inv_coefs:
+    if inv_coefs or inv_mats:
         L.append("    int zo; asm volatile(\"s_mov_b32 %0, 0\" : \"=s\"(zo));   // opaque 0: keeps the table reads inside the iteration")
     L.append("    const bool fin = f0 + 64 >= frames;   // the launch's last chunk: its last frame leaves every written variable as the script would")
     avail = {n.i for n in plan.inputs}
@@ -1349,6 +1374,15 @@ def emit_hip(plan: Plan, prog: Program, kernel_macro: str = "ZA_KERNEL(tpar)") -
                 L.append(f"    double sa{s} = {ref(c.A[0][0])}, sb{s} = {ref(c.b[0])};   // {nm}: affine recurrence")
                 L.append(f"    zt_scan1(sa{s}, sb{s});")
                 L.append(f"    const double n{s} = zt_shift1(__builtin_fma(sa{s}, {cname[nm]}, sb{s}), {cname[nm]});")
+            elif len(c.names) == 2 and tuple(x for row in c.A for x in row) in inv_mats:
+                n0, n1 = c.names
+                s0, s1 = plan.st[n0].i, plan.st[n1].i
+                k = inv_mats.index(tuple(x for row in c.A for x in row))
+                L.append(f"    double sb{s0} = {ref(c.b[0])}, sb{s1} = {ref(c.b[1])};   // {n0}, {n1}: coupled pair, launch-constant matrix")
+                L.append(f"    {{ const ZtMat2 am = {{{ref(c.A[0][0])}, {ref(c.A[0][1])}, {ref(c.A[1][0])}, {ref(c.A[1][1])}}};")
+                L.append(f"      zt_scan2_inv(sb{s0}, sb{s1}, am, zt_m + {k} * ZT_MAT_TABLE_DOUBLES, zo, {cname[n0]}, {cname[n1]}, lane); }}")
+                L.append(f"    const double n{s0} = zt_shift1(sb{s0}, {cname[n0]});")
+                L.append(f"    const double n{s1} = zt_shift1(sb{s1}, {cname[n1]});")
             else:
                 n0, n1 = c.names
                 s0, s1 = plan.st[n0].i, plan.st[n1].i
