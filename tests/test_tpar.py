@@ -49,18 +49,21 @@ def test_recurrence_zoo_classification():
         elif it[0] == "shift":
             kinds[(it[1],)] = "shift"
     assert kinds[("xpL",)] == kinds[("xpR",)] == kinds[("lastsign",)] == "shift"               # delayed signals
-    for one in ("dcL", "dcR", "lpL", "lpR", "cnt", "flips", "heldv", "acc", "tv"):            # affine, one state
+    for one in ("dcL", "dcR", "lpL", "lpR", "cnt", "flips", "heldv", "tv"):                   # affine, one state
         assert kinds[(one,)] == "scan", one
     assert kinds[("z1", "z2")] == "scan" and kinds[("swa", "swb")] == "scan"                    # coupled affine pairs
-    for one in ("gr", "pk", "hold", "ph", "__fnlocal__sample__follow__e"):                    # state-dependent conditions
+    for one in ("gr", "pk", "hold", "__fnlocal__sample__follow__e"):                          # state-dependent conditions
         assert kinds[(one,)] == "spec", one
-    assert plan.stats["spec_loops"] == 2            # five chains share two iterations
-    assert plan.stats["serial_loops"] == 0
+    # y = y + (fractional step) keeps its serial order: its rounding never decays and scripts test such sums against the
+    # values they are meant to land on (tpar._persistent_rounding); the integer counters above are exact in any order
+    for one in ("ph", "acc"):
+        assert kinds[(one,)] == "serial", one
+    assert plan.stats["spec_loops"] == 2 and plan.stats["serial_loops"] >= 1
 
 
 def test_switched_recurrences_fall_back_to_the_serial_loop(monkeypatch):
-    """With the iteration budget cut to one pass most chunks of the phase accumulator do not reach their fixed point; the
-    serial loop takes over for those chunks and the result is unchanged."""
+    """With the iteration budget cut to one pass some chunks of the peak hold and the smoothers do not reach their fixed point;
+    the serial loop takes over for those chunks and the result is unchanged."""
     from zajit import tpar
     plan, _ = _plan("fx_dynkat")
     g = load_golden("fx_dynkat_default")
@@ -197,17 +200,8 @@ def test_tpar_kernel_tracks_generic_kernel_over_a_long_run_and_across_launches(l
     err = np.abs(got.astype(np.float64) - want.astype(np.float64)).max()
     print(f"{leaf}: tpar vs generic over {frames} frames: {dbfs(err):.1f} dBFS")
     assert err <= AUDIO_EPS
-    # State: within 1e-8 -- except at a knife edge. A script that accumulates a fractional step and compares the sum with a
-    # threshold (BedRock's `burstPos += burstInc; burstPos < 1 ? ...`) takes its branch one frame earlier or later when the sum
-    # passes the threshold within rounding distance, and the scan's sum is the serial sum re-associated. The audio moves by
-    # one window step at its zero (far below 1e-5); a temporary assigned in that branch keeps the previous step's value.
-    # At most two such variables per instance are tolerated here, and they are printed.
     for i in range(n):
-        bad = [(nm, float(a), float(b)) for nm, a, b in zip(names, got_v[i], want_v[i])
-               if not (abs(a - b) <= SCALAR_EPS or a == b or (np.isnan(a) and np.isnan(b)))]
-        if bad:
-            print(f"{leaf}[{i}] knife-edge variables: {bad}")
-        assert len(bad) <= 2 and all(abs(a - b) <= 1e-3 for _, a, b in bad), bad
+        assert_state_close(names, got_v[i], want_v[i], what=f"{leaf} vars[{i}]")
 
 
 @pytest.mark.gpu

@@ -46,6 +46,13 @@ def main() -> int:
             run_one(zabatch, args, leaf, meta, nch, row, cap)
         rows.append(row)
         print(json.dumps(row), flush=True)
+    base = ROOT / "profiles" / "r01_catalog_sweep.json"          # previous round's sweep: the ratio per leaf at the same batch size
+    if base.exists():
+        old = {r["leaf"]: r for r in json.loads(base.read_text())}
+        for r in rows:
+            o = old.get(r["leaf"])
+            if o and r.get("kernel_ms") and o.get("kernel_ms") and o.get("instances") == r.get("instances") and o.get("frames") == r.get("frames"):
+                r["speedup_vs_r01"] = round(o["kernel_ms"] / r["kernel_ms"], 2)
     if args.out:
         Path(args.out).write_text(json.dumps(rows, indent=1))
     return 0
@@ -66,7 +73,7 @@ def run_one(zabatch, args, leaf, meta, nch, row, mem_cap):
                 e.process_device(d_in, d_out, args.frames, block=args.block); e.sync()       # warm-up
                 e.process_device(d_in, d_out, args.frames, block=args.block); e.sync()
                 ms, launches = e.last_timing()
-                row.update(status="ok", kernel_ms=ms, launches=launches, fast_path=bool(e.used_fast_path()),
+                row.update(status="ok", kernel_ms=ms, launches=launches, fast_path=bool(e.used_fast_path()), kernel=e.last_kernel_name(),
                            msamples_per_s=n * nch * args.frames / (ms * 1e-3) / 1e6,
                            realtime_factor=args.frames / 48000.0 / (ms * 1e-3))
         except zabatch.ZabError as ex:

@@ -1061,6 +1061,8 @@ def _classify(g: FrameGraph, plan: Plan, c: Component, comp_of: Dict[int, int], 
             rows.append(r)
         return rows, conds, gnodes
 
+    if d == 1 and _persistent_rounding(g, plan, c, mem):
+        return                                    # stays "serial": see _persistent_rounding
     res = attempt(False)
     if res is not None:
         c.kind = "scan"
@@ -1103,6 +1105,85 @@ def _classify(g: FrameGraph, plan: Plan, c: Component, comp_of: Dict[int, int], 
             sl[n.i] = n
             todo.extend(n.args)
         c.slice = [sl[i] for i in sorted(sl) if sl[i].kind != "st"]
+
+
+def _const_value(n: N) -> Optional[float]:
+    """Value of a node built from constants only."""
+    if n.kind == "const":
+        return float(n.val)
+    if n.kind == "op" and n.op in ("+", "-", "*", "neg") and n.args:
+        v = [_const_value(a) for a in n.args]
+        if any(x is None for x in v):
+            return None
+        return {"+": lambda: v[0] + v[1], "-": lambda: v[0] - v[1], "*": lambda: v[0] * v[1], "neg": lambda: -v[0]}[n.op]()
+    return None
+
+
+def _persistent_rounding(g: FrameGraph, plan: Plan, c: Component, mem) -> bool:
+    """A recurrence y = y + b with a fractional step keeps every rounding error it ever made (coefficient exactly 1: nothing
+    decays), and scripts put thresholds exactly where such sums are meant to land -- `pos += 1 / N; pos < 1 ? ...` reaches
+    1 after N steps only up to rounding, so the frame at which the test flips depends on the ORDER of the additions. A scan
+    re-associates them. Such components therefore keep their serial loop (exact order); integer-valued steps (counters,
+    hold timers) are exact in any order and stay scans, and |a| < 1 forgets its rounding, so thresholds on it are generic.
+    Decided on the branch-wise affine forms of the new state: (coefficient on itself, constant term) per path through ?: /
+    min / max; any path with coefficient 1 and a constant term that is not an integer literal marks the component."""
+    nm = c.names[0]
+    limit = 256
+
+    def forms(n: N):
+        if n.i not in mem:
+            return [(g.ZERO, n)]
+        if n.kind == "st":
+            return [(g.ONE, g.ZERO)]
+        if n.kind != "op":
+            return None
+        if n.op == "sel":
+            a, b = forms(n.args[1]), forms(n.args[2])
+            return None if a is None or b is None or len(a) + len(b) > limit else a + b
+        if n.op in ("min", "max"):
+            a, b = forms(n.args[0]), forms(n.args[1])
+            return None if a is None or b is None or len(a) + len(b) > limit else a + b
+        if n.op == "fabs":
+            a = forms(n.args[0])
+            return None if a is None else a + [(g.op("neg", k), g.op("neg", v)) for k, v in a]
+        if n.op in ("+", "-"):
+            a, b = forms(n.args[0]), forms(n.args[1])
+            if a is None or b is None or len(a) * len(b) > limit:
+                return None
+            return [(g.op(n.op, ka, kb), g.op(n.op, va, vb)) for ka, va in a for kb, vb in b]
+        if n.op == "neg":
+            a = forms(n.args[0])
+            return None if a is None else [(g.op("neg", k), g.op("neg", v)) for k, v in a]
+        if n.op == "*":
+            a, b = forms(n.args[0]), forms(n.args[1])
+            if a is None or b is None or len(a) * len(b) > limit:
+                return None
+            out = []
+            for ka, va in a:
+                for kb, vb in b:
+                    if _const_value(ka) == 0.0:
+                        out.append((g.op("*", va, kb), g.op("*", va, vb)))
+                    elif _const_value(kb) == 0.0:
+                        out.append((g.op("*", ka, vb), g.op("*", va, vb)))
+                    else:
+                        return None
+            return out
+        if n.op == "/":
+            a, b = forms(n.args[0]), forms(n.args[1])
+            if a is None or b is None or any(_const_value(kb) != 0.0 for kb, _ in b) or len(a) * len(b) > limit:
+                return None
+            return [(g.op("/", ka, vb), g.op("/", va, vb)) for ka, va in a for _, vb in b]
+        return None
+
+    fs = forms(plan.outs[nm])
+    if fs is None:
+        return False                              # not affine even branch-wise: the classification below decides
+    for k, v in fs:
+        if _const_value(k) == 1.0:
+            cv = _const_value(v)
+            if cv is None or cv != math.floor(cv):
+                return True
+    return False
 
 
 def try_plan(prog: Program, nch: int) -> Tuple[Optional[Plan], str]:
