@@ -63,6 +63,12 @@ CASES = [
     ("SOMA", "default", {}, 2048, 512),                # rand(): EEL2's MT19937 is process-global -> one process per case
     ("BedRock", "default", {}, 2048, 512),
     ("NeuroCV", "default", {}, 1024, 256),             # 18 channels, rand, sliderchange, memcpy
+    # leaves with file slots: nothing is assigned in the VM host (file_open -> -1, oracle/eel_host.cpp) nor in the engine
+    # (PsychoConvolver cannot have a VM fixture: the reference's EEL2 VM rejects the script -- "syntax error: max(1 <!> e-12"; EEL2 has
+    #  no exponent notation, the AOT grammar does -- so the reference's own shadow runtime cannot check this leaf either)
+    ("Contour", "default", {}, 2048, 512),
+    ("Texture", "default", {}, 1024, 256),
+    ("TextureXY", "default", {}, 2048, 512),
 ]
 
 

@@ -28,7 +28,8 @@ def test_leaf_matches_reference_vm(case, ipw, monkeypatch):
     if not zabatch.module_path(leaf).exists():
         pytest.skip(f"module for {leaf} not built")
     g = load_golden(case)
-    n = 70                                   # two waves, the second one partially filled
+    big = int(g["mem_high"]) > (1 << 22)     # Contour / Texture / TextureXY address tens of millions of cells (options:maxmem)
+    n = 3 if big else 70                     # two waves, the second one partially filled
     x = np.repeat(golden_input(g)[None], n, axis=0)
     with zabatch.Engine(leaf, n, srate=float(g["srate"]), mem_cap=max(65536, int(g["mem_high"]) + 64)) as e:
         assert e.nch == int(g["nch"])
@@ -40,17 +41,26 @@ def test_leaf_matches_reference_vm(case, ipw, monkeypatch):
         y = e.process_host(x, block=int(g["block"]))
         v = e.read_vars()
         high = e.mem_high()
-        mem = e.read_mem(0, int(g["mem_high"])) if int(g["mem_high"]) else None
+        mem = e.read_mem(0, int(g["mem_high"])) if int(g["mem_high"]) and not big else None
+        pages = {}
+        if big:                              # every 1024-cell page the VM left something in, and a few it left empty
+            want_pages = sorted(set((g["mem_idx"] // 1024).tolist()) | {0, 7, int(g["mem_high"]) // 1024 - 1})
+            pages = {pg: e.read_mem(pg * 1024, 1024) for pg in want_pages}
     err = np.abs(y.astype(np.float64) - g["out"].astype(np.float64)[None]).max()
     print(f"{case}: null test max {dbfs(err):.1f} dBFS")
     assert err <= AUDIO_EPS
-    for i in (0, 1, 63, 64, n - 1):
+    for i in sorted({0, 1, min(63, n - 1), min(64, n - 1), n - 1}):
         assert_state_close(names, prepared[i], g["vars_prepared"], what=f"{case} prepared[{i}]")
         assert_state_close(names, v[i], g["vars"], what=f"{case} vars[{i}]")
     if mem is not None:
         want = np.zeros(int(g["mem_high"]))
         want[g["mem_idx"]] = g["mem_val"]
         assert np.abs(mem - want[None]).max() <= SCALAR_EPS
+    for pg, got in pages.items():
+        want = np.zeros(1024)
+        sel = (g["mem_idx"] // 1024) == pg
+        want[g["mem_idx"][sel] - pg * 1024] = g["mem_val"][sel]
+        assert np.abs(got - want[None]).max() <= SCALAR_EPS, (case, pg)
     assert (high == int(g["mem_high"])).all()
     assert np.array_equal(y[0], y[n - 1]), "identical instances must produce identical audio"
 
