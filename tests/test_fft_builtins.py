@@ -11,24 +11,47 @@ import pytest
 from conftest import AUDIO_EPS, GOLDEN, SCALAR_EPS, assert_state_close, golden_input, load_golden
 
 KAT = np.load(GOLDEN / "wdl_fft.npz")
-SIZES = (16, 64, 256, 1024, 4096)
+SIZES = (16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768)     # every size the builtins accept
 OPS = {"fft": 1, "ifft": 2, "fft_real": 3, "ifft_real": 4, "fft_permute": 5, "fft_ipermute": 6, "convolve_c": 7}
+SRC_BASE = 65536          # convolve_c's second operand: the next 65536-cell page (a region may not cross a page)
+
+
+def _vectors(n):
+    """Known answers of the reference's WDL build: committed for n <= 4096 (wdl_fft.npz); above that (the vectors would be
+    megabytes of incompressible doubles) they are produced on the spot by the reference library itself (oracle/_ref travels)."""
+    if f"c{n}_in" in KAT:
+        return {k: KAT[f"{k[0]}{n}{k[1:]}"] for k in ("c_in", "c_fwd", "c_inv", "r_in", "r_fwd", "r_inv")} | {"perm": KAT[f"perm{n}"]}
+    from oracle import eel_oracle
+    if not eel_oracle.available():
+        pytest.skip("oracle/_ref not built (needed for sizes above 4096)")
+    rng = np.random.default_rng(20261004 + n)
+    z, r = rng.standard_normal(2 * n), rng.standard_normal(n)
+    return {"c_in": z, "c_fwd": eel_oracle.wdl_fft(z, n, False), "c_inv": eel_oracle.wdl_fft(z, n, True), "r_in": r,
+            "r_fwd": eel_oracle.wdl_real_fft(r, n, False), "r_inv": eel_oracle.wdl_real_fft(r, n, True),
+            "perm": eel_oracle.wdl_fft_permute(n)}
 
 
 def _cases(n):
-    """(op, input doubles, expected doubles)"""
-    perm = KAT[f"perm{n}"]
-    cin, cf, ci = KAT[f"c{n}_in"], KAT[f"c{n}_fwd"], KAT[f"c{n}_inv"]
+    """(op, input doubles, expected doubles, second operand or None)"""
+    V = _vectors(n)
+    perm = V["perm"]
+    cin, cf, ci = V["c_in"], V["c_fwd"], V["c_inv"]
     z = cin[0::2] + 1j * cin[1::2]
     nat = np.empty(2 * n); nat[0::2] = z[perm].real; nat[1::2] = z[perm].imag          # natural[k] = buf[perm[k]]
     wdl = np.empty_like(z); wdl[perm] = z
     ip = np.empty(2 * n); ip[0::2] = wdl.real; ip[1::2] = wdl.imag                      # buf[perm[k]] = natural[k]
-    yield "fft", cin, cf
-    yield "ifft", cin, ci
-    yield "fft_permute", cin, nat
-    yield "fft_ipermute", cin, ip
-    yield "fft_real", KAT[f"r{n}_in"], KAT[f"r{n}_fwd"]
-    yield "ifft_real", KAT[f"r{n}_in"], KAT[f"r{n}_inv"]
+    yield "fft", cin, cf, None
+    yield "ifft", cin, ci, None
+    yield "fft_permute", cin, nat, None
+    yield "fft_ipermute", cin, ip, None
+    yield "fft_real", V["r_in"], V["r_fwd"], None
+    yield "ifft_real", V["r_in"], V["r_inv"], None
+    # convolve_c: dest[i] *= src[i] over n complex pairs, the reference's own four products and two sums
+    # (src/JSFXJuceProcessor.cpp:1370-1380; no fused multiply-add on either side) -> bit-exact
+    src = np.roll(cin, 7) * 0.5
+    ar, ai, br, bi = cin[0::2], cin[1::2], src[0::2], src[1::2]
+    want = np.empty(2 * n); want[0::2] = ar * br - ai * bi; want[1::2] = ar * bi + ai * br
+    yield "convolve_c", cin, want, src
 
 
 def _tol(n, want):
@@ -61,14 +84,17 @@ def test_port_fft_known_answers(n):
     from oracle import port
     if not port.port_path("fx_fftkat").exists():
         pytest.skip("fixture port not built")
-    for op, x, want in _cases(n):
-        p = port.Port("fx_fftkat", 48000.0, mem_cap=1 << 17)
-        p.set_sliders([0, n, 0, 0]); p.prepare()
+    for op, x, want, src in _cases(n):
+        p = port.Port("fx_fftkat", 48000.0, mem_cap=1 << 18)
+        p.set_sliders([0, n, 0, SRC_BASE]); p.prepare()
         p.mem_write(0, x)
-        p.set_sliders([OPS[op], n, 0, 0]); p.run_slider()
+        if src is not None:
+            p.mem_write(SRC_BASE, src)
+        p.set_sliders([OPS[op], n, 0, SRC_BASE]); p.run_slider()
         got = p.mem(0, len(want))
         assert p.err == 0
-        assert np.abs(got - want).max() <= _tol(n, want), (op, n, np.abs(got - want).max())
+        tol = 0.0 if op == "convolve_c" else _tol(n, want)
+        assert np.abs(got - want).max() <= tol, (op, n, np.abs(got - want).max())
 
 
 def test_port_fft_argument_rules():
@@ -125,15 +151,21 @@ def test_gpu_fft_known_answers(n):
     import zabatch
     inst = 70
     scale = 1.0 + np.arange(inst)[:, None] * 0.125
-    for op, x, want in _cases(n):
-        with zabatch.Engine("fx_fftkat", inst, mem_cap=1 << 14) as e:
-            e.set_sliders([0, n, 0, 0]); e.prepare()
+    if n > 4096:
+        inst = 6                                    # (8192 and up take the serial device transform: keep the batch small)
+        scale = 1.0 + np.arange(inst)[:, None] * 0.125
+    for op, x, want, src in _cases(n):
+        with zabatch.Engine("fx_fftkat", inst, mem_cap=1 << 18) as e:
+            e.set_sliders([0, n, 0, SRC_BASE]); e.prepare()
             e.write_mem(0, scale * x[None, :])
-            e.set_sliders([OPS[op], n, 0, 0])
+            if src is not None:
+                e.write_mem(SRC_BASE, np.repeat(src[None, :], inst, axis=0))
+            e.set_sliders([OPS[op], n, 0, SRC_BASE])
             e.process_host(np.zeros((inst, 2, 8), np.float32), block=8)
             got = e.read_mem(0, len(want))
         ref = scale * want[None, :]
-        assert np.abs(got - ref).max() <= _tol(n, ref), (op, n, np.abs(got - ref).max())
+        tol = 0.0 if op == "convolve_c" else _tol(n, ref)     # (scaling by 1 + k/8 is exact, so the products scale exactly too)
+        assert np.abs(got - ref).max() <= tol, (op, n, np.abs(got - ref).max())
 
 
 @pytest.mark.gpu
