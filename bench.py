@@ -231,17 +231,12 @@ def main() -> int:
 
     leaf = args.leaf
     meta = zabatch.leaf_meta(leaf)
-    weak = args.instances_per_gpu > 0
-    if weak:
-        lo, hi = rank * args.instances_per_gpu, (rank + 1) * args.instances_per_gpu
-        n_total = world * args.instances_per_gpu
-    else:
-        n_total = args.instances_total
-        lo, hi = sharding.instance_range(n_total, rank, world)
-    n_inst = hi - lo
-    if n_inst <= 0:
-        print(f"bench.py: rank {rank} owns no instances ({n_total} over {world} ranks)", file=sys.stderr)
+    try:
+        shard = sharding.plan(rank, world, args.instances_total, args.instances_per_gpu)
+    except ValueError as ex:
+        print(f"bench.py: {ex}", file=sys.stderr)
         return 2
+    weak, lo, hi, n_total, n_inst = shard.scaling == "weak", shard.lo, shard.hi, shard.n_total, shard.count
     frames = args.frames
     path = {"auto": zabatch.ZAB_PATH_AUTO, "generic": zabatch.ZAB_PATH_GENERIC, "fast": zabatch.ZAB_PATH_FAST}[args.path]
     eng = zabatch.Engine(leaf, n_inst, srate=SRATE, max_block=BLOCK, device=local_rank, path=path, first_instance_id=1 + lo)

@@ -209,6 +209,38 @@ int zab_host_free(void* p);
  * number of mem[] words per instance held in LDS for the length of a launch (0: the arena is read in place). */
 int zab_launch_shape(zab_engine* e, int32_t* instances_per_wave, int32_t* lds_mem_words);
 
+/* ---- one job over several GPUs of a node -------------------------------------------------------------------
+ * The reference runs one plugin instance per audio thread; a batch job is N independent instances, so it shards by instance:
+ * shard k of n owns the contiguous range [k*N/n + min(k, N%n), ...) -- sizes differ by at most one, earlier shards take the
+ * extras -- on devices[k], with its own engine, stream and host thread. There is NO collective on the data path; the only
+ * exchange is zab_group_reduce(), a few doubles at the end of a run, over RCCL (xGMI) when the shards sit on distinct GPUs.
+ * Leaves coupled through gmem / msg_*() are "replicas only": every shard is its own communication domain.
+ * cfg->n_instances is the total N, cfg->device is ignored, cfg->first_instance_id applies to global instance 0. */
+typedef struct zab_group zab_group;
+typedef struct zab_group_stats {
+  double max_kernel_ms;    /* slowest shard's device time of its most recent zab_process (the job is as slow as that) */
+  double sum_kernel_ms;
+  double units;            /* samples processed by the most recent zab_group_process: sum over shards of count x channels x frames */
+  double max_value;        /* max over shards of the caller's per-shard value (e.g. worst null-test residual); 0 without one */
+  int32_t n_shards;
+  int32_t used_rccl;       /* 1: reduced with RCCL all-reduces on the shards' streams; 0: shards share a device, reduced on the host */
+} zab_group_stats;
+int zab_group_create(const char* module, const zab_config* cfg, const int32_t* devices, int32_t n_devices, zab_group** out);
+int zab_group_destroy(zab_group* g);
+int zab_group_size(zab_group* g);                                    /* number of shards */
+int zab_group_shard(zab_group* g, int32_t k, zab_engine** engine, int32_t* first, int32_t* count);
+/* as zab_set_sliders, [first, first+count) in GLOBAL instance numbers (count = 0 with first = 0 broadcasts one row) */
+int zab_group_set_sliders(zab_group* g, int32_t first, int32_t count, const double* values);
+int zab_group_prepare(zab_group* g);
+/* in[k] / out[k]: shard k's planar buffer [count_k][n_channels][frame_stride] -- device memory of devices[k] (ZAB_BUF_DEVICE:
+ * every GPU is launched and the call returns; zab_group_sync waits) or host memory (ZAB_BUF_HOST: one thread per shard stages
+ * its own PCIe pipeline, the call returns when all are done). */
+int zab_group_process(zab_group* g, const void* const* in, void* const* out, int64_t frames, int64_t frame_stride, int32_t block,
+                      int32_t placement);
+int zab_group_sync(zab_group* g);
+/* End-of-run statistics of the whole job; shard_values: one caller-supplied number per shard to take the maximum of, or NULL. */
+int zab_group_reduce(zab_group* g, const double* shard_values, zab_group_stats* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,6 +24,15 @@ def test_instance_ranges_partition_exactly():
         sharding.instance_range(4, 2, 2)
 
 
+def test_shard_plans():
+    import sharding
+    assert [sharding.plan(r, 2, instances_total=5).count for r in range(2)] == [3, 2]          # uneven: earlier ranks get the extra
+    assert [(s.lo, s.hi) for s in (sharding.plan(r, 3, instances_per_rank=4) for r in range(3))] == [(0, 4), (4, 8), (8, 12)]
+    assert sharding.plan(1, 3, instances_per_rank=4).scaling == "weak" and sharding.plan(1, 3, instances_per_rank=4).n_total == 12
+    with pytest.raises(ValueError):
+        sharding.plan(3, 4, instances_total=3)                                                 # a rank with nothing to do
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -47,7 +56,9 @@ def _worker(rank, world, port, n_total, frames, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    lo, hi = sharding.instance_range(n_total, rank, world)
+    shard = sharding.plan(rank, world, instances_total=n_total)          # what bench.py does with --instances-total
+    lo, hi = shard.lo, shard.hi
+    assert shard.scaling == "strong" and shard.n_total == n_total and (lo, hi) == sharding.instance_range(n_total, rank, world)
     meta = zabatch.leaf_meta("DDT")
     x = noise.white_noise(range(lo, hi), frames)
     y = np.zeros_like(x)

@@ -16,8 +16,12 @@
 #include <string.h>
 
 #include <atomic>
+#include <functional>
 #include <string>
+#include <thread>
 #include <vector>
+
+#include <rccl/rccl.h>      /* types only: the library is loaded on demand (zab_group_reduce), a single-GPU host never needs it */
 
 namespace {
 
@@ -1059,6 +1063,188 @@ int zab_launch_shape(zab_engine* e, int32_t* instances_per_wave, int32_t* lds_me
 }
 const char* zab_last_kernel_name(zab_engine* e) {
   return e ? e->kernel_name.c_str() : "";
+}
+
+}  // extern "C"
+
+// ---- one job over several GPUs: instance shards, one host thread + stream per GPU, RCCL only for the end-of-run reduce -------
+struct zab_group {
+  std::vector<zab_engine*> eng;
+  std::vector<int32_t> first, count, device;
+  int32_t total = 0;
+  int64_t last_frames = 0;
+  // RCCL (loaded on demand)
+  void* rccl = nullptr;
+  std::vector<ncclComm_t> comm;
+  std::vector<double*> d_stat;          // [4] per shard: {kernel ms, caller value | kernel ms, units}
+  bool rccl_tried = false, rccl_ok = false;
+  decltype(&ncclCommInitAll) p_init = nullptr;
+  decltype(&ncclAllReduce) p_allreduce = nullptr;
+  decltype(&ncclGroupStart) p_gstart = nullptr;
+  decltype(&ncclGroupEnd) p_gend = nullptr;
+  decltype(&ncclCommDestroy) p_destroy = nullptr;
+};
+
+namespace {
+// fn(k) for every shard on its own host thread; the first failure (code + text) is reported in the calling thread
+int each_shard(zab_group* g, const std::function<int(int)>& fn) {
+  const int n = (int)g->eng.size();
+  std::vector<int> rc((size_t)n, ZAB_OK);
+  std::vector<std::string> msg((size_t)n);
+  std::vector<std::thread> th;
+  for (int k = 0; k < n; ++k)
+    th.emplace_back([&, k] { rc[(size_t)k] = fn(k); if (rc[(size_t)k]) msg[(size_t)k] = zab_last_error(); });
+  for (auto& t : th) t.join();
+  for (int k = 0; k < n; ++k)
+    if (rc[(size_t)k]) return fail(rc[(size_t)k], "shard %d (device %d, instances [%d,+%d)): %s", k, g->device[(size_t)k], g->first[(size_t)k],
+                                   g->count[(size_t)k], msg[(size_t)k].c_str());
+  return ZAB_OK;
+}
+
+bool group_rccl(zab_group* g) {
+  if (g->rccl_tried) return g->rccl_ok;
+  g->rccl_tried = true;
+  for (size_t a = 0; a < g->device.size(); ++a)
+    for (size_t b = a + 1; b < g->device.size(); ++b)
+      if (g->device[a] == g->device[b]) return false;            // ranks of one communicator must sit on distinct devices
+  g->rccl = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+  if (!g->rccl) g->rccl = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!g->rccl) return false;
+  g->p_init = (decltype(g->p_init))dlsym(g->rccl, "ncclCommInitAll");
+  g->p_allreduce = (decltype(g->p_allreduce))dlsym(g->rccl, "ncclAllReduce");
+  g->p_gstart = (decltype(g->p_gstart))dlsym(g->rccl, "ncclGroupStart");
+  g->p_gend = (decltype(g->p_gend))dlsym(g->rccl, "ncclGroupEnd");
+  g->p_destroy = (decltype(g->p_destroy))dlsym(g->rccl, "ncclCommDestroy");
+  if (!g->p_init || !g->p_allreduce || !g->p_gstart || !g->p_gend || !g->p_destroy) return false;
+  g->comm.assign(g->device.size(), nullptr);
+  if (g->p_init(g->comm.data(), (int)g->device.size(), g->device.data()) != ncclSuccess) { g->comm.clear(); return false; }
+  g->d_stat.assign(g->device.size(), nullptr);
+  for (size_t k = 0; k < g->device.size(); ++k) {
+    if (hipSetDevice(g->device[k]) != hipSuccess || hipMalloc((void**)&g->d_stat[k], 4 * sizeof(double)) != hipSuccess) return false;
+  }
+  g->rccl_ok = true;
+  return true;
+}
+}  // namespace
+
+extern "C" {
+
+int zab_group_create(const char* module, const zab_config* cfg, const int32_t* devices, int32_t n_devices, zab_group** out) {
+  if (!module || !cfg || !devices || !out || n_devices <= 0) return fail(ZAB_E_ARG, "zab_group_create: bad argument");
+  if (cfg->n_instances < n_devices) return fail(ZAB_E_ARG, "zab_group_create: %d instances over %d shards leaves a shard empty", cfg->n_instances, n_devices);
+  *out = nullptr;
+  zab_group* g = new zab_group();
+  g->total = cfg->n_instances;
+  const int32_t base = cfg->n_instances / n_devices, extra = cfg->n_instances % n_devices;
+  for (int32_t k = 0; k < n_devices; ++k) {          // contiguous ranges, sizes differ by at most one (sharding.instance_range)
+    const int32_t lo = k * base + (k < extra ? k : extra), cnt = base + (k < extra ? 1 : 0);
+    zab_config c = *cfg;
+    c.n_instances = cnt;
+    c.device = devices[k];
+    c.first_instance_id = (cfg->first_instance_id ? cfg->first_instance_id : 1) + (uint64_t)lo;
+    zab_engine* e = nullptr;
+    const int rc = zab_create(module, &c, &e);
+    if (rc) {
+      const std::string why = zab_last_error();
+      zab_group_destroy(g);
+      return fail(rc, "zab_group_create: shard %d on device %d: %s", k, devices[k], why.c_str());
+    }
+    g->eng.push_back(e); g->first.push_back(lo); g->count.push_back(cnt); g->device.push_back(devices[k]);
+  }
+  *out = g;
+  return ZAB_OK;
+}
+
+int zab_group_destroy(zab_group* g) {
+  if (!g) return ZAB_OK;
+  for (size_t k = 0; k < g->d_stat.size(); ++k) if (g->d_stat[k]) { hipSetDevice(g->device[k]); hipFree(g->d_stat[k]); }
+  if (g->p_destroy) for (ncclComm_t c : g->comm) if (c) g->p_destroy(c);
+  for (zab_engine* e : g->eng) zab_destroy(e);
+  delete g;                               // (librccl stays loaded, like the plugin modules)
+  return ZAB_OK;
+}
+
+int zab_group_size(zab_group* g) { return g ? (int)g->eng.size() : 0; }
+
+int zab_group_shard(zab_group* g, int32_t k, zab_engine** engine, int32_t* first, int32_t* count) {
+  if (!g || k < 0 || k >= (int32_t)g->eng.size()) return fail(ZAB_E_ARG, "zab_group_shard: bad argument");
+  if (engine) *engine = g->eng[(size_t)k];
+  if (first) *first = g->first[(size_t)k];
+  if (count) *count = g->count[(size_t)k];
+  return ZAB_OK;
+}
+
+int zab_group_set_sliders(zab_group* g, int32_t first, int32_t count, const double* values) {
+  if (!g || !values) return fail(ZAB_E_ARG, "zab_group_set_sliders: null argument");
+  const bool bcast = first == 0 && count == 0;
+  if (!bcast && (first < 0 || count < 0 || (int64_t)first + count > g->total)) return fail(ZAB_E_ARG, "zab_group_set_sliders: range outside the job");
+  for (size_t k = 0; k < g->eng.size(); ++k) {
+    if (bcast) { const int rc = zab_set_sliders(g->eng[k], 0, 0, values); if (rc) return rc; continue; }
+    const int32_t lo = std::max(first, g->first[k]), hi = std::min(first + count, g->first[k] + g->count[k]);
+    if (lo >= hi) continue;
+    const int rc = zab_set_sliders(g->eng[k], lo - g->first[k], hi - lo, values + (size_t)(lo - first) * 64);
+    if (rc) return rc;
+  }
+  return ZAB_OK;
+}
+
+int zab_group_prepare(zab_group* g) {
+  if (!g) return fail(ZAB_E_ARG, "zab_group_prepare: null group");
+  return each_shard(g, [g](int k) { return zab_prepare(g->eng[(size_t)k]); });
+}
+
+int zab_group_process(zab_group* g, const void* const* in, void* const* out, int64_t frames, int64_t frame_stride, int32_t block, int32_t placement) {
+  if (!g || !in || !out) return fail(ZAB_E_ARG, "zab_group_process: null argument");
+  g->last_frames = frames;
+  return each_shard(g, [=](int k) { return zab_process(g->eng[(size_t)k], in[k], out[k], frames, frame_stride, block, placement); });
+}
+
+int zab_group_sync(zab_group* g) {
+  if (!g) return fail(ZAB_E_ARG, "zab_group_sync: null group");
+  return each_shard(g, [g](int k) { return zab_sync(g->eng[(size_t)k]); });
+}
+
+int zab_group_reduce(zab_group* g, const double* shard_values, zab_group_stats* out) {
+  if (!g || !out) return fail(ZAB_E_ARG, "zab_group_reduce: null argument");
+  const size_t n = g->eng.size();
+  std::vector<double> ms(n, 0.0), units(n, 0.0);
+  for (size_t k = 0; k < n; ++k) {
+    int32_t launches = 0;
+    if (g->eng[k]->timing_valid) { const int rc = zab_last_timing(g->eng[k], &ms[k], &launches); if (rc) return rc; }
+    units[k] = (double)g->count[k] * g->eng[k]->mod->nch * (double)g->last_frames;
+  }
+  memset(out, 0, sizeof *out);
+  out->n_shards = (int32_t)n;
+  if (group_rccl(g)) {
+    // {max: kernel ms, caller value} and {sum: kernel ms, units}: two all-reduces per shard on its own stream, grouped
+    for (size_t k = 0; k < n; ++k) {
+      const double h[4] = {ms[k], shard_values ? shard_values[k] : 0.0, ms[k], units[k]};
+      HIP_TRY(hipSetDevice(g->device[k]));
+      HIP_TRY(hipMemcpyAsync(g->d_stat[k], h, sizeof h, hipMemcpyHostToDevice, g->eng[k]->stream));
+    }
+    if (g->p_gstart() != ncclSuccess) return fail(ZAB_E_HIP, "ncclGroupStart failed");
+    for (size_t k = 0; k < n; ++k) {
+      if (g->p_allreduce(g->d_stat[k], g->d_stat[k], 2, ncclDouble, ncclMax, g->comm[k], g->eng[k]->stream) != ncclSuccess ||
+          g->p_allreduce(g->d_stat[k] + 2, g->d_stat[k] + 2, 2, ncclDouble, ncclSum, g->comm[k], g->eng[k]->stream) != ncclSuccess)
+        return fail(ZAB_E_HIP, "ncclAllReduce failed on shard %zu", k);
+    }
+    if (g->p_gend() != ncclSuccess) return fail(ZAB_E_HIP, "ncclGroupEnd failed");
+    double h[4];
+    HIP_TRY(hipSetDevice(g->device[0]));
+    HIP_TRY(hipMemcpyAsync(h, g->d_stat[0], sizeof h, hipMemcpyDeviceToHost, g->eng[0]->stream));
+    HIP_TRY(hipStreamSynchronize(g->eng[0]->stream));
+    for (size_t k = 1; k < n; ++k) { HIP_TRY(hipSetDevice(g->device[k])); HIP_TRY(hipStreamSynchronize(g->eng[k]->stream)); }
+    out->max_kernel_ms = h[0]; out->max_value = h[1]; out->sum_kernel_ms = h[2]; out->units = h[3];
+    out->used_rccl = 1;
+    return ZAB_OK;
+  }
+  for (size_t k = 0; k < n; ++k) {        // shards share a device (or no RCCL on this host): nothing to move between GPUs
+    out->max_kernel_ms = std::max(out->max_kernel_ms, ms[k]);
+    out->sum_kernel_ms += ms[k];
+    out->units += units[k];
+    if (shard_values) out->max_value = std::max(out->max_value, shard_values[k]);
+  }
+  return ZAB_OK;
 }
 
 }  // extern "C"

@@ -29,6 +29,32 @@ def owner_of(instance: int, n_total: int, world: int) -> int:
 
 
 @dataclass
+class Shard:
+    lo: int                   # first global instance of this rank
+    hi: int                   # one past its last
+    n_total: int              # instances of the whole job
+    scaling: str              # "strong": n_total fixed, split over the ranks; "weak": a fixed count on every rank
+
+    @property
+    def count(self) -> int:
+        return self.hi - self.lo
+
+
+def plan(rank: int, world: int, instances_total: int = 0, instances_per_rank: int = 0) -> Shard:
+    """The shard of one rank, as bench.py and the C group API (zab_group_create) lay a job out: `instances_per_rank` > 0 gives
+    every rank that many (weak scaling); otherwise `instances_total` is split with instance_range (strong scaling). A rank
+    that would own nothing is an error -- the job is mis-sized, not something to run silently on fewer GPUs."""
+    if instances_per_rank > 0:
+        sh = Shard(rank * instances_per_rank, (rank + 1) * instances_per_rank, world * instances_per_rank, "weak")
+    else:
+        lo, hi = instance_range(instances_total, rank, world)
+        sh = Shard(lo, hi, instances_total, "strong")
+    if sh.count <= 0:
+        raise ValueError(f"rank {rank} of {world} owns no instances ({sh.n_total} in total)")
+    return sh
+
+
+@dataclass
 class RunStats:
     elapsed_s: float          # wall time of the timed region on this rank
     units: float              # samples (instances x channels x frames x steps) this rank processed

@@ -40,6 +40,11 @@ class zab_host_state(C.Structure):      # include/zabatch.h
                 ("mem_high", C.POINTER(C.c_int64)), ("flags", C.POINTER(C.c_uint32))]
 
 
+class zab_group_stats(C.Structure):
+    _fields_ = [("max_kernel_ms", C.c_double), ("sum_kernel_ms", C.c_double), ("units", C.c_double), ("max_value", C.c_double),
+                ("n_shards", C.c_int32), ("used_rccl", C.c_int32)]
+
+
 class zab_pool_entry(C.Structure):
     _fields_ = [("offset_items", C.c_int64), ("frames", C.c_int32), ("sample_rate", C.c_int32), ("channels", C.c_int32),
                 ("peak", C.c_float), ("rms", C.c_float)]
@@ -59,6 +64,8 @@ ABI_SYMBOLS = [
     "zab_read_mem", "zab_write_mem", "zab_read_mem_high", "zab_device_alloc", "zab_device_free", "zab_device_upload",
     "zab_device_download", "zab_device_noise", "zab_last_timing", "zab_timing_history", "zab_stream",
     "zab_used_fast_path", "zab_last_kernel_name", "zab_launch_shape", "zab_host_alloc", "zab_host_free", "zab_state_upload", "zab_state_download", "zab_run_section", "zab_gmem_read", "zab_gmem_write", "zab_gmem_seq", "zab_pool_upload", "zab_file_slot_set",
+    "zab_group_create", "zab_group_destroy", "zab_group_size", "zab_group_shard", "zab_group_set_sliders", "zab_group_prepare",
+    "zab_group_process", "zab_group_sync", "zab_group_reduce",
 ]
 
 _lib = None
@@ -117,6 +124,15 @@ def load_runtime():
     L.zab_gmem_seq.argtypes = [vp, i64, C.POINTER(C.c_uint64)]
     L.zab_pool_upload.argtypes = [vp, i32, C.POINTER(zab_pool_entry), C.POINTER(C.c_float), i64]
     L.zab_file_slot_set.argtypes = [vp, i32, i32, C.c_double, C.POINTER(C.c_double), i64]
+    L.zab_group_create.argtypes = [C.c_char_p, C.POINTER(zab_config), C.POINTER(i32), i32, C.POINTER(vp)]
+    L.zab_group_destroy.argtypes = [vp]
+    L.zab_group_size.argtypes = [vp]
+    L.zab_group_shard.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(i32)]
+    L.zab_group_set_sliders.argtypes = [vp, i32, i32, C.POINTER(d)]
+    L.zab_group_prepare.argtypes = [vp]
+    L.zab_group_process.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), i64, i64, i32, i32]
+    L.zab_group_sync.argtypes = [vp]
+    L.zab_group_reduce.argtypes = [vp, C.POINTER(d), C.POINTER(zab_group_stats)]
     _lib = L
     return L
 
@@ -438,6 +454,103 @@ class Engine:
         out = np.zeros(cnt, dtype=np.int64)
         self._chk(self.L.zab_read_mem_high(self.h, int(first), int(cnt), out.ctypes.data_as(C.POINTER(C.c_int64))))
         return out
+
+
+class Group:
+    """One job sharded by instance over several GPUs of a node (zab_group_*, include/zabatch.h): contiguous instance ranges,
+    one engine + stream + host thread per shard, no collective on the data path, RCCL for the end-of-run statistics."""
+
+    def __init__(self, leaf: str, n_instances: int, devices, srate: float = 48000.0, max_block: int = 512,
+                 path: int = ZAB_PATH_AUTO, mem_cap: int = 0, first_instance_id: int = 1):
+        self.L = load_runtime()
+        mp = module_path(leaf)
+        if not mp.exists():
+            raise ZabError(-2, f"{mp} missing: leaf {leaf} has not been built (no CPU fallback exists)")
+        cfg = zab_config(int(n_instances), 0, float(srate), int(max_block), int(path), int(mem_cap), int(first_instance_id))
+        devs = (C.c_int32 * len(devices))(*[int(x) for x in devices])
+        h = C.c_void_p()
+        self.h = None
+        self._chk(self.L.zab_group_create(str(mp).encode(), C.byref(cfg), devs, len(devices), C.byref(h)))
+        self.h = h
+        self.n = int(n_instances)
+        self.shards = []                       # (first, count, Engine view) per shard
+        for k in range(self.L.zab_group_size(self.h)):
+            eh, first, count = C.c_void_p(), C.c_int32(), C.c_int32()
+            self._chk(self.L.zab_group_shard(self.h, k, C.byref(eh), C.byref(first), C.byref(count)))
+            self.shards.append((first.value, count.value, _EngineView(self.L, eh, leaf, count.value, srate)))
+        self.nch = self.shards[0][2].nch
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise ZabError(rc, self.L.zab_last_error().decode(errors="replace"))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.zab_group_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_sliders(self, values, first: int = 0, count: Optional[int] = None):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        if v.ndim == 1:
+            row = np.zeros(64)
+            row[: len(v)] = v
+            self._chk(self.L.zab_group_set_sliders(self.h, 0, 0, _dp(row)))
+            return
+        cnt = v.shape[0] if count is None else count
+        full = np.zeros((cnt, 64))
+        full[:, : v.shape[1]] = v[:cnt]
+        self._chk(self.L.zab_group_set_sliders(self.h, int(first), int(cnt), _dp(full)))
+
+    def prepare(self):
+        self._chk(self.L.zab_group_prepare(self.h))
+
+    def process_host(self, x: np.ndarray, block: int = 512) -> np.ndarray:
+        """x: float32 [N, nch, frames] for the whole job; every shard stages its own slice (one host thread per shard)."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        assert x.shape[0] == self.n and x.shape[1] == self.nch
+        y = np.empty_like(x)
+        frames = x.shape[2]
+        ins = (C.c_void_p * len(self.shards))(*[x[f:f + c].ctypes.data for f, c, _ in self.shards])
+        outs = (C.c_void_p * len(self.shards))(*[y[f:f + c].ctypes.data for f, c, _ in self.shards])
+        self._chk(self.L.zab_group_process(self.h, ins, outs, frames, frames, int(block), ZAB_BUF_HOST))
+        return y
+
+    def process_device(self, d_in, d_out, frames: int, stride: Optional[int] = None, block: int = 512):
+        ins = (C.c_void_p * len(self.shards))(*d_in)
+        outs = (C.c_void_p * len(self.shards))(*d_out)
+        self._chk(self.L.zab_group_process(self.h, ins, outs, int(frames), int(stride or frames), int(block), ZAB_BUF_DEVICE))
+
+    def sync(self):
+        self._chk(self.L.zab_group_sync(self.h))
+
+    def reduce(self, shard_values=None) -> dict:
+        st = zab_group_stats()
+        v = None if shard_values is None else np.ascontiguousarray(shard_values, dtype=np.float64)
+        self._chk(self.L.zab_group_reduce(self.h, None if v is None else _dp(v), C.byref(st)))
+        return {k: getattr(st, k) for k, _ in zab_group_stats._fields_}
+
+
+class _EngineView(Engine):
+    """An engine owned by a Group: the Engine methods over a borrowed handle (close() leaves it to the group)."""
+
+    def __init__(self, L, handle, leaf, n, srate):
+        self.L, self.h, self.leaf, self.n, self.srate = L, handle, leaf, int(n), float(srate)
+        info = zab_info()
+        self._chk(self.L.zab_get_info(self.h, C.byref(info)))
+        self.info, self.nch, self.nvars, self.mem_cap = info, info.n_channels, info.nvars, int(info.mem_cap)
+        self._owned = []
+
+    def close(self):
+        for p in list(self._owned):
+            self.L.zab_device_free(self.h, p)
+        self._owned.clear()
+        self.h = None
 
 
 class JsfxBatchProcessor:
