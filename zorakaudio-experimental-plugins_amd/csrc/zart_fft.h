@@ -85,8 +85,8 @@ extern "C" __global__ void za_fft_table_kernel() {
     za_fft_cos[j] = cs;
     za_fft_sin[j] = sn;
   }
-  if (j >= ZA_FFT_MIN && j < 2 * ZA_FFT_COOP_MAX) {      // j = n + i with n the largest power of two <= j
-    uint32_t n = ZA_FFT_MIN;
+  if (j >= 2 && j < 2 * ZA_FFT_COOP_MAX) {      // j = n + i with n the largest power of two <= j (real transforms use sizes from 8)
+    uint32_t n = 2;
     while (2 * n <= (uint32_t)j) n <<= 1;
     za_fft_perm[j] = (uint16_t)za_fft_bin_of_pos((uint32_t)j - n, n);
   }
@@ -126,25 +126,29 @@ ZA_FN bool za_fft_region(S& s, double baseD, int64_t span, int64_t& base, int64_
 __shared__ double za_fft_tw[ZA_FFT_COOP_MAX];
 __shared__ int za_fft_tw_ready;
 #define ZA_KERNEL_ENTRY() do { za_fft_tw_ready = 0; __builtin_amdgcn_wave_barrier(); } while (0)
-enum { ZA_COOP_FFT = 0, ZA_COOP_IFFT = 1, ZA_COOP_PERMUTE = 2, ZA_COOP_IPERMUTE = 3 };
+enum { ZA_COOP_FFT = 0, ZA_COOP_IFFT = 1, ZA_COOP_PERMUTE = 2, ZA_COOP_IPERMUTE = 3, ZA_COOP_FFT_REAL = 4, ZA_COOP_IFFT_REAL = 5,
+       ZA_COOP_CONVOLVE = 6 };
 __device__ __forceinline__ int64_t za_readlane64(int64_t v, int l) {
   const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffff), l), hi = __builtin_amdgcn_readlane((int)(v >> 32), l);
   return ((int64_t)hi << 32) | (uint32_t)lo;
 }
 // Every lane that reached the builtin calls this (converged at the call site); `ok` says whether this lane has a valid
 // request (base, n). Returns true for the lanes whose request was served here.
+// Real transforms (n reals = n / 2 complex points, so n up to 2 * ZA_FFT_COOP_MAX) and convolve_c (n = complex pairs, base2 = its
+// second operand) take the same route; the arithmetic per element is the serial form's, hence the same bits.
 template <class S>
-__device__ __noinline__ bool za_fft_coop(S& s, bool ok, int64_t base, int n, int op) {
+__device__ __noinline__ bool za_fft_coop(S& s, bool ok, int64_t base, int n, int op, int64_t base2 = 0) {
   __shared__ double buf[2 * ZA_FFT_COOP_MAX];
   double* const tw = za_fft_tw;
-  const bool coop = ok && n <= ZA_FFT_COOP_MAX;
+  const bool is_real = op == ZA_COOP_FFT_REAL || op == ZA_COOP_IFFT_REAL;
+  const bool coop = ok && (op == ZA_COOP_CONVOLVE || n <= (is_real ? 2 * ZA_FFT_COOP_MAX : ZA_FFT_COOP_MAX));
   const bool mine = coop && !s.replica;            // replica lanes help with their primary's request, they add none
   const uint64_t active = __ballot(1);
   uint64_t todo = __ballot(mine);
   const int lane = (int)(threadIdx.x & 63);
   const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
   const int rank = __popcll(active & below), nact = __popcll(active);
-  if (todo && (op == ZA_COOP_FFT || op == ZA_COOP_IFFT) && za_fft_tw_ready != 1) {
+  if (todo && (op == ZA_COOP_FFT || op == ZA_COOP_IFFT || is_real) && za_fft_tw_ready != 1) {
     // twiddles of the largest cooperative size, staged once per workgroup launch (the HBM table is 1 us away per read)
     for (int j = rank; j < ZA_FFT_COOP_MAX / 2; j += nact) {
       tw[2 * j] = za_fft_cos[j * (ZA_FFT_MAX / ZA_FFT_COOP_MAX)];
@@ -159,9 +163,32 @@ __device__ __noinline__ bool za_fft_coop(S& s, bool ok, int64_t base, int n, int
     todo &= todo - 1;
     double* const mp = (double*)za_readlane64((int64_t)(uintptr_t)s.mem, l);
     const int64_t ms = za_readlane64(s.mem_stride, l), bl = za_readlane64(base, l);
-    const int nl = __builtin_amdgcn_readlane(n, l);
+    const int nreq = __builtin_amdgcn_readlane(n, l);
+    const int nl = is_real ? nreq >> 1 : nreq;                 // complex points of the transform
     const int bits = za_log2((uint32_t)nl);
 #define ZA_G(a) mp[(bl + (a)) * ms]
+    if (op == ZA_COOP_CONVOLVE) {
+      // dest[i] *= src[i]; on overlap the reference multiplies by a copy of src taken first (src/JSFXJuceProcessor.cpp:1363-1369)
+      const int64_t rl = za_readlane64(base2, l);
+      double* const fp = (double*)za_readlane64((int64_t)(uintptr_t)s.fft, l);
+      const int64_t fs = za_readlane64(s.fft_stride, l);
+      const bool overlap = (bl < rl + 2 * (int64_t)nl) && (rl < bl + 2 * (int64_t)nl) && bl != rl;
+      if (overlap) {
+        for (int i = rank; i < 2 * nl; i += nact) fp[(int64_t)i * fs] = mp[(rl + i) * ms];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      }
+      for (int i = rank; i < nl; i += nact) {
+        const double ar = ZA_G(2 * i), ai = ZA_G(2 * i + 1);
+        const double br = overlap ? fp[(int64_t)(2 * i) * fs] : mp[(rl + 2 * i) * ms];
+        const double bi = overlap ? fp[(int64_t)(2 * i + 1) * fs] : mp[(rl + 2 * i + 1) * ms];
+        ZA_G(2 * i) = ar * br - ai * bi;
+        ZA_G(2 * i + 1) = ar * bi + ai * br;
+      }
+      __builtin_amdgcn_wave_barrier();
+      continue;
+    }
     // ---- stage the request's buffer in LDS, in the order its transform wants ----------------------------------------
     // (eight HBM reads in flight per lane: one read per trip would cost a full memory latency per element)
     for (int i0 = rank; i0 < nl; i0 += 8 * nact) {
@@ -173,16 +200,16 @@ __device__ __noinline__ bool za_fft_coop(S& s, bool ok, int64_t base, int n, int
         const bool in = i < nl;
         vr[u] = in ? ZA_G(2 * i) : 0.0;
         vi[u] = in ? ZA_G(2 * i + 1) : 0.0;
-        pm[u] = (in && (op == ZA_COOP_IFFT || op == ZA_COOP_PERMUTE)) ? za_fft_perm[nl + i] : 0;
+        pm[u] = (in && (op == ZA_COOP_IFFT || op == ZA_COOP_PERMUTE || op == ZA_COOP_IFFT_REAL)) ? za_fft_perm[nl + i] : 0;
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int i = i0 + u * nact;
         if (i < nl) {
           uint32_t dst;
-          if (op == ZA_COOP_FFT) dst = za_bitrev((uint32_t)i, bits);
+          if (op == ZA_COOP_FFT || op == ZA_COOP_FFT_REAL) dst = za_bitrev((uint32_t)i, bits);
           else if (op == ZA_COOP_IFFT) dst = za_bitrev(pm[u], bits);
-          else if (op == ZA_COOP_PERMUTE) dst = pm[u];
+          else if (op == ZA_COOP_PERMUTE || op == ZA_COOP_IFFT_REAL) dst = pm[u];      // (ifft_real: natural bin order first)
           else dst = (uint32_t)i;
           buf[2 * dst] = vr[u];
           buf[2 * dst + 1] = vi[u];
@@ -190,8 +217,46 @@ __device__ __noinline__ bool za_fft_coop(S& s, bool ok, int64_t base, int n, int
       }
     }
     __builtin_amdgcn_wave_barrier();
-    if (op == ZA_COOP_FFT || op == ZA_COOP_IFFT) {
-      const int sign = op == ZA_COOP_FFT ? -1 : +1;
+    if (op == ZA_COOP_IFFT_REAL) {
+      // packed spectrum (natural order in buf) -> Z of the half-size complex transform, in place: bins k and h - k only need
+      // each other; then the in-place bit reversal the butterflies want
+      const int h = nl, step = ZA_FFT_MAX / nreq;
+      for (int k = rank; k <= (h >> 1); k += nact) {
+        const int m = h - k;
+        if (k == 0) {
+          const double x0 = buf[0], xn = buf[1];
+          buf[0] = x0 + xn; buf[1] = x0 - xn;
+        } else {
+          const double ar = buf[2 * k], ai = buf[2 * k + 1], cr = buf[2 * m], ci = buf[2 * m + 1];
+          {
+            const double br = cr, bi = -ci;                                  // conj X[h-k]
+            const double er = ar + br, ei = ai + bi, dr = ar - br, di = ai - bi;
+            const double c = za_fft_cos[k * step], sn = za_fft_sin[k * step];
+            buf[2 * k] = er + (-sn * dr - c * di);
+            buf[2 * k + 1] = ei + (-sn * di + c * dr);
+          }
+          if (m != k) {
+            const double br = ar, bi = -ai;                                  // the same formula for bin h - k
+            const double er = cr + br, ei = ci + bi, dr = cr - br, di = ci - bi;
+            const double c = za_fft_cos[m * step], sn = za_fft_sin[m * step];
+            buf[2 * m] = er + (-sn * dr - c * di);
+            buf[2 * m + 1] = ei + (-sn * di + c * dr);
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (int i = rank; i < h; i += nact) {
+        const int r = (int)za_bitrev((uint32_t)i, bits);
+        if (i < r) {
+          const double t0 = buf[2 * i], t1 = buf[2 * i + 1];
+          buf[2 * i] = buf[2 * r]; buf[2 * i + 1] = buf[2 * r + 1];
+          buf[2 * r] = t0; buf[2 * r + 1] = t1;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (op == ZA_COOP_FFT || op == ZA_COOP_IFFT || is_real) {
+      const int sign = (op == ZA_COOP_FFT || op == ZA_COOP_FFT_REAL) ? -1 : +1;
       for (int len = 2; len <= nl; len <<= 1) {
         const int half = len >> 1, step = ZA_FFT_COOP_MAX / len;
         // four independent butterflies per trip: all their LDS reads are issued before the first store, which the
@@ -222,6 +287,29 @@ __device__ __noinline__ bool za_fft_coop(S& s, bool ok, int64_t base, int n, int
         }
         __builtin_amdgcn_wave_barrier();
       }
+    }
+    if (op == ZA_COOP_FFT_REAL) {
+      // Z (natural order in buf) -> the packed spectrum of the real input, position i holds bin perm_h(i), scaled by 2
+      const int h = nl, step = ZA_FFT_MAX / nreq;
+      for (int i = rank; i < h; i += nact) {
+        const int k = (int)za_fft_perm[h + i];
+        double re, im;
+        if (k == 0) {
+          re = 2.0 * (buf[0] + buf[1]);
+          im = 2.0 * (buf[0] - buf[1]);
+        } else {
+          const int m = h - k;
+          const double zr = buf[2 * k], zi = buf[2 * k + 1], yr = buf[2 * m], yi = -buf[2 * m + 1];
+          const double er = zr + yr, ei = zi + yi, dr = zr - yr, di = zi - yi;
+          const double c = za_fft_cos[k * step], sn = za_fft_sin[k * step];
+          re = er + (-sn * dr + c * di);
+          im = ei + (-sn * di - c * dr);
+        }
+        ZA_G(2 * i) = re;
+        ZA_G(2 * i + 1) = im;
+      }
+      __builtin_amdgcn_wave_barrier();
+      continue;
     }
     // ---- write back in the order the builtin defines -------------------------------------------------------------------
     for (int i0 = rank; i0 < nl; i0 += 8 * nact) {
@@ -353,8 +441,10 @@ template <class S> ZA_NOINLINE double za_fft_ipermute(S& s, double baseD, double
 //   inverse:  the exact reverse, then an unscaled inverse FFT_{N/2}.
 template <class S> ZA_NOINLINE double za_fft_real(S& s, double baseD, double sizeD) {
   const int64_t n = za_round_idx(sizeD);
-  int64_t base;
-  if (!za_fft_pow2(n) || !za_fft_region(s, baseD, n, base, 2 * n)) return 0.0;
+  int64_t base = 0;
+  const bool ok = za_fft_pow2(n) && za_fft_region(s, baseD, n, base, 2 * n);
+  ZA_FFT_TRY_COOP(ZA_COOP_FFT_REAL);
+  if (!ok) return 0.0;
   const int h = (int)(n >> 1), bits = za_log2((uint32_t)h);
   for (int i = 0; i < h; ++i) {
     const uint32_t r = za_bitrev((uint32_t)i, bits);
@@ -385,8 +475,10 @@ template <class S> ZA_NOINLINE double za_fft_real(S& s, double baseD, double siz
 }
 template <class S> ZA_NOINLINE double za_ifft_real(S& s, double baseD, double sizeD) {
   const int64_t n = za_round_idx(sizeD);
-  int64_t base;
-  if (!za_fft_pow2(n) || !za_fft_region(s, baseD, n, base, 2 * n)) return 0.0;
+  int64_t base = 0;
+  const bool ok = za_fft_pow2(n) && za_fft_region(s, baseD, n, base, 2 * n);
+  ZA_FFT_TRY_COOP(ZA_COOP_IFFT_REAL);
+  if (!ok) return 0.0;
   const int h = (int)(n >> 1), bits = za_log2((uint32_t)h);
   // gather the packed spectrum into natural order at the start of scratch's upper half, then build Z bit-reversed
   // in the lower half. scratch capacity >= 2*(2h) doubles is guaranteed by fft_cap >= n (complex count) * 2.
@@ -423,10 +515,12 @@ template <class S> ZA_NOINLINE double za_ifft_real(S& s, double baseD, double si
 // convolve_c(dest, src, size): dest[i] *= src[i] for `size` complex pairs, src read before dest is written on overlap.
 template <class S> ZA_NOINLINE double za_convolve_c(S& s, double destD, double srcD, double sizeD) {
   const int64_t cnt = za_round_idx(sizeD);
-  if (cnt <= 0 || cnt > ZA_FFT_PAGE / 2) return 0.0;
-  int64_t d, r;
-  if (!za_fft_region(s, destD, 2 * cnt, d, 2 * cnt)) return 0.0;
-  if (!za_fft_region(s, srcD, 2 * cnt, r, 2 * cnt)) return 0.0;
+  int64_t d = 0, r = 0;
+  const bool okc = cnt > 0 && cnt <= ZA_FFT_PAGE / 2 && za_fft_region(s, destD, 2 * cnt, d, 2 * cnt) && za_fft_region(s, srcD, 2 * cnt, r, 2 * cnt);
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+  if (za_fft_coop(s, okc, d, (int)cnt, ZA_COOP_CONVOLVE, r)) return 0.0;
+#endif
+  if (!okc) return 0.0;
   const bool overlap = (d < r + 2 * cnt) && (r < d + 2 * cnt) && d != r;
   if (overlap) for (int64_t i = 0; i < 2 * cnt; ++i) ZA_F(i) = ZA_M(r + i);
   for (int64_t i = 0; i < cnt; ++i) {
