@@ -51,6 +51,10 @@ CASES = [
     ("fx_dynkat", "default", {}, 3000, 512),          # repo-authored recurrence zoo for the time-parallel kernels
     ("fx_dynkat", "hot", {0: 0.8, 1: -40, 2: 1.5, 3: 30, 4: 3000}, 2500, 500),
     ("fx_randkat", "default", {}, 3000, 512),         # rand() on the audio path, conditional draws, generation crossings
+    ("fx_ringkat", "default", {}, 3000, 512),         # delay lines + mem[] cells for the time-parallel kernels
+    ("fx_ringkat", "long", {0: 380, 1: 0.8, 2: 77}, 2600, 500),
+    ("fx_ringabort", "default", {}, 3000, 512),       # the write position skips every 1000 frames: those chunks go to the generic code
+    ("fx_ringabort", "stride2", {0: 50000, 1: 1}, 1500, 500),     # never a unit step: the whole launch does
     ("fx_delaytaps", "far", {0: 90, 1: 24, 2: 80, 3: -6.0, 4: 100}, 3000, 500),
     # random programs over the constructs the AOT lowering and the EEL2 VM agree on (tests/fixtures/make_fuzz.py)
     ("fx_fuzz0", "default", {0: 3.0}, 600, 128), ("fx_fuzz1", "default", {0: 7.5}, 600, 128),

@@ -16,8 +16,9 @@ from conftest import AUDIO_EPS, GOLDEN, ROOT, SCALAR_EPS, assert_state_close, db
 
 REF_PLUGINS = Path("/root/reference/plugins")
 FIXTURES = ROOT / "tests" / "fixtures"
-TPAR_CATALOG = ["ADS", "ATTACK", "RTT", "SaliencePush", "BedRock"]
-TPAR_FIXTURES = ["fx_dynkat_default", "fx_dynkat_hot", "fx_randkat_default"]
+TPAR_CATALOG = ["ADS", "ATTACK", "RTT", "SaliencePush", "BedRock", "DPT", "Roomalizer"]
+TPAR_FIXTURES = ["fx_dynkat_default", "fx_dynkat_hot", "fx_randkat_default", "fx_ringkat_default", "fx_ringkat_long"]
+TPAR_ABORTS = ["fx_ringabort_default", "fx_ringabort_stride2"]      # launches the kernel hands (partly) to the generic code
 
 
 def _source(leaf):
@@ -35,6 +36,31 @@ def _plan(leaf):
     prog = program.analyse_file(src)
     nch = max(1, min(64, int(prog.io["process"])))
     return tpar.build_plan(prog, nch), prog
+
+
+def _prepared_arena(leaf, g):
+    """mem[] and its write high-water mark after prepare (@init / @slider), from the CPU port."""
+    from oracle import port
+    if not port.port_path(leaf).exists():
+        pytest.skip(f"port of {leaf} not built")
+    p = port.Port(leaf, float(g["srate"]))
+    p.set_sliders(g["sliders"]); p.prepare()
+    return p.mem(0, 1 << 16), p.mem_high
+
+
+def test_delay_line_conditions_are_checked_chunk_by_chunk():
+    """A write position that jumps twice inside one chunk is not a ring's wrap: the staged algorithm stops at that chunk (the
+    kernel hands the rest of the launch to the generic code); a stride of two stops it at frame 0."""
+    from zajit import tpar
+    plan, _ = _plan("fx_ringabort")
+    for case, f0 in (("fx_ringabort_default", 960), ("fx_ringabort_stride2", 0)):
+        g = load_golden(case)
+        names = [str(s) for s in g["var_names"]]
+        v0 = {n: (0.0 if np.isnan(v) else float(v)) for n, v in zip(names, g["vars_prepared"])}
+        mem0, _ = _prepared_arena("fx_ringabort", g)
+        with pytest.raises(tpar.TparAbort) as ei:
+            plan.simulate(v0, golden_input(g), sliders=g["sliders"], mem=mem0)
+        assert ei.value.f0 == f0
 
 
 def test_recurrence_zoo_classification():
@@ -78,7 +104,7 @@ def test_switched_recurrences_fall_back_to_the_serial_loop(monkeypatch):
 
 def test_unsupported_scripts_keep_the_generic_kernel_only():
     from zajit import program, tpar
-    for fx, why in (("delaytaps", "mem"), ("slidewrite", "@block"), ("stft", "mem")):
+    for fx, why in (("delaytaps", "loop()"), ("slidewrite", "@block"), ("stft", "loop()")):
         plan, msg = tpar.try_plan(program.analyse_file(FIXTURES / f"{fx}.jsfx"), 2)
         assert plan is None and why in msg, (fx, msg)
 
@@ -91,9 +117,14 @@ def test_staged_algorithm_matches_reference_vm(case):
     names = [str(s) for s in g["var_names"]]
     v0 = {n: (0.0 if np.isnan(v) else float(v)) for n, v in zip(names, g["vars_prepared"])}
     x = golden_input(g)
-    y, va, _ = plan.simulate(v0, x, sliders=g["sliders"], srate=float(g["srate"]))
+    mem0, high0 = _prepared_arena(leaf, g) if plan.stats["mem_cells"] + plan.stats["delay_writes"] else (None, 0)
+    y, va, _ = plan.simulate(v0, x, sliders=g["sliders"], srate=float(g["srate"]), mem=mem0)
     assert np.abs(y.astype(np.float64) - g["out"]).max() <= AUDIO_EPS
     assert_state_close(names, [va.get(n, 0.0) for n in names], g["vars"], what=f"{case} vars")
+    if mem0 is not None:
+        want = np.zeros(len(mem0)); want[g["mem_idx"]] = g["mem_val"]
+        assert np.abs(plan.mem_after - want).max() <= SCALAR_EPS
+        assert max(plan.mem_high_after, high0) == int(g["mem_high"])
     if case == "fx_randkat_default":            # 6021 draws: nine generations of the generator, conditional bursts included
         assert va["draws"] == 6021.0 and plan.mt_after[1] == 6021 - 9 * 624
 
@@ -133,7 +164,7 @@ def test_staged_algorithm_is_independent_of_launch_boundaries():
 
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", TPAR_FIXTURES + [f"{l}_default" for l in TPAR_CATALOG])
+@pytest.mark.parametrize("case", TPAR_FIXTURES + TPAR_ABORTS + [f"{l}_default" for l in TPAR_CATALOG])
 def test_tpar_kernel_matches_reference_vm(case):
     import zabatch
     leaf = leaf_of(case)
@@ -153,18 +184,24 @@ def test_tpar_kernel_matches_reference_vm(case):
             assert e.used_fast_path() == (label == "tpar")
             if label == "tpar":
                 assert e.last_kernel_name().endswith("_tpar")
-            res[label] = (y, e.read_vars())
-    for label, (y, v) in res.items():
+            high = e.mem_high()
+            mem = e.read_mem(0, int(g["mem_high"])) if int(g["mem_high"]) else None
+            res[label] = (y, e.read_vars(), high, mem)
+    for label, (y, v, high, mem) in res.items():
         err = np.abs(y.astype(np.float64) - g["out"].astype(np.float64)[None]).max()
         print(f"{case} [{label}]: null test max {dbfs(err):.1f} dBFS")
         assert err <= AUDIO_EPS, label
         for i in (0, n - 1):
             assert_state_close(names, v[i], g["vars"], what=f"{case} {label} vars[{i}]")
+        assert (high == int(g["mem_high"])).all(), (label, high)
+        if mem is not None:
+            want = np.zeros(int(g["mem_high"])); want[g["mem_idx"]] = g["mem_val"]
+            assert np.abs(mem - want[None]).max() <= SCALAR_EPS, label
     assert np.array_equal(res["tpar"][0][0], res["tpar"][0][n - 1])
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("leaf", ["fx_dynkat", "fx_randkat"] + TPAR_CATALOG)
+@pytest.mark.parametrize("leaf", ["fx_dynkat", "fx_randkat", "fx_ringkat", "fx_ringabort"] + TPAR_CATALOG)
 def test_tpar_kernel_tracks_generic_kernel_over_a_long_run_and_across_launches(leaf):
     """One second of audio, distinct noise and sliders per instance: the time-parallel kernel in ragged launches (lengths with
     chunk remainders 1, 63, 0 and a single frame) against the generic kernel in one launch -- audio within the reference's
@@ -188,7 +225,7 @@ def test_tpar_kernel_tracks_generic_kernel_over_a_long_run_and_across_launches(l
         e.set_sliders(rows); e.prepare()
         want = e.process_host(x, block=512)
         want_v = e.read_vars(); names = e.var_names()
-        want_ck = e.checkpoint()
+        want_ck = e.checkpoint()                                 # (arena up to the write high-water mark, marks, rand() state)
     cuts = [0, 1, 66, 66 + 63, 4096 + 129, 30000, frames]
     with zabatch.Engine(leaf, n, path=zabatch.ZAB_PATH_FAST) as e:
         e.set_sliders(rows); e.prepare()
@@ -197,6 +234,9 @@ def test_tpar_kernel_tracks_generic_kernel_over_a_long_run_and_across_launches(l
         got_v = e.read_vars()
         got_ck = e.checkpoint()
     assert np.array_equal(got_ck["mti"], want_ck["mti"]) and np.array_equal(got_ck["mt"], want_ck["mt"])     # rand() state
+    assert np.array_equal(got_ck["mem_high"], want_ck["mem_high"])
+    if want_ck["mem_data"].size:
+        assert np.abs(got_ck["mem_data"] - want_ck["mem_data"]).max() <= SCALAR_EPS
     err = np.abs(got.astype(np.float64) - want.astype(np.float64)).max()
     print(f"{leaf}: tpar vs generic over {frames} frames: {dbfs(err):.1f} dBFS")
     assert err <= AUDIO_EPS

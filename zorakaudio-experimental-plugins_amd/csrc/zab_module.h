@@ -6,7 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define ZAB_MODULE_ABI 13
+#define ZAB_MODULE_ABI 14
 
 enum { ZAB_FLAG_SLIDER_DIRTY = 1u, ZAB_FLAG_PREPARED = 2u };
 
@@ -46,6 +46,9 @@ struct ZabBatch {
                                                // two): instance i runs in lane i % ipw of workgroup i / ipw
   int32_t lmem_words;                          // process kernel keeps mem[0, lmem_words) of its instances in LDS (0 = off);
                                                // chosen by the runtime after prepare from the instances' arena footprint
+  int64_t* resume;                             // [n_pad] frames of the current launch already done by a time-parallel kernel
+                                               // (zajit/tpar.py): == frames normally; less when it handed an instance back to
+                                               // the generic code, which then finishes the launch from there
 };
 
 struct ZabAudio {

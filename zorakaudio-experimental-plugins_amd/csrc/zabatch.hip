@@ -337,7 +337,7 @@ int zab_create(const char* module, const zab_config* cfg, zab_engine** out) {
       (rc = e->alloc(&b.mem_high, (size_t)P)) || (rc = e->alloc(&b.mem_need, (size_t)P)) ||
       (rc = e->alloc(&b.err, (size_t)P)) || (rc = e->alloc(&b.flags, (size_t)P)) ||
       (rc = e->alloc(&b.pend, (size_t)P * 4)) ||      /* change / automate / automate-end, + their OR since the host last looked */ (rc = e->alloc(&b.vis_mask, (size_t)P)) ||
-      (rc = e->alloc(&b.vis_init, (size_t)P)) ||
+      (rc = e->alloc(&b.vis_init, (size_t)P)) || (rc = e->alloc(&b.resume, (size_t)P)) ||
       (m->fft_scratch_doubles > 0 && (rc = e->alloc(&b.fft, (size_t)P * m->fft_scratch_doubles))) ||
       (m->uses_gmem && (rc = setup_gmem(e))) ||
       (m->uses_files && ((rc = e->alloc(&e->d_files, 1)) || (rc = e->alloc(&b.fh, (size_t)P * kFileHandleWords)))) ||

@@ -24,6 +24,14 @@ __device__ __forceinline__ double zt_readlane(double v, int l) {      // l must 
   return __builtin_bit_cast(double, t);
 }
 
+// value of an arbitrary lane, per lane (LDS crossbar, no LDS memory); src must be 0..63
+__device__ __forceinline__ double zt_bperm(double v, int src) {
+  int2 t = __builtin_bit_cast(int2, v);
+  t.x = __builtin_amdgcn_ds_bpermute(src << 2, t.x);
+  t.y = __builtin_amdgcn_ds_bpermute(src << 2, t.y);
+  return __builtin_bit_cast(double, t);
+}
+
 // A value every lane computed identically, declared wave-uniform: it can live in scalar registers (or, spilled, in single
 // lanes of a vector register) instead of occupying a vector register pair in all 64 lanes.
 __device__ __forceinline__ double zt_uniform(double v) {
@@ -94,7 +102,12 @@ __device__ __forceinline__ double zt_pow_row(double a, int lane) {   // a^((lane
   for (int k = 0; k < 5; ++k) { r = ((e >> k) & 1) ? r * p : r; p = p * p; }
   return r;
 }
+__device__ __forceinline__ double zt_scan1_sum(double b, double y_in, int lane);
 __device__ __forceinline__ double zt_scan1_inv(double b, double a, const ZtPow& q, double w, double y_in, int lane) {
+  // (a is wave-uniform.) 0 and 1 are what a variable assigned under a launch-constant condition turns into -- `mode ? x = e`
+  // is x = mode ? e : x, i.e. a = 0 or a = 1 for the whole launch -- and neither needs the weighted scan
+  if (a == 0.0) return b;
+  if (a == 1.0) return zt_scan1_sum(b, y_in, lane);
   b = lane == 0 ? __builtin_fma(a, y_in, b) : b;
   b = __builtin_fma(a, zt_dppz<ZT_ROW_SHR(1)>(b), b);
   b = __builtin_fma(q.a2, zt_dppz<ZT_ROW_SHR(2)>(b), b);

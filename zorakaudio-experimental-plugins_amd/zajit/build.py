@@ -164,7 +164,10 @@ def module_source(unit: codegen.Unit) -> str:
     from .emit import FFT_CALLS
     fft_hot = bool(_hot_calls(p) & set(FFT_CALLS)) or ("coop" in unit.features and "gmem" not in unit.features)   # replica lanes
     # (2 = instance-major AND thin wavefronts with replica lanes while the batch is small, see zabatch.hip / zab_generic)
-    lines.append(f"  {2 if fft_hot else (1 if name in INSTANCE_MAJOR else 0)}, 65536, za_var_names, {2 * 32768 if 'fft' in unit.features else 0}, {(2 if p.options.get('gmem') else 1) if 'gmem' in unit.features else 0}, {1 if 'pool' in unit.features else 0}, {1 if 'file' in unit.features else 0}, {1 if 'msg' in unit.features else 0},")
+    # leaves whose time-parallel kernel reads delay lines: 64 consecutive frames of ONE instance per access, so its arena must be
+    # contiguous (interleaved, those 64 reads would touch 64 cache lines)
+    tp_mem = plan is not None and bool(plan.loads or plan.stores)
+    lines.append(f"  {2 if fft_hot else (1 if (name in INSTANCE_MAJOR or tp_mem) else 0)}, 65536, za_var_names, {2 * 32768 if 'fft' in unit.features else 0}, {(2 if p.options.get('gmem') else 1) if 'gmem' in unit.features else 0}, {1 if 'pool' in unit.features else 0}, {1 if 'file' in unit.features else 0}, {1 if 'msg' in unit.features else 0},")
     lines.append("  za_launch_prepare, za_launch_process, za_launch_slider,")
     if fast:
         lines.append("  za_fast_applies, za_launch_fast, ZA_FAST_KERNEL_NAME,")
@@ -191,7 +194,9 @@ def build_module(jsfx_path, name: Optional[str] = None, force=False, verbose=Fal
     so = LIB / f"libzab_{prog.name}.so"
     leaf_flags = LEAF_FLAGS.get(prog.name, [])
     text = module_source(unit) + (f"// leaf build flags: {' '.join(leaf_flags)}\n" if leaf_flags else "")
-    deps = [CSRC / "zart.h", CSRC / "zab_generic.hip.h", CSRC / "zab_module.h", CSRC / "zart_tpar.h"]
+    deps = [CSRC / "zart.h", CSRC / "zab_generic.hip.h", CSRC / "zab_module.h"]
+    if "zart_tpar.h" in text:
+        deps.append(CSRC / "zart_tpar.h")
     if prog.name in FAST_KERNELS:
         deps.append(CSRC / FAST_KERNELS[prog.name])
     for extra in ("zart_fft.h", "zart_gmem.h", "zart_pool.h", "zart_file.h", "zart_msg.h"):

@@ -49,17 +49,21 @@ class Unsupported(Exception):
 
 
 class N:
-    __slots__ = ("i", "kind", "op", "args", "val", "name", "uniform")
+    __slots__ = ("i", "kind", "op", "args", "val", "name", "uniform", "su", "extra")
 
     def __init__(self, i, kind, op=None, args=(), val=None, name=None):
         self.i, self.kind, self.op, self.args, self.val, self.name = i, kind, op, tuple(args), val, name
         self.uniform = False
+        self.su = False          # built from constants and variables @sample never assigns: constant over a launch (known while walking)
+        self.extra = ()          # ld: nodes this load must wait for besides its address (the stores it may have to forward from)
 
     def __repr__(self):
         if self.kind == "const":
             return f"#{self.i}:{self.val!r}"
         if self.kind in ("var", "inv", "st", "in"):
             return f"#{self.i}:{self.kind}({self.name})"
+        if self.kind == "ld":
+            return f"#{self.i}:ld({self.args[0].i})"
         return f"#{self.i}:{self.op}(" + ",".join(str(a.i) for a in self.args) + ")"
 
 
@@ -83,6 +87,20 @@ class FrameGraph:
         self.scope: List[Dict[str, str]] = []
         self.depth = 0
         self.rand_sites = 0
+        # variables assigned anywhere in @sample (or a function it can reach): everything else is constant over a launch, which
+        # lets the walk tell launch-constant addresses (mem[] cells used as named state) from moving ones (delay lines)
+        self.wsyn = set()
+        todo = list(prog.sections.get("sample", [])) + [f.body for f in prog.fns.values()]
+        while todo:
+            x = todo.pop()
+            if isinstance(x, S.Assign) and isinstance(x.target, S.Var):
+                self.wsyn.add(x.target.name)
+            todo.extend(S.children(x))
+        self.pred: Optional[N] = None            # path condition of the statement being walked (None: unconditional)
+        self.mem_seq = 0                         # program order of the memory operations of a frame
+        self.cells: Dict[str, N] = {}            # "mem@<id>" -> its (launch-constant) address node
+        self.loads: List[N] = []                 # moving-address loads
+        self.stores: List["StoreSite"] = []      # moving-address stores
         self.ZERO, self.ONE = self.const(0.0), self.const(1.0)
 
     # -- node construction -------------------------------------------------------------------------------------------------
@@ -91,6 +109,12 @@ class FrameGraph:
         n = self.memo.get(key)
         if n is None:
             n = N(len(self.nodes), kind, op, args, val, name)
+            if kind == "const":
+                n.su = True
+            elif kind == "var":
+                n.su = name not in self.wsyn and name != RNG_INDEX and not name.startswith("mem@") and not name.startswith("memw@")
+            elif kind == "op":
+                n.su = op != "mtout" and all(a.su for a in args)
             self.nodes.append(n)
             self.memo[key] = n
         return n
@@ -128,7 +152,8 @@ class FrameGraph:
         elif key == "samplesblock":
             raise Unsupported("@sample reads samplesblock (per host block)")
         else:
-            if (is_slider_name(key) is None and key not in ("srate", "midi_bus", "ext_midi_bus", RNG_INDEX) and key not in self.p.vars):
+            if (is_slider_name(key) is None and key not in ("srate", "midi_bus", "ext_midi_bus", RNG_INDEX) and key not in self.p.vars
+                    and key not in self.cells and not key.startswith("memw@")):
                 raise Unsupported(f"unknown variable {key}")
             n = self.mk("var", name=key)
         self.varnodes[key] = n
@@ -144,7 +169,7 @@ class FrameGraph:
             k = is_spl_name(key)
             if k is not None and not 0 <= k < 64:
                 raise Unsupported("spl index out of range")
-            if k is None and key not in self.p.vars and key != RNG_INDEX:
+            if k is None and key not in self.p.vars and key != RNG_INDEX and key not in self.cells and not key.startswith("memw@"):
                 raise Unsupported(f"unknown variable {key}")
             if key not in self.written:
                 self.written.append(key)
@@ -178,8 +203,52 @@ class FrameGraph:
                 return self.ZERO
         return self.read(nm)
 
+    # -- mem[] ---------------------------------------------------------------------------------------------------------------
+    def _address(self, n) -> N:
+        if isinstance(n.base, S.Var) and n.base.name == "gmem":
+            raise Unsupported("gmem[] access in @sample")
+        b = self.ev(n.base)
+        i = self.ev(n.index)
+        return self.op("addr", b, i)              # za_addr(base, index) of csrc/zart.h, as a double
+
+    def _region(self, a: N) -> tuple:
+        """Launch-constant terms of base + index: accesses that differ in them are taken to address different buffers (checked
+        at run time, chunk by chunk: a load that falls into another buffer's freshly written span aborts the fast path)."""
+        terms, todo = [], list(a.args)
+        while todo:
+            x = todo.pop()
+            if x.kind == "op" and x.op == "+":
+                todo.extend(x.args)
+            elif x.su and not (x.kind == "const" and x.val == 0.0):
+                terms.append(x.i)
+        return tuple(sorted(terms))
+
+    def _cell(self, a: N) -> str:
+        key = f"mem@{a.i}"
+        self.cells[key] = a
+        return key
+
+    def _load(self, a: N) -> N:
+        if a.su:                                   # a cell: mem[] used as a named state variable
+            return self.read(self._cell(a))
+        self.mem_seq += 1
+        ld = self.mk("ld", args=(a,), val=self.mem_seq)
+        self.loads.append(ld)
+        return ld
+
+    def _store(self, a: N, v: N):
+        if a.su:
+            key = self._cell(a)
+            self.write(key, v)
+            # "has this cell been stored to in this launch": the write high-water mark of the arena moves only for executed
+            # stores, and a store under a condition may never run. (An ordinary state: its updates merge like any variable's.)
+            self.write("memw@" + key[4:], self.ONE)
+            return
+        self.mem_seq += 1
+        self.stores.append(StoreSite(len(self.stores), a, v, self.pred, self.mem_seq, self._region(a)))
+
     def v_Index(self, n):
-        raise Unsupported("mem[] / gmem[] access in @sample")
+        return self._load(self._address(n))
 
     def v_Loop(self, n):
         raise Unsupported("loop() in @sample")
@@ -203,9 +272,12 @@ class FrameGraph:
     def v_Binary(self, n):
         if n.op in ("&&", "||"):
             l = self.ev(n.l)
-            env0 = self.env
+            env0, pred0 = self.env, self.pred
             self.env = dict(env0)
+            gate = l if n.op == "&&" else self.op("not", l)          # the right operand runs iff ...
+            self.pred = gate if pred0 is None else self.op("land", pred0, gate)
             r = self.ev(n.r)
+            self.pred = pred0
             env_r = self.env
             if all(env_r.get(k) is v for k, v in env0.items()) and len(env_r) == len(env0):
                 self.env = env0                      # right operand has no effects: both sides evaluated, plain logic
@@ -244,14 +316,17 @@ class FrameGraph:
 
     def _branch(self, cond_ast, then_ast, else_ast) -> Tuple[N, N]:
         c = self.ev(cond_ast)
-        env0 = self.env
-        scope_keys = None
+        env0, pred0 = self.env, self.pred
         self.env = dict(env0)
+        self.pred = c if pred0 is None else self.op("land", pred0, c)
         vt = self.ev(then_ast) if then_ast is not None else self.ZERO
         env_t = self.env
         self.env = dict(env0)
+        nc = self.op("not", c)
+        self.pred = nc if pred0 is None else self.op("land", pred0, nc)
         ve = self.ev(else_ast) if else_ast is not None else self.ZERO
         env_e = self.env
+        self.pred = pred0
         self.env = self._merge(c, env_t, env_e, env0)
         return c, self.sel(c, vt, ve)
 
@@ -273,8 +348,19 @@ class FrameGraph:
     def v_Assign(self, n):
         tgt = n.target
         rhs = self.ev(n.value)
+        if isinstance(tgt, S.Index):               # value first, then base and index (zajit/emit.py e_Assign)
+            a = self._address(tgt)
+            if n.op == "=":
+                val = rhs
+            else:
+                bop = n.op[:-1]
+                if bop not in BIN_OPS:
+                    raise Unsupported(f"assignment operator {n.op}")
+                val = self.op(bop, self._load(a), rhs)
+            self._store(a, val)
+            return val
         if not isinstance(tgt, S.Var):
-            raise Unsupported("assignment to mem[] / slider() / spl() in @sample")
+            raise Unsupported("assignment to slider() / spl() in @sample")
         if n.op == "=":
             val = rhs
         else:
@@ -340,6 +426,13 @@ class FrameGraph:
 # ----------------------------------------------------------------------------------------------------------------------
 # 2. analysis: recurrences, affine forms, schedule
 # ----------------------------------------------------------------------------------------------------------------------
+class StoreSite:
+    """One moving-address store of the frame (a delay line's write)."""
+
+    def __init__(self, j, addr, value, pred, seq, region):
+        self.j, self.addr, self.value, self.pred, self.seq, self.region = j, addr, value, pred, seq, region
+
+
 class Component:
     """One recurrence: the state variables whose state-in nodes lie on a common cycle."""
 
@@ -373,6 +466,9 @@ class Plan:
         self.inputs: List[N] = []
         self.stats: Dict[str, int] = {}
         self.uses_rand = False
+        self.cells: Dict[str, N] = {}            # "mem@<id>" -> launch-constant address node (mem[] used as named state)
+        self.stores: List[StoreSite] = []        # delay-line writes (moving addresses), program order
+        self.loads: List[N] = []                 # delay-line reads
 
     # ------------------------------------------------------------------------------------------------------------------
     # numpy restatement of the staged algorithm (tests)
@@ -402,10 +498,14 @@ class Plan:
             caps[nm][tn:] = cur[nm]
             val[self.st[nm].i] = caps[nm]
 
-    def simulate(self, vars0: Dict[str, float], x: np.ndarray, sliders=None, srate=48000.0, spl0=None, mt=None):
+    def simulate(self, vars0: Dict[str, float], x: np.ndarray, sliders=None, srate=48000.0, spl0=None, mt=None, mem=None):
         """x: [nch, frames] float32. vars0: name -> value before the launch (missing names are 0). mt: (randMT[624], randIndex)
-        before the launch for scripts that call rand(); self.mt_after holds the pair after it.
-        Returns (y float32 [nch, frames], vars after {name: value}, spl after {k: value})."""
+        before the launch for scripts that call rand(); self.mt_after holds the pair after it. mem: the arena before the launch
+        (numpy doubles) for scripts that touch mem[]; self.mem_after / self.mem_high_after hold it after.
+        Returns (y float32 [nch, frames], vars after {name: value}, spl after {k: value}). Raises TparAbort when a chunk breaks
+        one of the run-time conditions of the delay-line handling (the kernel hands such a launch to the generic kernel)."""
+        memv = np.zeros(1 << 16) if mem is None else np.array(mem, dtype=np.float64)
+        mem_high = 0
         stream = MtStream(*(mt if mt is not None else (None, 0))) if self.uses_rand else None
         _MT_CTX[0] = stream
         x = np.asarray(x, dtype=np.float32)
@@ -419,8 +519,11 @@ class Plan:
                 return float(sliders[k - 1])
             if name == "srate":
                 return float(srate)
-            if name in ("midi_bus", "ext_midi_bus", RNG_INDEX):
+            if name in ("midi_bus", "ext_midi_bus", RNG_INDEX) or name.startswith("memw@"):
                 return 0.0
+            if name in self.cells:
+                a = int(val[self.cells[name].i])
+                return float(memv[a]) if a < len(memv) else 0.0
             k = is_spl_name(name)
             if k is not None:
                 return float(spl_state.get(k, 0.0))
@@ -436,7 +539,11 @@ class Plan:
                     val[n.i] = np.float64(inv_value(n.name))
                 else:
                     val[n.i] = _np_op(n.op, [val[a.i] for a in n.args])
+            cell_addr = {name: int(val[a.i]) for name, a in self.cells.items()}
+            if len(set(cell_addr.values())) != len(cell_addr) or any(a >= len(memv) for a in cell_addr.values()):
+                raise TparAbort(0, "mem[] cells alias each other or lie past the arena")
             carry = {name: np.float64(inv_value(name)) for name in self.st}
+            sites: Dict[int, dict] = {}
             y = np.zeros_like(x)
             final_vals: Dict[int, float] = {}
             lane = np.arange(WAVE)
@@ -447,9 +554,44 @@ class Plan:
                     col = np.zeros(WAVE)
                     col[:tn] = x[int(n.val), f0:f0 + tn].astype(np.float64)
                     val[n.i] = col
+                sites.clear()
                 for it in self.items:
                     kind = it[0]
-                    if kind == "par":
+                    if kind == "site":
+                        st_: StoreSite = it[1]
+                        A = np.broadcast_to(val[st_.addr.i], (WAVE,)).astype(np.int64)
+                        d = np.diff(A[:tn])
+                        brk = np.flatnonzero(d != 1)
+                        if len(brk) > 1 or A[:tn].min() < 0 or A[:tn].max() >= len(memv):
+                            raise TparAbort(f0, "a delay-line write does not advance by one cell per frame (or leaves the arena)")
+                        k = int(brk[0]) + 1 if len(brk) else tn
+                        sites[st_.j] = {"A": A, "a0": int(A[0]), "k": k, "ak": int(A[k]) if k < tn else 0}
+                        if any(lo <= a <= hi for a in cell_addr.values() for lo, hi in ((A[:tn].min(), A[:tn].max()),)):
+                            raise TparAbort(f0, "a delay line runs over a mem[] cell")
+                    elif kind == "par" and it[1].kind == "ld":
+                        n = it[1]
+                        B = np.broadcast_to(val[n.args[0].i], (WAVE,)).astype(np.int64)
+                        out = np.where(B < len(memv), memv[np.minimum(B, len(memv) - 1)], 0.0)
+                        best = np.full(WAVE, -1)
+                        for st_ in self.stores:
+                            si = sites[st_.j]
+                            tw = np.full(WAVE, -1)
+                            d0 = B - si["a0"]
+                            tw = np.where((d0 >= 0) & (d0 < si["k"]), d0, tw)
+                            d1 = B - si["ak"]
+                            tw = np.where((d1 >= 0) & (d1 < tn - si["k"]), si["k"] + d1, tw)
+                            if ",".join(map(str, st_.region)) != n.name:
+                                if np.any(tw[:tn] >= 0):
+                                    raise TparAbort(f0, "a delay-line read falls into another buffer's freshly written span")
+                                continue
+                            vis = (tw >= 0) & ((tw < lane) | ((tw == lane) & (st_.seq < n.val))) & (tw >= best)
+                            V = np.broadcast_to(val[st_.value.i], (WAVE,)).astype(np.float64)
+                            out = np.where(vis, V[np.clip(tw, 0, WAVE - 1)], out)
+                            best = np.where(vis, tw, best)
+                        if any(np.any(B[:tn] == a) for a in cell_addr.values()):
+                            raise TparAbort(f0, "a delay-line read hits a mem[] cell")
+                        val[n.i] = out
+                    elif kind == "par":
                         n = it[1]
                         val[n.i] = np.broadcast_to(_np_op(n.op, [val[a.i] for a in n.args]), (WAVE,)).astype(np.float64)
                     elif kind == "shift":
@@ -511,6 +653,10 @@ class Plan:
                                 self._sim_serial(comp, val, carry, tn)
                     else:
                         raise AssertionError(kind)
+                for st_ in self.stores:                    # the chunk's writes land after all of its reads are resolved
+                    si = sites[st_.j]
+                    memv[si["A"][:tn]] = np.broadcast_to(val[st_.value.i], (WAVE,))[:tn]
+                    mem_high = max(mem_high, int(si["A"][:tn].max()) + 1)
                 for ch in range(self.nch):
                     v = np.broadcast_to(val[self.spl_out[ch].i], (WAVE,))
                     y[ch, f0:f0 + tn] = v[:tn].astype(np.float32)
@@ -529,11 +675,27 @@ class Plan:
         final_vals.pop(RNG_INDEX, None)
         for name, v in final_vals.items():
             k = is_spl_name(name)
-            if k is not None:
+            if name.startswith("memw@"):
+                continue
+            if name in self.cells:
+                if final_vals.get("memw@" + name[4:], 0.0) != 0.0:       # stored to at least once in this launch
+                    memv[cell_addr[name]] = v
+                    mem_high = max(mem_high, cell_addr[name] + 1)
+            elif k is not None:
                 spl_after[k] = v
             else:
                 vars_after[name] = v
+        self.mem_after, self.mem_high_after = memv, mem_high
         return y, vars_after, spl_after
+
+
+class TparAbort(Exception):
+    """A chunk broke a run-time condition of the delay-line handling at frame `f0`; the kernel stops there and the generic
+    kernel finishes the launch."""
+
+    def __init__(self, f0, why):
+        super().__init__(f"frame {f0}: {why}")
+        self.f0, self.why = f0, why
 
 
 class MtStream:
@@ -701,6 +863,9 @@ def _np_op(op, a):
         return np.arctan2(a[0], a[1])
     if op == "mtout":
         return _MT_CTX[0].word(np.asarray(a[0]))
+    if op == "addr":          # za_addr: trunc(base + index + 1e-5), negatives (and NaN) to 0
+        x = np.asarray(a[0], dtype=np.float64) + a[1] + 1.0e-5
+        return np.where(x > 0.0, np.trunc(np.where(x > 0.0, x, 0.0)), 0.0)
     if op in PURE_MATH1:
         f = {"sin": np.sin, "cos": np.cos, "sqrt": np.sqrt, "fabs": np.fabs, "floor": np.floor, "ceil": np.ceil, "asin": np.arcsin,
              "acos": np.arccos, "atan": np.arctan, "exp": np.exp, "log": np.log, "tan": np.tan, "log10": np.log10}[op]
@@ -782,16 +947,31 @@ def build_plan(prog: Program, nch: int) -> Plan:
     plan.outs = {name: g.env[name] for name in written}
     plan.spl_out = [g.env.get(f"spl{ch}", None) or g.read(f"spl{ch}") for ch in range(nch)]
     plan.st = {name: vn for name, vn in g.varnodes.items() if vn.kind == "st"}
+    plan.cells = dict(g.cells)
+    plan.stores, plan.loads = list(g.stores), list(g.loads)
+    for st_ in plan.stores:
+        if st_.pred is not None:
+            raise Unsupported("conditional store to a moving mem[] address")
+    if plan.stores and g.rand_sites:
+        raise Unsupported("rand() together with delay lines")
+    for ld in plan.loads:
+        # a load may have to take its value from a store of this chunk: it waits for every store of its own buffer (address
+        # and value) and, for the aliasing check, for the addresses of all the others
+        reg = g._region(ld.args[0])
+        ld.name = ",".join(map(str, reg))
+        ld.extra = tuple(x for st_ in plan.stores for x in ((st_.addr, st_.value) if st_.region == reg else (st_.addr,)))
 
     # live nodes
     live: Dict[int, N] = {}
-    todo = list(plan.outs.values()) + list(plan.spl_out)
+    todo = list(plan.outs.values()) + list(plan.spl_out) + [x for st_ in plan.stores for x in (st_.addr, st_.value)]
+    todo += [a for a in plan.cells.values()]
     while todo:
         n = todo.pop()
         if n.i in live:
             continue
         live[n.i] = n
         todo.extend(n.args)
+        todo.extend(n.extra)
         if n.kind == "st":
             todo.append(plan.outs[n.name])
     order = sorted(live)                     # creation order is a topological order of the in-frame edges
@@ -799,7 +979,7 @@ def build_plan(prog: Program, nch: int) -> Plan:
     succ: List[List[int]] = [[] for _ in order]
     for i in order:
         n = live[i]
-        for a in n.args:
+        for a in n.args + n.extra:
             succ[pos[a.i]].append(pos[i])
         if n.kind == "st":
             succ[pos[plan.outs[n.name].i]].append(pos[i])
@@ -812,6 +992,8 @@ def build_plan(prog: Program, nch: int) -> Plan:
         if not cyclic:
             continue
         members = [live[i] for i in sorted(ids)]
+        if any(m.kind == "ld" for m in members):
+            raise Unsupported("feedback through a delay line (a stored value depends on a load of the same buffer)")
         names = [m.name for m in members if m.kind == "st"]
         names.sort(key=lambda nm: written.index(nm))
         c = Component(names, members)
@@ -824,7 +1006,7 @@ def build_plan(prog: Program, nch: int) -> Plan:
         n = live[i]
         if n.kind in ("const", "inv"):
             n.uniform = True
-        elif n.kind in ("st", "in"):
+        elif n.kind in ("st", "in", "ld"):
             n.uniform = False
         else:
             n.uniform = all(a.uniform for a in n.args) and n.i not in comp_of
@@ -887,6 +1069,7 @@ def build_plan(prog: Program, nch: int) -> Plan:
         else:
             c.inputs = ext
 
+    site_done: set = set()
     remaining = list(pending_nodes)
     guard = 0
     while remaining:
@@ -911,7 +1094,12 @@ def build_plan(prog: Program, nch: int) -> Plan:
                 else:
                     nxt.append(n)
                 continue
-            if all(a.i in done for a in n.args):
+            if all(a.i in done for a in n.args + n.extra):
+                if n.kind == "ld":
+                    for st_ in plan.stores:              # every write's span is known before the first read is resolved
+                        if st_.j not in site_done:
+                            site_done.add(st_.j)
+                            items.append(("site", st_))
                 items.append(("par", n))
                 done.add(n.i)
                 progressed = True
@@ -936,6 +1124,9 @@ def build_plan(prog: Program, nch: int) -> Plan:
         items.append((kind, [components[ci] for ci in ready]))
         for ci in ready:
             comp_done[ci] = True
+    for st_ in plan.stores:
+        if st_.j not in site_done:
+            items.append(("site", st_))
     plan.items = items
     plan.uses_rand = RNG_INDEX in plan.outs
     plan.stats = {
@@ -950,6 +1141,7 @@ def build_plan(prog: Program, nch: int) -> Plan:
         "serial_chains": sum(len(it[1]) for it in items if it[0] == "serial"),
         "serial_ops": sum(len([m for m in c.members if m.kind != "st"]) for it in items if it[0] == "serial" for c in it[1]),
         "states": len(plan.st), "written": len(plan.outs), "rand_sites": g.rand_sites,
+        "mem_cells": len(plan.cells), "delay_writes": len(plan.stores), "delay_reads": len(plan.loads),
     }
     return plan
 
@@ -1230,6 +1422,8 @@ def _expr(op: str, a: List[str]) -> str:
         return f"{PURE_MATH1[op]}({a[0]})"
     if op == "mtout":
         return f"zt_mt_word(zt_mt, zt_pos0, {a[0]})"
+    if op == "addr":
+        return f"(double)za_addr({a[0]}, {a[1]})"
     raise AssertionError(op)
 
 
@@ -1249,14 +1443,18 @@ def emit_hip(plan: Plan, prog: Program, kernel_macro: str = "ZA_KERNEL(tpar)") -
             return f"b.sliders[{k - 1} * b.sl_se + inst * b.sl_si]"
         if name == "srate":
             return "b.srate"
-        if name in ("midi_bus", "ext_midi_bus", RNG_INDEX):
+        if name in ("midi_bus", "ext_midi_bus", RNG_INDEX) or name.startswith("memw@"):
             return "0.0"
+        if name in plan.cells:
+            return f"(ca{plan.cells[name].i} < mcap ? memp[ca{plan.cells[name].i} * mse] : 0.0)"
         k = is_spl_name(name)
         if k is not None:
             return f"b.spl[{k} * b.sl_se + inst * b.sl_si]"
         return f"b.vars[{prog.vars[name]} * b.var_se + inst * b.var_si]"
 
     def dst(name: str) -> str:
+        if name in plan.cells:
+            return f"memp[ca{plan.cells[name].i} * mse]"
         k = is_spl_name(name)
         if k is not None:
             return f"b.spl[{k} * b.sl_se + inst * b.sl_si]"
@@ -1289,6 +1487,30 @@ def emit_hip(plan: Plan, prog: Program, kernel_macro: str = "ZA_KERNEL(tpar)") -
             L.append(f"  const double u{n.i} = {inv_src(n.name)};   // {n.name}")
         else:
             L.append(f"  const double u{n.i} = ZT_UNI({_expr(n.op, [ref(x) for x in n.args])});")
+    has_mem = bool(plan.cells or plan.stores or plan.loads)
+    has_streams = bool(plan.stores)
+    cell_addrs: List[N] = []
+    for a in plan.cells.values():
+        if a not in cell_addrs:
+            cell_addrs.append(a)
+    if has_mem:
+        L.append("  // mem[]: launch-constant addresses are cells (named state kept in registers), moving ones are delay lines")
+        L.append("  double* const memp = b.mem + inst * b.mem_si;")
+        L.append("  const int64_t mse = b.mem_se, mcap = b.mem_cap;")
+        L.append("  int64_t zt_high = b.mem_high[inst], zt_hc = 0;")
+        for a in cell_addrs:
+            L.append(f"  const int64_t ca{a.i} = (int64_t){ref(a)};")
+        if cell_addrs:
+            clash = " || ".join([f"ca{a.i} >= mcap" for a in cell_addrs] +
+                                [f"ca{a.i} == ca{b_.i}" for i_, a in enumerate(cell_addrs) for b_ in cell_addrs[i_ + 1:]])
+            lo = cell_addrs[0]
+            L.append(f"  int64_t cmin = ca{lo.i}, cmax = ca{lo.i};")
+            for a in cell_addrs[1:]:
+                L.append(f"  cmin = ca{a.i} < cmin ? ca{a.i} : cmin; cmax = ca{a.i} > cmax ? ca{a.i} : cmax;")
+            L.append(f"  if ({clash}) {{   // cells that alias each other (or lie past the arena): not a case for this kernel")
+            L.append("    if (lane == 0) b.resume[inst] = 0;")
+            L.append("    return;")
+            L.append("  }")
     # recurrences whose coefficient is constant over the launch: one LDS row of per-lane weights per distinct coefficient
     inv_coefs: List[N] = []
     for it in plan.items:
@@ -1318,6 +1540,8 @@ def emit_hip(plan: Plan, prog: Program, kernel_macro: str = "ZA_KERNEL(tpar)") -
             L.append(f"  zt_w[{k} * 64 + lane] = zt_pow_row({ref(a)}, lane);")
             L.append(f"  if (lane == 0) {{ const double p2 = {ref(a)} * {ref(a)}, p4 = p2 * p2, p8 = p4 * p4; zt_q[{k} * 4] = p2; zt_q[{k} * 4 + 1] = p4; zt_q[{k} * 4 + 2] = p8; zt_q[{k} * 4 + 3] = p8 * p8; }}")
         L.append("  __syncthreads();")
+    if has_streams:
+        L.append(f"  __shared__ double zt_snap[{max(1, len(cname))}];")
     L.append("  // state carried from frame to frame (wave-uniform)")
     for name, c in cname.items():
         L.append(f"  double {c} = {inv_src(name)};   // {name}")
@@ -1384,8 +1608,15 @@ def emit_hip(plan: Plan, prog: Program, kernel_macro: str = "ZA_KERNEL(tpar)") -
     # end of the chunk body (144 written variables would be 288 registers per lane there).
     if inv_coefs or inv_mats:
         L.append("    int zo; asm volatile(\"s_mov_b32 %0, 0\" : \"=s\"(zo));   // opaque 0: keeps the table reads inside the iteration")
+    if has_streams:
+        L.append(f"    if (lane == 0) {{   // the states as they stand before this chunk, in case it has to be handed to the generic kernel")
+        for k, (name, c) in enumerate(cname.items()):
+            L.append(f"      zt_snap[{k}] = {c};")
+        L.append("    }")
+        L.append("    bool zt_bad = false, zt_badl = false;")
     L.append("    const bool fin = f0 + 64 >= frames;   // the launch's last chunk: its last frame leaves every written variable as the script would")
     avail = {n.i for n in plan.inputs}
+    raw_issued: set = set()
     unit_done: set = set()
     carried: set = set()
     stored: set = set()
@@ -1403,12 +1634,21 @@ def emit_hip(plan: Plan, prog: Program, kernel_macro: str = "ZA_KERNEL(tpar)") -
                 carried.add(name)
                 L.append(f"    {c} = {ref(o) if (o.uniform or o.kind == 'const') else f'zt_readlane(n{o.i}, last)'};")
         for name, o in finals:
+            if (name in plan.cells or name.startswith("memw@")) and not final:
+                continue                                   # (a cell needs its "stored to" flag beside it: both go out at the end)
             if name not in stored and ready(o) and (final or not (o.uniform or o.kind == "const")):
                 stored.add(name)
                 pending.append((name, o))
         if pending and (final or len(pending) >= 12):
             L.append("    if (fin && lane == last) {")
             for name, o in pending:
+                if name.startswith("memw@"):
+                    continue
+                if name in plan.cells:                     # a cell is written back only if the launch stored to it at all
+                    flag = plan.outs.get("memw@" + name[4:])
+                    if flag is not None:
+                        L.append(f"      if ({ref(flag)} != 0.0) {{ {dst(name)} = {ref(o)}; zt_hc = zt_hc > ca{plan.cells[name].i} + 1 ? zt_hc : ca{plan.cells[name].i} + 1; }}")
+                    continue
                 L.append(f"      {dst(name)} = {ref(o)};")
             L.append("    }")
             pending.clear()
@@ -1417,6 +1657,8 @@ def emit_hip(plan: Plan, prog: Program, kernel_macro: str = "ZA_KERNEL(tpar)") -
         kind = it[0]
         if kind == "par":
             avail.add(it[1].i)
+        elif kind == "site":
+            pass
         elif kind == "shift":
             avail.add(plan.st[it[1]].i)
             unit_done.add(it[1])
@@ -1431,9 +1673,54 @@ def emit_hip(plan: Plan, prog: Program, kernel_macro: str = "ZA_KERNEL(tpar)") -
                     unit_done.add(nm)
         if gid:
             pass
+        if kind == "site":
+            st_: StoreSite = it[1]
+            j, an = st_.j, ref(st_.addr)
+            L.append(f"    // delay-line write {j}: must advance by one cell per frame (at most one wrap inside the chunk)")
+            L.append(f"    const double sp{j} = zt_shift1({an}, {an} - 1.0);")
+            L.append(f"    const uint64_t sm{j} = __ballot(valid && lane > 0 && ({an} - sp{j} != 1.0));")
+            L.append(f"    const int sk{j} = sm{j} ? (int)__ffsll((long long)sm{j}) - 1 : tn;")
+            L.append(f"    const int64_t s0{j} = (int64_t)zt_readlane({an}, 0), s1{j} = sk{j} < tn ? (int64_t)zt_readlane({an}, sk{j}) : 0;")
+            L.append(f"    zt_bad |= __popcll(sm{j}) > 1 || s0{j} + sk{j} > mcap || (sk{j} < tn && s1{j} + (tn - sk{j}) > mcap);")
+            if cell_addrs:
+                L.append(f"    zt_bad |= (s0{j} <= cmax && s0{j} + sk{j} > cmin) || (sk{j} < tn && s1{j} <= cmax && s1{j} + (tn - sk{j}) > cmin);")
+            continue
+        if kind == "par" and it[1].kind == "ld":
+            n = it[1]
+            L.append(f"    double n{n.i};   // delay-line read: memory as it was before this chunk, or the value an earlier frame of the chunk writes")
+            L.append("    {")
+            if n.i in raw_issued:
+                L.append(f"      const int64_t B = B{n.i};")
+                L.append(f"      double v = raw{n.i};")
+            else:
+                L.append(f"      const int64_t B = (int64_t){ref(n.args[0])};")
+                L.append("      double v = B < mcap ? memp[B * mse] : 0.0;")
+            L.append("      int best = -1;")
+            for st_ in plan.stores:
+                j = st_.j
+                L.append(f"      {{ int tw = -1; const int64_t d0 = B - s0{j}, d1 = B - s1{j};")
+                L.append(f"        if ((uint64_t)d0 < (uint64_t)sk{j}) tw = (int)d0;")
+                L.append(f"        if ((uint64_t)d1 < (uint64_t)(tn - sk{j})) tw = sk{j} + (int)d1;")
+                if ",".join(map(str, st_.region)) != n.name:
+                    L.append("        zt_badl |= tw >= 0; }")
+                else:
+                    before = "true" if st_.seq < n.val else "false"
+                    L.append(f"        const bool vis = valid && tw >= 0 && (tw < lane || (tw == lane && {before})) && tw >= best;")
+                    L.append(f"        if (__ballot(vis)) {{ const double fw = zt_bperm({ref(st_.value)}, tw); v = vis ? fw : v; best = vis ? tw : best; }} }}")
+            if cell_addrs:
+                L.append("      zt_badl |= B >= cmin && B <= cmax;")
+            L.append(f"      n{n.i} = v;")
+            L.append("    }")
+            retire()
+            continue
         if kind == "par":
             n = it[1]
             L.append(f"    const double n{n.i} = {_expr(n.op, [ref(x) for x in n.args])};")
+            for ld in plan.loads:            # the reads of this address go out now: their latency overlaps everything up to their use
+                if ld.args[0] is n and ld.i not in raw_issued:
+                    raw_issued.add(ld.i)
+                    L.append(f"    const int64_t B{ld.i} = (int64_t)n{n.i};")
+                    L.append(f"    const double raw{ld.i} = B{ld.i} < mcap ? memp[B{ld.i} * mse] : 0.0;")
         elif kind == "shift":
             name = it[1]
             L.append(f"    const double n{plan.st[name].i} = zt_shift1({ref(plan.outs[name])}, {cname[name]});   // {name}[t-1]")
@@ -1555,7 +1842,33 @@ def emit_hip(plan: Plan, prog: Program, kernel_macro: str = "ZA_KERNEL(tpar)") -
         else:
             raise AssertionError(kind)
         retire()
+    if has_streams:
+        L.append("    if (zt_bad || __ballot(valid && zt_badl)) {")
+        L.append("      // a condition of the delay-line handling does not hold in this chunk: put the states back as they were before it")
+        L.append("      // and leave the rest of the launch to the generic kernel (za_launch_fast runs it right behind this one)")
+        L.append("      if (lane == 0) {")
+        for k, name in enumerate(cname):
+            if name.startswith("memw@") or name == RNG_INDEX:
+                continue
+            if name in plan.cells:
+                flag = "memw@" + name[4:]
+                if flag in cname:
+                    fk = list(cname).index(flag)
+                    L.append(f"        if (zt_snap[{fk}] != 0.0) {{ {dst(name)} = zt_snap[{k}]; zt_high = zt_high > ca{plan.cells[name].i} + 1 ? zt_high : ca{plan.cells[name].i} + 1; }}")
+                continue
+            L.append(f"        {dst(name)} = zt_snap[{k}];")
+        L.append("        b.mem_high[inst] = zt_high;")
+        L.append("        b.resume[inst] = f0;")
+        L.append("      }")
+        L.append("      return;")
+        L.append("    }")
+        L.append("    // the chunk's writes land after all of its reads are resolved")
+        for st_ in plan.stores:
+            L.append(f"    if (valid) memp[(int64_t){ref(st_.addr)} * mse] = {ref(st_.value)};")
+            L.append(f"    {{ const int64_t h0 = s0{st_.j} + sk{st_.j}, h1 = sk{st_.j} < tn ? s1{st_.j} + (tn - sk{st_.j}) : 0; zt_high = h0 > zt_high ? h0 : zt_high; zt_high = h1 > zt_high ? h1 : zt_high; }}")
     retire(final=True)
+    if has_mem:
+        L.append("    if (fin && lane == last) { b.mem_high[inst] = zt_high > zt_hc ? zt_high : zt_hc; b.resume[inst] = frames; }")
     L.append("    if (valid) {")
     for ch in range(plan.nch):
         L.append(f"      out_[{ch} * a.frame_stride + f0 + lane] = (float){ref(plan.spl_out[ch])};")
@@ -1566,9 +1879,35 @@ def emit_hip(plan: Plan, prog: Program, kernel_macro: str = "ZA_KERNEL(tpar)") -
     if plan.uses_rand:
         L.append(f"  zt_mt_end(zt_mt, zt_pos0, (int){cname[RNG_INDEX]}, zt_gmt, b.mt_se, b.mti + inst, lane);")
     L.append("}")
+    if has_mem:
+        # the generic code of the leaf, one lane per instance, from wherever the kernel above stopped (normally: nowhere)
+        L.append("// instances the time-parallel kernel handed back (b.resume[i] < frames) finish the launch here, frame by frame, with the")
+        L.append("// generic section code -- the exact serial semantics; every other lane leaves at once")
+        L.append(f'extern "C" __global__ void __launch_bounds__(64) {kernel_macro[:-1]}_tail)(ZabBatch b, ZabAudio a) {{')
+        L.append("  ZA_KERNEL_ENTRY();")
+        L.append("  const int inst = blockIdx.x * 64 + threadIdx.x;")
+        L.append("  if (inst >= b.n_inst) return;")
+        L.append("  const int64_t from = b.resume[inst];")
+        L.append("  if (from >= a.frames) return;")
+        L.append("  ZaS s;")
+        L.append("  za_state_load(s, b, inst);")
+        L.append(f"  const float* in = a.in + (int64_t)inst * {plan.nch} * a.frame_stride;")
+        L.append(f"  float* out = a.out + (int64_t)inst * {plan.nch} * a.frame_stride;")
+        L.append("  for (int64_t t = from; t < a.frames; ++t) {")
+        for ch in range(plan.nch):
+            L.append(f"    s.spl[{ch}] = (double)in[{ch} * a.frame_stride + t];")
+        L.append("    za_section_sample(s);")
+        for ch in range(plan.nch):
+            L.append(f"    out[{ch} * a.frame_stride + t] = (float)s.spl[{ch}];")
+        L.append("  }")
+        L.append("  za_state_store(s, b, inst);")
+        L.append("  b.resume[inst] = a.frames;")
+        L.append("}")
     L.append("static int32_t za_fast_applies(const ZabBatch* b, const ZabAudio* a) { (void)b; return a->frames > 0 ? 1 : 0; }")
     L.append("static hipError_t za_launch_fast(const ZabBatch* b, const ZabAudio* a, hipStream_t st) {")
     L.append(f"  hipLaunchKernelGGL({kernel_macro}, dim3(b->n_inst), dim3(64), 0, st, *b, *a);")
+    if has_mem:
+        L.append(f"  hipLaunchKernelGGL({kernel_macro[:-1]}_tail), dim3((b->n_inst + 63) / 64), dim3(64), 0, st, *b, *a);")
     L.append("  return hipGetLastError();")
     L.append("}")
     return "\n".join(L) + "\n"
