@@ -760,6 +760,7 @@ class MtStream:
 
 _MT_CTX: List[Optional[MtStream]] = [None]
 
+ULDS_THRESHOLD = 64   # launch-constant values beyond which they live in LDS rather than in (spilled) scalar registers
 SPEC_TOL = 1.0e-13    # relative change of a state between two iterations below which it counts as settled (ZT_SPEC_TOL)
 SPEC_MAX = 8          # iterations of a switched recurrence before the chunk falls back to its serial loop (ZT_SPEC_MAX)
 
@@ -1432,9 +1433,20 @@ def emit_hip(plan: Plan, prog: Program, kernel_macro: str = "ZA_KERNEL(tpar)") -
     g = plan.g
     L: List[str] = []
 
+    # Launch-constant values: a few dozen fit the scalar registers (ZT_UNI); past that the compiler spills them into lanes of
+    # vector registers and every use costs two v_readlane. Large scripts keep them in LDS instead: one broadcast ds_read_b64 per
+    # use, the `zo` offset (an opaque 0 set per chunk) keeping the reads inside the iteration.
+    n_uni = sum(1 for n in plan.uniform if n.kind != "const")
+    mode = os.environ.get("ZA_TPAR_ULDS", "auto")
+    ulds = mode == "1" or (mode == "auto" and n_uni > ULDS_THRESHOLD)
+    uslot = {n.i: k for k, n in enumerate(x for x in plan.uniform if x.kind != "const")}
+    in_loop = [False]
+
     def ref(n: N) -> str:
         if n.kind == "const":
             return c_double(n.val)
+        if n.uniform and ulds and in_loop[0]:
+            return f"zt_u[{uslot[n.i]} + zo]"
         return (f"u{n.i}" if n.uniform else f"n{n.i}")
 
     def inv_src(name: str) -> str:
@@ -1487,6 +1499,14 @@ def emit_hip(plan: Plan, prog: Program, kernel_macro: str = "ZA_KERNEL(tpar)") -
             L.append(f"  const double u{n.i} = {inv_src(n.name)};   // {n.name}")
         else:
             L.append(f"  const double u{n.i} = ZT_UNI({_expr(n.op, [ref(x) for x in n.args])});")
+    if ulds:
+        L.append(f"  __shared__ double zt_u[{max(1, n_uni)}];")
+        L.append("  if (lane == 0) {")
+        for n in plan.uniform:
+            if n.kind != "const":
+                L.append(f"    zt_u[{uslot[n.i]}] = u{n.i};")
+        L.append("  }")
+        L.append("  __syncthreads();")
     has_mem = bool(plan.cells or plan.stores or plan.loads)
     has_streams = bool(plan.stores)
     cell_addrs: List[N] = []
@@ -1606,7 +1626,8 @@ def emit_hip(plan: Plan, prog: Program, kernel_macro: str = "ZA_KERNEL(tpar)") -
     # as both its recurrence and its new value exist, and the values a launch must leave in vars[] -- needed in the launch's
     # last chunk only -- are stored in small conditional batches right after they are computed, instead of all living to the
     # end of the chunk body (144 written variables would be 288 registers per lane there).
-    if inv_coefs or inv_mats:
+    in_loop[0] = True
+    if inv_coefs or inv_mats or ulds:
         L.append("    int zo; asm volatile(\"s_mov_b32 %0, 0\" : \"=s\"(zo));   // opaque 0: keeps the table reads inside the iteration")
     if has_streams:
         L.append(f"    if (lane == 0) {{   // the states as they stand before this chunk, in case it has to be handed to the generic kernel")
