@@ -29,7 +29,7 @@ def main():
         shutil.copy(f, out / f"{tag}_bench_kernel_stats.csv")
     fetch, nf = counter_mean(out / f"{tag}_pmc_fetch", "FETCH_SIZE", kern)
     write, nw = counter_mean(out / f"{tag}_pmc_write", "WRITE_SIZE", kern)
-    rec = {"kernel": kern, "instances": bench["config"]["instances_total"], "frames": bench["config"]["frames_per_step"],
+    rec = {"kernel": kern, "leaf": bench["config"].get("leaf", "DDT"), "instances": bench["config"]["instances_rank0"], "frames": bench["config"]["frames_per_step"],
            "fast": True, "FETCH_SIZE_KB_mean": fetch, "WRITE_SIZE_KB_mean": write, "launches_sampled": [nf, nw],
            "correction": "FETCH_SIZE x2 (gfx950 reports half of wide coalesced reads), WRITE_SIZE as is; KB = 1024 B"}
     if fetch is not None and write is not None:
