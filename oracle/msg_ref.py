@@ -8,6 +8,7 @@ then all outboxes are flushed in instance order. No reference test pins the bus 
 from __future__ import annotations
 
 RING, OUTBOX, INBOX, CHANNELS = 4096, 1024, 1024, 24
+PAY, OUT_CELLS = 64, 65536          # payload cells per ring slot / per outbox and block
 DEFAULT_DOMAIN = 0x9ae16a3b2f90404f
 
 
@@ -64,29 +65,55 @@ class BusRef:
         s = me.slot(key, True)
         if s: s[3] += 1
 
-    def send(self, i, c, tag, a, b, cc, d, target=None):
+    def send(self, i, c, tag, a, b, cc, d, target=None, buf=None):
+        """buf: list of payload cells for msg_send_buf / msg_sendto_buf (copied when queued)."""
         me, key = self.inst[i], self.key(c)
-        if len(me.outbox) >= OUTBOX:
+        cells = sum(len(m["buf"]) for m in me.outbox if m["buf"] is not None)
+        if len(me.outbox) >= OUTBOX or (buf is not None and cells + len(buf) > OUT_CELLS):
             self._drop(me, key)
             return 0.0
         me.outbox.append({"chan": key, "src": me.id, "target": (max(0, int(target + 0.5)) if target is not None else 0),
-                          "direct": target is not None, "vals": (tag, a, b, cc, d)})
+                          "direct": target is not None, "vals": (tag, a, b, cc, d), "buf": None if buf is None else list(buf)})
         return 1.0
 
-    def recv(self, i, c):
-        me, key = self.inst[i], self.key(c)
+    def _front(self, me, key):
         for m in me.inbox:
             if not m.get("used") and m["chan"] == key:
-                m["used"] = True
-                return 1.0, (float(m["src"]),) + m["vals"]
-        return 0.0, None
+                return m
+        return None
+
+    def recv(self, i, c):
+        me = self.inst[i]
+        m = self._front(me, self.key(c))
+        if m is None or m["buf"] is not None:        # a buffer at the front waits for recv_buf
+            return 0.0, None
+        m["used"] = True
+        me.last_len = 0
+        return 1.0, (float(m["src"]),) + m["vals"]
+
+    def recv_buf(self, i, c, capacity):
+        """-> (return value, (src, tag, copied cells) or None)"""
+        me = self.inst[i]
+        if capacity <= 0:
+            return 0.0, None
+        m = self._front(me, self.key(c))
+        if m is None or m["buf"] is None:
+            return 0.0, None
+        m["used"] = True
+        n = len(m["buf"])
+        me.last_len = n
+        return (float(n) if capacity >= n else -float(n)), (float(m["src"]), m["vals"][0], m["buf"][:int(min(capacity, n))])
+
+    def length(self, i):
+        return float(getattr(self.inst[i], "last_len", 0))
 
     def avail(self, i, c):
         key = self.key(c)
         return float(sum(1 for m in self.inst[i].inbox if not m.get("used") and m["chan"] == key))
 
     def kind(self, i, c):
-        return 1.0 if self.avail(i, c) > 0 else 0.0
+        m = self._front(self.inst[i], self.key(c))
+        return 0.0 if m is None else (2.0 if m["buf"] is not None else 1.0)
 
     def clear(self, i, c):
         key, n = self.key(c), 0
@@ -159,6 +186,9 @@ class BusRef:
     def flush_all(self):
         for me in self.inst:
             for m in me.outbox:
+                if m["buf"] is not None and len(m["buf"]) > PAY:       # does not fit a ring slot
+                    self._drop(me, m["chan"])
+                    continue
                 if m["direct"]:
                     t = self._peer(m["target"]) if m["target"] >= self.first_id else None
                     ok = t is not None and t.domain == me.domain
@@ -169,5 +199,5 @@ class BusRef:
                     continue
                 self.seq += 1
                 self.ring[self.seq % RING] = {"seq": self.seq, "chan": m["chan"], "src": me.id,
-                                              "target": m["target"] if m["direct"] else 0, "vals": m["vals"]}
+                                              "target": m["target"] if m["direct"] else 0, "vals": m["vals"], "buf": m["buf"]}
             me.outbox = []

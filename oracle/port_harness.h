@@ -33,7 +33,8 @@ struct ZaPort {
   ZaBusView bview;                       // a bus with this one instance on it
   std::vector<ZaMsg> mring, moutbox, minbox;
   uint64_t mseq, mdomain, mlast, mch_hash[ZA_MSG_CHANNELS], mch_caps[ZA_MSG_CHANNELS], mch_dropped[ZA_MSG_CHANNELS];
-  uint32_t mch_flags[ZA_MSG_CHANNELS], mout_count, min_count;
+  uint32_t mch_flags[ZA_MSG_CHANNELS], mout_count, min_count, mout_cells, mlast_len;
+  std::vector<double> mout_pay, mring_pay, min_pay;
 #endif
 #ifdef ZA_FILE_H_INCLUDED
   ZaFileView fview;
@@ -63,7 +64,12 @@ ZaPort* port_create(double srate, int64_t mem_cap) {
   memset(p->mch_hash, 0, sizeof p->mch_hash); memset(p->mch_caps, 0, sizeof p->mch_caps);
   memset(p->mch_dropped, 0, sizeof p->mch_dropped); memset(p->mch_flags, 0, sizeof p->mch_flags);
   p->bview = ZaBusView{p->mring.data(), &p->mseq, &p->mdomain, p->mch_hash, p->mch_flags, p->mch_caps, p->mch_dropped, &p->mlast,
-                       p->moutbox.data(), &p->mout_count, p->minbox.data(), &p->min_count, 1u, 0u, 1ull};
+                       p->moutbox.data(), &p->mout_count, p->minbox.data(), &p->min_count, 1u, 0u, 1ull, nullptr, nullptr, nullptr,
+                       nullptr, nullptr};
+  p->mout_pay.assign((size_t)ZA_MSG_OUTBOX * ZA_MSG_PAY, 0.0); p->mring_pay.assign((size_t)ZA_MSG_RING * ZA_MSG_PAY, 0.0);
+  p->min_pay.assign((size_t)ZA_MSG_INBOX * ZA_MSG_PAY, 0.0); p->mout_cells = 0; p->mlast_len = 0;
+  p->bview.out_pay = p->mout_pay.data(); p->bview.ring_pay = p->mring_pay.data(); p->bview.in_pay = p->min_pay.data();
+  p->bview.out_cells = &p->mout_cells; p->bview.last_len = &p->mlast_len;
   p->s.bus = &p->bview;
   p->s.inst_index = 0;
 #endif

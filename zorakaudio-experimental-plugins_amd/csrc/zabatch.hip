@@ -93,13 +93,14 @@ struct ZabFileSlotDev { const double* items; int64_t n_items; int32_t channels; 
 struct ZabFileViewDev { ZabFileSlotDev slot[16]; };
 enum { kFileHandleWords = 26 };
 // mirrors ZaMsg / ZaBusView of csrc/zart_msg.h
-struct ZabMsgDev { uint64_t seq, chan, src, target; double tag, a, b, c, d; uint32_t kind, pad; };
+struct ZabMsgDev { uint64_t seq, chan, src, target; double tag, a, b, c, d; uint32_t kind, pad, blen, pad2; };
 struct ZabBusViewDev {
   ZabMsgDev* ring; uint64_t* global_seq; uint64_t* domain; uint64_t* ch_hash; uint32_t* ch_flags; uint64_t* ch_caps;
   uint64_t* ch_dropped; uint64_t* last_read; ZabMsgDev* outbox; uint32_t* out_count; ZabMsgDev* inbox; uint32_t* in_count;
   uint32_t n_inst, pad; uint64_t first_id;
+  double *out_pay, *ring_pay, *in_pay; uint32_t *out_cells, *last_len;      // buffer messages (uses_msg == 2), else null
 };
-enum { kMsgRing = 4096, kMsgChannels = 24, kMsgOutbox = 1024, kMsgInbox = 1024, kMsgMaxInstances = 256 };
+enum { kMsgRing = 4096, kMsgChannels = 24, kMsgOutbox = 1024, kMsgInbox = 1024, kMsgMaxInstances = 256, kMsgPay = 64 };
 static const uint64_t kMsgDefaultDomain = 0x9ae16a3b2f90404full;
 
 struct zab_engine {
@@ -185,6 +186,10 @@ static int reset_bus(zab_engine* e) {
   HIP_TRY(hipMemsetAsync(v.last_read, 0, 8 * n, e->stream));
   HIP_TRY(hipMemsetAsync(v.out_count, 0, 4 * n, e->stream));
   HIP_TRY(hipMemsetAsync(v.in_count, 0, 4 * n, e->stream));
+  if (v.out_cells) {
+    HIP_TRY(hipMemsetAsync(v.out_cells, 0, 4 * n, e->stream));
+    HIP_TRY(hipMemsetAsync(v.last_len, 0, 4 * n, e->stream));
+  }
   std::vector<uint64_t> dom(n, kMsgDefaultDomain);
   HIP_TRY(hipMemcpyAsync(v.domain, dom.data(), 8 * n, hipMemcpyHostToDevice, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
@@ -202,6 +207,10 @@ static int setup_bus(zab_engine* e) {
       (rc = e->alloc(&v.ch_caps, n * kMsgChannels)) || (rc = e->alloc(&v.ch_dropped, n * kMsgChannels)) ||
       (rc = e->alloc(&v.last_read, n)) || (rc = e->alloc(&v.outbox, n * kMsgOutbox)) || (rc = e->alloc(&v.out_count, n)) ||
       (rc = e->alloc(&v.inbox, n * kMsgInbox)) || (rc = e->alloc(&v.in_count, n)) || (rc = e->alloc(&e->d_bus, 1)))
+    return rc;
+  if (e->mod->uses_msg == 2 &&         // payload rows of the buffer messages (msg_send_buf / msg_recv_buf)
+      ((rc = e->alloc(&v.out_pay, n * kMsgOutbox * kMsgPay)) || (rc = e->alloc(&v.ring_pay, (size_t)kMsgRing * kMsgPay)) ||
+       (rc = e->alloc(&v.in_pay, n * kMsgInbox * kMsgPay)) || (rc = e->alloc(&v.out_cells, n)) || (rc = e->alloc(&v.last_len, n))))
     return rc;
   v.n_inst = (uint32_t)e->b.n_inst; v.pad = 0; v.first_id = e->b.first_id;
   if (hipMemcpyAsync(e->d_bus, &v, sizeof v, hipMemcpyHostToDevice, e->stream) != hipSuccess) return fail(ZAB_E_HIP, "bus view upload failed");

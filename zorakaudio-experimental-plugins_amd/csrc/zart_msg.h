@@ -17,7 +17,16 @@
 // The reference delivers what a sender flushed at the end of ITS block to whoever starts a block afterwards; instances run
 // on unrelated threads, so the order inside one host block is unspecified there. Here every instance of the engine runs
 // host block k, then all outboxes are flushed in instance order, then block k + 1 starts: a message sent in block k is
-// received in block k + 1. Buffer messages (msg_*_buf) and the string-valued peer queries stay host-only.
+// received in block k + 1.
+//   msg_send_buf / msg_sendto_buf(…, tag, srcBase, len): the payload is copied out of mem[] when the message is queued; an
+//                                  outbox holds at most 65536 payload cells per block (else dropped[channel]++); a payload of
+//                                  more than 64 cells does not fit a ring slot and is dropped (and counted) at the flush
+//                                  ............. src/DspJsfxRuntimeBuiltins.cpp:289-338, DspJsfxRuntime.cpp:318-392,442-464,
+//                                  DspJsfxMessageBus.cpp:22,205-222,558-562
+//   msg_recv_buf(chan, src, tag, dstBase, maxLen): only if the channel's oldest message is a buffer; copies min(maxLen, n) cells,
+//                                  returns n, or -n when maxLen < n; msg_length() = n of the last buffer received (0 after a
+//                                  scalar); msg_recv only takes a scalar at the front; msg_kind: 1 scalar, 2 buffer
+// The string-valued peer queries (msg_peer_name / uid) stay host-only.
 #pragma once
 #define ZA_MSG_H_INCLUDED 1
 
@@ -28,13 +37,17 @@
 #define ZA_MSG_OUTBOX 1024
 #define ZA_MSG_INBOX 1024
 #define ZA_MSG_MAX_INSTANCES 256
+#define ZA_MSG_PAY 64                  /* payload cells a ring slot carries (kIpcMaxPayloadCells) */
+#define ZA_MSG_OUT_CELLS 65536         /* payload cells an outbox may hold per block (kMaxOutboxBufferCells) */
 #define ZA_MSG_DEFAULT_DOMAIN 0x9ae16a3b2f90404full
 
 struct ZaMsg {
   uint64_t seq, chan, src, target;
   double tag, a, b, c, d;
-  uint32_t kind;       // 0 none / consumed, 1 scalar
-  uint32_t pad;
+  uint32_t kind;       // 0 none / consumed, 1 scalar, 2 buffer
+  uint32_t pad;        // outbox: 1 = direct
+  uint32_t blen;       // buffer: payload cells as sent (what msg_length reports)
+  uint32_t pad2;
 };
 struct ZaBusView {
   ZaMsg* ring;                 // [ZA_MSG_RING]
@@ -52,6 +65,12 @@ struct ZaBusView {
   uint32_t n_inst;
   uint32_t pad;
   uint64_t first_id;
+  // buffer messages (null unless the leaf uses msg_*_buf): payload rows parallel to outbox / ring / inbox entries
+  double* out_pay;             // [n][ZA_MSG_OUTBOX][ZA_MSG_PAY]
+  double* ring_pay;            // [ZA_MSG_RING][ZA_MSG_PAY]
+  double* in_pay;              // [n][ZA_MSG_INBOX][ZA_MSG_PAY]
+  uint32_t* out_cells;         // [n] payload cells queued in this block
+  uint32_t* last_len;          // [n] msg_length()
 };
 
 // channel / domain identity of a string handle: the handle value itself (one script per engine: equal names are equal handles)
@@ -114,16 +133,43 @@ template <class S> ZA_NOINLINE double za_msg_advertise(S& s, double chanH, doubl
   return 1.0;
 }
 template <class S> ZA_NOINLINE double za_msg_queue(S& s, uint64_t target, bool direct, double chanH, double tag, double a, double b,
-                                                  double c, double d) {
+                                                  double c, double d, int64_t buf_base = -1, int64_t buf_len = 0) {
   if (!s.bus) return 0.0;
   const uint64_t chan = za_msg_key(chanH);
   const uint32_t n = s.bus->out_count[s.inst_index];
-  if (n >= ZA_MSG_OUTBOX) { za_msg_drop(s, chan); return 0.0; }
+  const bool is_buf = buf_base >= 0;
+  if (n >= ZA_MSG_OUTBOX || (is_buf && (int64_t)s.bus->out_cells[s.inst_index] + buf_len > ZA_MSG_OUT_CELLS)) { za_msg_drop(s, chan); return 0.0; }
   ZaMsg& m = s.bus->outbox[(int64_t)s.inst_index * ZA_MSG_OUTBOX + n];
   m.seq = 0; m.chan = chan; m.src = s.instance_id; m.target = direct ? target : 0;
-  m.tag = tag; m.a = a; m.b = b; m.c = c; m.d = d; m.kind = 1; m.pad = direct ? 1u : 0u;
+  m.tag = tag; m.a = a; m.b = b; m.c = c; m.d = d; m.kind = is_buf ? 2u : 1u; m.pad = direct ? 1u : 0u;
+  m.blen = is_buf ? (uint32_t)buf_len : 0u; m.pad2 = 0;
+  if (is_buf) {
+    double* row = s.bus->out_pay + ((int64_t)s.inst_index * ZA_MSG_OUTBOX + n) * ZA_MSG_PAY;
+    for (int64_t i = 0; i < buf_len && i < ZA_MSG_PAY; ++i) row[i] = s.mem[(buf_base + i) * s.mem_stride];   // (longer ones die at the flush)
+    s.bus->out_cells[s.inst_index] += (uint32_t)buf_len;
+  }
   s.bus->out_count[s.inst_index] = n + 1;
   return 1.0;
+}
+// std::llround into int with saturation, non-finite -> 0 (toInt, src/DspJsfxRuntimeBuiltins.cpp:35-44)
+ZA_FN int64_t za_msg_toint(double v) {
+  if (!(v == v) || v - v != 0.0) return 0;
+  if (v <= -2147483648.0) return -2147483648ll;
+  if (v >= 2147483647.0) return 2147483647ll;
+  return za_f2i64(v + (v < 0 ? -0.5 : 0.5));
+}
+template <class S> ZA_FN double za_msg_send_buf(S& s, double chanH, double tag, double srcBase, double len) {
+  if (!s.bus || !s.bus->out_pay) return 0.0;
+  const int64_t base = za_msg_toint(srcBase), n = za_msg_toint(len);
+  if (base < 0 || n <= 0 || base + n > s.mem_cap) return 0.0;
+  return za_msg_queue(s, 0, false, chanH, tag, 0.0, 0.0, 0.0, 0.0, base, n);
+}
+template <class S> ZA_FN double za_msg_sendto_buf(S& s, double targetD, double chanH, double tag, double srcBase, double len) {
+  if (!s.bus || !s.bus->out_pay) return 0.0;
+  const int64_t base = za_msg_toint(srcBase), n = za_msg_toint(len);
+  if (base < 0 || n <= 0 || base + n > s.mem_cap) return 0.0;
+  const int64_t t = za_f2i64(targetD + 0.5);
+  return za_msg_queue(s, t < 0 ? 0 : (uint64_t)t, true, chanH, tag, 0.0, 0.0, 0.0, 0.0, base, n);
 }
 template <class S> ZA_FN double za_msg_send(S& s, double chanH, double tag, double a, double b, double c, double d) {
   return za_msg_queue(s, 0, false, chanH, tag, a, b, c, d);
@@ -143,11 +189,35 @@ template <class S> ZA_FN int64_t za_msg_front(S& s, uint64_t chan) {
 template <class S> ZA_NOINLINE double za_msg_recv(S& s, double chanH, double* src, double* tag, double* a, double* b, double* c, double* d) {
   if (!s.bus) return 0.0;
   const int64_t at = za_msg_front(s, za_msg_key(chanH));
-  if (at < 0) return 0.0;
+  if (at < 0 || s.bus->inbox[at].kind != 1) return 0.0;      // (a buffer at the front waits for msg_recv_buf)
   ZaMsg& m = s.bus->inbox[at];
   *src = (double)m.src; *tag = m.tag; *a = m.a; *b = m.b; *c = m.c; *d = m.d;
   m.kind = 0;
+  if (s.bus->last_len) s.bus->last_len[s.inst_index] = 0;
   return 1.0;
+}
+template <class S> ZA_NOINLINE double za_msg_recv_buf(S& s, double chanH, double* src, double* tag, double dstBase, double maxLen) {
+  if (!s.bus || !s.bus->in_pay) return 0.0;
+  int64_t cap = za_msg_toint(maxLen);
+  if (cap <= 0) return 0.0;
+  const int64_t dst = za_msg_toint(dstBase);
+  if (dst < 0) return 0.0;
+  if (dst + cap > s.mem_cap) {            // the reference grows mem here; a fixed arena reports the overflow
+    s.err |= ZA_ERR_MEM_OVERFLOW;
+    if (dst + cap > s.mem_need) s.mem_need = dst + cap;
+    return 0.0;
+  }
+  const int64_t at = za_msg_front(s, za_msg_key(chanH));
+  if (at < 0 || s.bus->inbox[at].kind != 2) return 0.0;
+  ZaMsg& m = s.bus->inbox[at];
+  *src = (double)m.src; *tag = m.tag;
+  const int64_t n = m.blen, cp = cap < n ? cap : n;
+  const double* row = s.bus->in_pay + at * ZA_MSG_PAY;
+  for (int64_t i = 0; i < cp; ++i) s.mem[(dst + i) * s.mem_stride] = row[i];
+  if (cp > 0) za_note_store(s, dst + cp);
+  s.bus->last_len[s.inst_index] = (uint32_t)n;
+  m.kind = 0;
+  return cap >= n ? (double)n : -(double)n;
 }
 template <class S> ZA_NOINLINE double za_msg_avail(S& s, double chanH) {
   if (!s.bus) return 0.0;
@@ -159,7 +229,8 @@ template <class S> ZA_NOINLINE double za_msg_avail(S& s, double chanH) {
 }
 template <class S> ZA_FN double za_msg_kind(S& s, double chanH) {
   if (!s.bus) return 0.0;
-  return za_msg_front(s, za_msg_key(chanH)) >= 0 ? 1.0 : 0.0;
+  const int64_t at = za_msg_front(s, za_msg_key(chanH));
+  return at >= 0 ? (double)s.bus->inbox[at].kind : 0.0;
 }
 template <class S> ZA_NOINLINE double za_msg_clear(S& s, double chanH) {
   if (!s.bus) return 0.0;
@@ -175,7 +246,7 @@ template <class S> ZA_FN double za_msg_dropped(S& s, double chanH) {
   const int k = za_msg_slot(s, za_msg_key(chanH), false);
   return k >= 0 ? (double)s.bus->ch_dropped[(int64_t)s.inst_index * ZA_MSG_CHANNELS + k] : 0.0;
 }
-template <class S> ZA_FN double za_msg_length(S& s) { (void)s; return 0.0; }      // scalar messages carry no buffer
+template <class S> ZA_FN double za_msg_length(S& s) { return (s.bus && s.bus->last_len) ? (double)s.bus->last_len[s.inst_index] : 0.0; }
 
 ZA_FN bool za_msg_matches(const ZaBusView* B, uint32_t j, uint64_t chan, int role) {   // channelMatches
   const bool wantSub = role == 1 || role == 3 || role <= 0, wantPub = role == 2 || role == 3 || role <= 0;
@@ -229,7 +300,14 @@ template <class S> ZA_NOINLINE void za_msg_begin_block(S& s) {
   const int64_t ibase = (int64_t)me * ZA_MSG_INBOX;
   uint32_t n = 0;                                        // compact the ready inbox (drop consumed entries, keep order)
   for (uint32_t i = 0; i < B->in_count[me]; ++i)
-    if (B->inbox[ibase + i].kind != 0) { if (n != i) B->inbox[ibase + n] = B->inbox[ibase + i]; ++n; }
+    if (B->inbox[ibase + i].kind != 0) {
+      if (n != i) {
+        B->inbox[ibase + n] = B->inbox[ibase + i];
+        if (B->in_pay && B->inbox[ibase + i].kind == 2)
+          for (int c = 0; c < ZA_MSG_PAY; ++c) B->in_pay[(ibase + n) * ZA_MSG_PAY + c] = B->in_pay[(ibase + i) * ZA_MSG_PAY + c];
+      }
+      ++n;
+    }
   const uint64_t newest = *B->global_seq, last = B->last_read[me];
   if (newest > last) {
     uint64_t first = last + 1;
@@ -245,8 +323,12 @@ template <class S> ZA_NOINLINE void za_msg_begin_block(S& s) {
       if (m.target != 0) mine = m.target == s.instance_id;
       else mine = m.src != s.instance_id && za_msg_matches(B, me, m.chan, 1);
       if (!mine) continue;
-      if (n < ZA_MSG_INBOX) B->inbox[ibase + n++] = m;
-      else za_msg_drop(s, m.chan);
+      if (n < ZA_MSG_INBOX) {
+        B->inbox[ibase + n] = m;
+        if (B->in_pay && m.kind == 2)
+          for (int c = 0; c < ZA_MSG_PAY; ++c) B->in_pay[(ibase + n) * ZA_MSG_PAY + c] = B->ring_pay[(int64_t)(q % ZA_MSG_RING) * ZA_MSG_PAY + c];
+        ++n;
+      } else za_msg_drop(s, m.chan);
     }
     B->last_read[me] = newest;
   }
@@ -275,7 +357,9 @@ ZA_FN void za_msg_flush_all(const ZaBusView* B) {
     for (uint32_t k = 0; k < cnt; ++k) {
       const ZaMsg& in = B->outbox[(int64_t)i * ZA_MSG_OUTBOX + k];
       bool has_target = false;
-      if (in.pad) {                                      // direct
+      const bool oversize = in.kind == 2 && in.blen > ZA_MSG_PAY;      // does not fit a ring slot: dropped, whoever listens
+      if (oversize) {
+      } else if (in.pad) {                               // direct
         const int64_t j = (int64_t)in.target - (int64_t)B->first_id;
         has_target = j >= 0 && j < (int64_t)B->n_inst && B->domain[j] == dom;
       } else {
@@ -304,10 +388,13 @@ ZA_FN void za_msg_flush_all(const ZaBusView* B) {
           out.seq = seq; out.src = me; out.pad = 0;
           if (!in.pad) out.target = 0;
           B->ring[seq % ZA_MSG_RING] = out;
+          if (in.kind == 2)
+            for (int c = 0; c < ZA_MSG_PAY; ++c)
+              B->ring_pay[(int64_t)(seq % ZA_MSG_RING) * ZA_MSG_PAY + c] = c < (int)in.blen ? B->out_pay[((int64_t)i * ZA_MSG_OUTBOX + k) * ZA_MSG_PAY + c] : 0.0;
         }
       }
       ZA_MSG_CONVERGE();
     }
-    if (lane == 0) B->out_count[i] = 0;
+    if (lane == 0) { B->out_count[i] = 0; if (B->out_cells) B->out_cells[i] = 0; }
   }
 }

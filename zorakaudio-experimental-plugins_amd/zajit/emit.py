@@ -27,11 +27,11 @@ PURE_MATH2 = {"pow": "pow", "atan2": "atan2"}
 NOOP_CALLS = {"sprintf", "printf", "strcpy", "strcat", "strcmp", "strlen", "str_getchar", "str_setchar",
               "str_insert", "str_delete", "str_mid", "strncpy", "file_read", "file_write", "file_string"}
 # builtins that need a host (MIDI, files, strings, messaging): reaching one on the device latches ZA_ERR_UNSUPPORTED.
-HOST_ONLY = {"msg_send_buf", "msg_sendto_buf", "msg_recv_buf", "msg_peer_name", "msg_peer_uid",
-             "sample_name", "sample_preview_read", "sample_preview_bins"}
+HOST_ONLY = {"msg_peer_name", "msg_peer_uid", "sample_name", "sample_preview_read", "sample_preview_bins"}
 # scalar message bus between the instances of one engine (csrc/zart_msg.h)
 MSG_CALLS = {"msg_subscribe", "msg_unsubscribe", "msg_advertise", "msg_send", "msg_sendto", "msg_avail", "msg_kind", "msg_recv",
-             "msg_length", "msg_dropped", "msg_clear", "msg_peer_count", "msg_peer_id", "msg_peer_caps", "msg_peer_alive"}
+             "msg_length", "msg_dropped", "msg_clear", "msg_peer_count", "msg_peer_id", "msg_peer_caps", "msg_peer_alive",
+             "msg_send_buf", "msg_sendto_buf", "msg_recv_buf"}
 # file_*() over host-provided file slots (csrc/zart_file.h)
 FILE_CALLS = {"file_open", "file_open_multi", "file_close", "file_rewind", "file_seek", "file_avail", "file_text", "file_mem",
               "file_multi_count", "file_multi_select", "file_var", "file_riff"}
@@ -550,6 +550,14 @@ class Emitter:
                 pre, args = self.ordered(n.args[:1])
                 outs = ", ".join(self.out_ptr(a, fn) for a in n.args[1:])
                 return self.wrap(pre, f"za_msg_recv(s, {args[0]}, {outs})")
+            if fn in ("msg_send_buf", "msg_sendto_buf", "msg_recv_buf"):
+                self.features.add("msgbuf")
+                self.features.add("mem")
+            if fn == "msg_recv_buf":                # (channel, &src, &tag, dstBase, maxLen)
+                self.nargs(n, 5)
+                pre, args = self.ordered([n.args[0], n.args[3], n.args[4]])
+                outs = ", ".join(self.out_ptr(a, fn) for a in n.args[1:3])
+                return self.wrap(pre, f"za_msg_recv_buf(s, {args[0]}, {outs}, {args[1]}, {args[2]})")
             return self.call_rt(n, "za_" + fn)
         if fn in HOST_CONST:
             self.features.add("hostconst")
