@@ -11,22 +11,28 @@ from conftest import AUDIO_EPS, SCALAR_EPS, assert_state_close, dbfs, golden_inp
 pytestmark = pytest.mark.gpu
 
 DDT_CASES = ["DDT_default", "DDT_far_extreme", "DDT_near_eco_direct", "DDT_diffuse_ragged"]
-# the fast kernel runs NW wavefronts per instance (picked from the batch size); ZAB_DDT_NW pins it so every variant is covered
-FAST_VARIANTS = ["fast1", "fast2", "fast4", "fast8", "fast1p", "fast2p", "fast1d"]   # p / d: pin the ring addressing mode
+# the fast kernels run NW wavefronts per instance (picked from the batch size); ZAB_DDT_NW pins it so every variant is covered.
+# fastN: zab_ddt_fast (filtered rings); wideN[p|d]: zab_ddt_wide, the single-history-ring kernel that takes over when the
+# delays are too long for two rings (ZAB_DDT_KERNEL=wide pins it; p / d pin its ring addressing mode)
+FAST_VARIANTS = ["fast1", "fast2", "fast4", "fast8", "wide1", "wide2", "wide8", "wide1p", "wide2p", "wide1d"]
 
 
 @pytest.fixture(autouse=True)
 def _unpin_nw(monkeypatch):
     monkeypatch.delenv("ZAB_DDT_NW", raising=False)
     monkeypatch.delenv("ZAB_DDT_RING", raising=False)
+    monkeypatch.delenv("ZAB_DDT_KERNEL", raising=False)
 
 
 def _paths(zabatch, monkeypatch):
     """(name, path) pairs; selecting one pins the wave count through the environment."""
     def select(name):
-        if name.startswith("fast"):
+        if name.startswith(("fast", "wide")):
             monkeypatch.setenv("ZAB_DDT_NW", name[4])
             monkeypatch.delenv("ZAB_DDT_RING", raising=False)
+            monkeypatch.delenv("ZAB_DDT_KERNEL", raising=False)
+            if name.startswith("wide"):
+                monkeypatch.setenv("ZAB_DDT_KERNEL", "wide")
             if name[5:]:          # power-of-two ring with masked offsets / doubled ring without wrap
                 monkeypatch.setenv("ZAB_DDT_RING", {"p": "pow2", "d": "dbl"}[name[5:]])
             return zabatch.ZAB_PATH_FAST
@@ -53,7 +59,7 @@ def test_ddt_matches_reference_vm(case, path_name, monkeypatch):
     g = load_golden(case)
     path = _paths(zabatch, monkeypatch)(path_name)
     y, prepared, vars_, mem, high, names, fast = _run(zabatch, path, g)
-    assert fast == path_name.startswith("fast")
+    assert fast == path_name.startswith(("fast", "wide"))
     assert names == [str(s) for s in g["var_names"]]
     # state after prepareToPlay (@init + @slider on the device)
     for i in range(y.shape[0]):

@@ -1,4 +1,7 @@
-// ddt_fast.hip.h -- hand-written gfx950 kernel for the @sample loop of Spatialization/DDT.
+// ddt_fast.hip.h -- zab_ddt_wide[_nw2|_nw4|_nw8]: hand-written gfx950 kernel for the @sample loop of Spatialization/DDT with ONE raw
+// history ring in LDS (taps first, then the six one-poles). Round 1's headline kernel; since round 2 the fallback of
+// ddt_ring2.hip.h (zab_ddt_fast: one-poles first, two filtered rings) for tap delays too long for two rings -- up to the
+// script's 16 382 frames fit here -- and the home of the helpers both share.
 //
 // What it computes is exactly DDT's @sample section (reference: plugins/Spatialization/DDT/src/DDT.jsfx:440-536,
 // run per frame by jsfx_process_block, dsp_jsfx_aot.py:5713-5905); HOW it computes it is MI355X-first:
@@ -40,13 +43,17 @@
 #include <mutex>
 #include <type_traits>
 
-static char ddt_kernel_name[24] = "zab_ddt_fast";   /* + _nw2 / _nw4 / _nw8 once a launch has picked the waves per instance */
+static char ddt_kernel_name[24] = "zab_ddt_fast";   /* zab_ddt_{fast,wide}[_nw2|_nw4|_nw8] once a launch has picked kernel and waves per instance */
 #define ZA_FAST_KERNEL_NAME ddt_kernel_name
 #define DDT_KF 4                       /* frames per lane */
 #define DDT_CHUNK (64 * DDT_KF)        /* frames per wave iteration */
 #define DDT_MAXTAPS 64
 #define DDT_RING 16384                 /* BUF_LEN of the script */
 #define DDT_MAXNW 8
+// The meter one-poles (a = 0.9985, 0.9990) are only observable as state after the launch, and a frame k frames before the
+// end of the launch enters them with weight a^k: beyond 57 344 frames that is below 0.9990^57344 = 2^-82 of the frame's own
+// magnitude -- under the rounding of the sums it would be added to -- so only the launch's last 224 chunks feed the meters.
+#define DDT_METER_FRAMES 57344
 
 struct DdtTap { int32_t dL8, dR8; double gL, gR; };          // 8*delay (bytes) and gains of one tap (wave-uniform when used)
 struct DdtTapRegs { int dpack; double gL, gR; };             // lane j of every wave keeps staged tap j: dL | dR << 16, gains
@@ -56,6 +63,22 @@ struct DdtPole {
   double sp[4];        // (a^4)^(2^j), j = 0..3 : in-row scan step coefficients
   double a256;         // a^256: decay of a state across one chunk
 };
+
+// Optional in-kernel phase clock (-DDDT_STAMPS, tools/ddt_stamps.py): per-wave cycles between the stamps of an iteration,
+// summed over the launch into ddt_stamp_acc. A stamp waits for its own s_memtime only; it still perturbs the LDS pipelining a
+// little, so the build is for attribution, not for timing.
+#ifdef DDT_STAMPS
+__device__ unsigned long long ddt_stamp_acc[16];
+#define DDT_STAMP_DECL unsigned long long ddt_st[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ddt_tl = __builtin_amdgcn_s_memtime();
+#define DDT_STAMP(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ddt_st[i] += now_ - ddt_tl; ddt_tl = now_; }
+#define DDT_STAMP_ARGS , unsigned long long (&ddt_st)[10], unsigned long long& ddt_tl
+#define DDT_STAMP_PASS , ddt_st, ddt_tl
+#else
+#define DDT_STAMP_DECL
+#define DDT_STAMP(i)
+#define DDT_STAMP_ARGS
+#define DDT_STAMP_PASS
+#endif
 
 // ---- wave-level helpers ------------------------------------------------------------------------------------------
 __device__ __forceinline__ double ddt_readlane(double v, int l) {
@@ -262,7 +285,7 @@ __device__ __forceinline__ void ddt_tap_run(const DdtCtx& C, const DdtTapRegs& R
 // Phase B: taps (:459-484), transpose, in-lane recurrences + scans. Leaves y (zero-state responses) and G in K.
 template <bool PARTIAL, bool DBL>
 __device__ __forceinline__ void ddt_phase_b(const DdtCtx& C, const DdtTapRegs& R, DdtChunk& K, int lane, int64_t f0, int nb, const double (&carry)[6], bool head,
-                                            const double (&cb1)[3], const double (&cb2)[3], bool want_last) {
+                                            const double (&cb1)[3], const double (&cb2)[3], bool want_last DDT_STAMP_ARGS) {
   int first_lane = 0, first_k = 0;
   if (PARTIAL) {
     const int firstv = (int)(-f0);
@@ -293,9 +316,13 @@ __device__ __forceinline__ void ddt_phase_b(const DdtCtx& C, const DdtTapRegs& R
       __builtin_amdgcn_wave_barrier();                                                                 \
     }
     ddt_tap_run<DBL>(C, R, ringb, lane8nb, 0, C.nE, sE);
+    DDT_STAMP(2)
     DDT_TRANSPOSE(sE, 2)
+    DDT_STAMP(3)
     ddt_tap_run<DBL>(C, R, ringb, lane8nb, C.nE, C.nT, sL);
+    DDT_STAMP(2)
     DDT_TRANSPOSE(sL, 4)
+    DDT_STAMP(3)
 #undef DDT_TRANSPOSE
   }
   // direct path (:444-451)
@@ -321,10 +348,11 @@ __device__ __forceinline__ void ddt_phase_b(const DdtCtx& C, const DdtTapRegs& R
 #pragma unroll
   for (int s = 0; s < 6; ++s)
     K.G[s] = ddt_pole_local<PARTIAL>(C.P[s >> 1], cb1[s >> 1], cb2[s >> 1], K.y[s], carry[s], head, lane, first_lane, first_k);
+  DDT_STAMP(4)
 }
 
 // Phase C: apply the state carried into the chunk, mix (:492-505), meters (:510-536), store audio.
-template <bool PARTIAL>
+template <bool PARTIAL, bool METERS>
 __device__ __forceinline__ void ddt_phase_c(const DdtCtx& C, DdtChunk& K, int lane, int64_t f0, const double (&cw)[6], bool chained,
                                             const double (&ql)[3], double (&accM)[6], double& accC, double dMi, double dCi,
                                             double wM, double wC, const double (&cwM)[DDT_KF], const double (&cwC)[DDT_KF],
@@ -354,6 +382,7 @@ __device__ __forceinline__ void ddt_phase_c(const DdtCtx& C, DdtChunk& K, int la
     s0 = s0 > 8.0 ? 8.0 : (s0 < -8.0 ? -8.0 : s0);
     s1 = s1 > 8.0 ? 8.0 : (s1 < -8.0 ? -8.0 : s1);
     o0[k] = (float)s0; o1[k] = (float)s1;
+    if (!METERS) continue;
     // meters (:510-531): the 0.5 of s_dir/s_ear/s_lat is applied once to the reduced sums (exact: a power of two), and
     // the s_tot one-pole, being linear, is the sum of the three (final reduction)
     const double s_dir2 = fabs(dirZL) + fabs(dirZR);
@@ -383,9 +412,11 @@ __device__ __forceinline__ void ddt_phase_c(const DdtCtx& C, DdtChunk& K, int la
       C.SPL[0] = s0; C.SPL[1] = s1;
     }
   }
+  if (METERS) {
 #pragma unroll
-  for (int q = 0; q < 6; ++q) accM[q] = __builtin_fma(accM[q], dMi, wM * zM[q]);
-  accC = __builtin_fma(accC, dCi, wC * zC);
+    for (int q = 0; q < 6; ++q) accM[q] = __builtin_fma(accM[q], dMi, wM * zM[q]);
+    accC = __builtin_fma(accC, dCi, wC * zC);
+  }
 
   const int64_t t0 = f0 + DDT_KF * lane;
   if (C.vec_ok && (!PARTIAL || t0 >= 0)) {
@@ -536,6 +567,7 @@ __device__ __forceinline__ void ddt_fast_body(const ZabBatch& b, const ZabAudio&
   const int64_t f_first = frames - DDT_CHUNK * nchunks;    // <= 0; chunks are end-aligned
   const int64_t niter = (nchunks + NW - 1) / NW;
   DdtChunk K;
+  DDT_STAMP_DECL
   int64_t my_last_chunk = -1;
   int pos = DBL ? ddt_pos(C.wofs0 + f_first + (int64_t)DDT_CHUNK * wave, W) : 0;
   // The HBM read of a wave's next chunk is issued a whole iteration ahead of its use.
@@ -561,16 +593,20 @@ __device__ __forceinline__ void ddt_fast_body(const ZabBatch& b, const ZabAudio&
     if (DBL) { pos += NW * DDT_CHUNK; pos = pos >= W ? pos - W : pos; }
     if (active) ddt_phase_a<PART, DBL>(C, K, lane, f0, nb, pf0, pf1);
     prefetch(c + NW);                                      // this wave's next chunk: in flight across phases B and C
+    DDT_STAMP(0)
     ddt_barrier();                                         // ring holds every frame of this iteration
+    DDT_STAMP(1)
     if (active) {
-      ddt_phase_b<PART, DBL>(C, R, K, lane, f0, nb, carry, head, cb1, cb2, want_last);
+      ddt_phase_b<PART, DBL>(C, R, K, lane, f0, nb, carry, head, cb1, cb2, want_last DDT_STAMP_PASS);
       if (lane == 63) {
 #pragma unroll
         for (int s = 0; s < 6; ++s) gend[wave * 6 + s] = K.G[s];
       }
       my_last_chunk = c;
     }
+    DDT_STAMP(4)
     ddt_barrier();                                         // chunk-end responses published; taps of this iteration done
+    DDT_STAMP(5)
     // carry chain: state entering wave w's chunk = a^256 * (state entering w-1) + response of w-1; wave 0 injected `carry`
     double cw[6] = {0, 0, 0, 0, 0, 0};
     {
@@ -590,12 +626,24 @@ __device__ __forceinline__ void ddt_fast_body(const ZabBatch& b, const ZabAudio&
 #pragma unroll
       for (int s = 0; s < 6; ++s) carry[s] = run[s];       // state after this iteration's last chunk (same in every wave)
     }
-    if (active) ddt_phase_c<PART>(C, K, lane, f0, cw, wave != 0, ql, accM, accC, dMi, dCi, wM, wC, cwM, cwC, want_last);
+    if (active) {
+      if (f0 + DDT_CHUNK > frames - DDT_METER_FRAMES)     // wave-uniform
+        ddt_phase_c<PART, true>(C, K, lane, f0, cw, wave != 0, ql, accM, accC, dMi, dCi, wM, wC, cwM, cwC, want_last);
+      else
+        ddt_phase_c<PART, false>(C, K, lane, f0, cw, wave != 0, ql, accM, accC, dMi, dCi, wM, wC, cwM, cwC, want_last);
+    }
+    DDT_STAMP(6)
   };
   int64_t it = 0;
   if (f_first < 0) iteration(std::true_type{}, it++);     // workgroup-uniform
   for (; it < niter; ++it) iteration(std::false_type{}, it);
 
+#ifdef DDT_STAMPS
+  if (lane == 0) {
+    for (int q = 0; q < 7; ++q) atomicAdd(&ddt_stamp_acc[q], ddt_st[q]);
+    atomicAdd(&ddt_stamp_acc[15], 1ull);
+  }
+#endif
   // ---- meters: m_final = a^frames * m_start + sum over waves/lanes of the weighted partials ----------------------------
   double red[7];
   {
@@ -664,10 +712,10 @@ __device__ __forceinline__ void ddt_fast_body(const ZabBatch& b, const ZabAudio&
   extern "C" __global__ void __launch_bounds__(64 * NW, 2) name(ZabBatch b, ZabAudio a, int W) {         \
     if (W < 0) ddt_fast_body<NW, true>(b, a, -W); else ddt_fast_body<NW, false>(b, a, W);                \
   }
-DDT_KERNEL(zab_ddt_fast, 1)
-DDT_KERNEL(zab_ddt_fast_nw2, 2)
-DDT_KERNEL(zab_ddt_fast_nw4, 4)
-DDT_KERNEL(zab_ddt_fast_nw8, 8)
+DDT_KERNEL(zab_ddt_wide, 1)
+DDT_KERNEL(zab_ddt_wide_nw2, 2)
+DDT_KERNEL(zab_ddt_wide_nw4, 4)
+DDT_KERNEL(zab_ddt_wide_nw8, 8)
 #undef DDT_KERNEL
 
 // ---- plan: max tap delay over the batch (decides the LDS ring length) -----------------------------------------------
@@ -696,6 +744,13 @@ extern "C" __global__ void zab_ddt_plan(ZabBatch b) {
   if (bad) atomicMax(&ddt_plan_word[1], 1);
 }
 
+#ifdef DDT_STAMPS
+extern "C" int zab_ddt_stamps(unsigned long long* out, int reset) {      // [16]: cycles per phase summed over waves, [15] = waves
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ddt_stamp_acc), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(ddt_stamp_acc), z, sizeof z) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
 struct DdtPlan { uint64_t epoch; int dmax; bool ok; };
 static std::mutex ddt_mu;
 static std::map<const void*, DdtPlan> ddt_plans;
@@ -749,15 +804,7 @@ static void ddt_geometry(const ZabBatch* b, int& W, int& nw) {
   nw = 1;
 }
 
-static int32_t za_fast_applies(const ZabBatch* b, const ZabAudio* a) {
-  if (!b->instance_major || b->var_se != 1 || b->mem_se != 1 || b->sl_se != 1) return 0;
-  if (a->frames <= 0) return 0;
-  int W, nw;
-  ddt_geometry(b, W, nw);
-  return W != 0 ? 1 : 0;
-}
-
-static hipError_t za_launch_fast(const ZabBatch* b, const ZabAudio* a, hipStream_t st) {
+static hipError_t ddt_wide_launch(const ZabBatch* b, const ZabAudio* a, hipStream_t st) {
   int W, nw;
   ddt_geometry(b, W, nw);
   if (W == 0) return hipErrorInvalidValue;
@@ -765,18 +812,18 @@ static hipError_t za_launch_fast(const ZabBatch* b, const ZabAudio* a, hipStream
   static std::once_flag once;
   std::call_once(once, [] {
     const int cap = 160 * 1024 - 512;
-    (void)hipFuncSetAttribute((const void*)zab_ddt_fast, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-    (void)hipFuncSetAttribute((const void*)zab_ddt_fast_nw2, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-    (void)hipFuncSetAttribute((const void*)zab_ddt_fast_nw4, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-    (void)hipFuncSetAttribute((const void*)zab_ddt_fast_nw8, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute((const void*)zab_ddt_wide, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute((const void*)zab_ddt_wide_nw2, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute((const void*)zab_ddt_wide_nw4, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute((const void*)zab_ddt_wide_nw8, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
   });
   const dim3 grid(b->n_inst), block(64 * nw);
-  snprintf(ddt_kernel_name, sizeof ddt_kernel_name, nw == 1 ? "zab_ddt_fast" : "zab_ddt_fast_nw%d", nw);
+  snprintf(ddt_kernel_name, sizeof ddt_kernel_name, nw == 1 ? "zab_ddt_wide" : "zab_ddt_wide_nw%d", nw);
   switch (nw) {
-    case 1: hipLaunchKernelGGL(zab_ddt_fast, grid, block, lds, st, *b, *a, W); break;
-    case 2: hipLaunchKernelGGL(zab_ddt_fast_nw2, grid, block, lds, st, *b, *a, W); break;
-    case 4: hipLaunchKernelGGL(zab_ddt_fast_nw4, grid, block, lds, st, *b, *a, W); break;
-    default: hipLaunchKernelGGL(zab_ddt_fast_nw8, grid, block, lds, st, *b, *a, W); break;
+    case 1: hipLaunchKernelGGL(zab_ddt_wide, grid, block, lds, st, *b, *a, W); break;
+    case 2: hipLaunchKernelGGL(zab_ddt_wide_nw2, grid, block, lds, st, *b, *a, W); break;
+    case 4: hipLaunchKernelGGL(zab_ddt_wide_nw4, grid, block, lds, st, *b, *a, W); break;
+    default: hipLaunchKernelGGL(zab_ddt_wide_nw8, grid, block, lds, st, *b, *a, W); break;
   }
   return hipGetLastError();
 }

@@ -38,7 +38,8 @@ HIP_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", 
 HIP_FLAGS += os.environ.get("ZA_EXTRA_HIP_FLAGS", "").split()      # experiments (e.g. -DZA_LD_BRANCH)
 
 # leaves with a hand-written kernel: name -> header under csrc/kernels/
-FAST_KERNELS = {"DDT": "kernels/ddt_fast.hip.h"}
+FAST_KERNELS = {"DDT": "kernels/ddt_ring2.hip.h"}
+FAST_KERNEL_DEPS = {"DDT": ["kernels/ddt_fast.hip.h"]}     # headers the hand-written kernel file includes
 # Per-leaf code-shape choices measured on MI355X (tools/catalog_sweep.py, 1024 instances). zart.h's arena
 # load is branch-free by default (better or equal on 20 leaves, up to 14 %); these four delay-line / FIR style scripts run
 # faster with the bounds check as a branch around the load (Roomalizer 1.76x, TSEQ 1.07x, DOT 1.05x, DPT 1.03x).
@@ -199,6 +200,7 @@ def build_module(jsfx_path, name: Optional[str] = None, force=False, verbose=Fal
         deps.append(CSRC / "zart_tpar.h")
     if prog.name in FAST_KERNELS:
         deps.append(CSRC / FAST_KERNELS[prog.name])
+        deps += [CSRC / d for d in FAST_KERNEL_DEPS.get(prog.name, [])]
     for extra in ("zart_fft.h", "zart_gmem.h", "zart_pool.h", "zart_file.h", "zart_msg.h"):
         if (CSRC / extra).exists():
             deps.append(CSRC / extra)
