@@ -34,6 +34,8 @@
 #define D2_MINW 2                      /* waves per SIMD the register allocation must allow */
 #endif
 
+typedef float d2_f4 __attribute__((ext_vector_type(4)));   // a float4 the register allocator keeps as ONE 128-bit tuple
+
 struct D2Uni {               // launch constants kept in LDS (read where used)
   double dgc, dgm;           // dIn = dgc * x + dgm * (L + R)
   double pdx, pdz, tapc;     // out = clamp(tapc * (eZ + lZ) + pdx * x + pdz * dirZ)   (monitor modes folded in)
@@ -65,7 +67,7 @@ __device__ __forceinline__ double d2_ld_l2(const double* p) {     // reads what 
 // HIST: every frame of the chunk lies before the launch (inputs from the mem[] rings, no direct path).
 // PARTIAL: the chunk straddles the launch's first frame.
 template <bool PARTIAL, bool HIST>
-__device__ __forceinline__ void d2_filter_local(const D2Ctx& C, int lane, int64_t f0, const float4& p0, const float4& p1, const double (&carry)[4],
+__device__ __forceinline__ void d2_filter_local(const D2Ctx& C, int lane, int64_t f0, const d2_f4& p0, const d2_f4& p1, const double (&carry)[4],
                                                 bool head, double (&x0)[D2_KF], double (&x1)[D2_KF], double (&y)[4][D2_KF], double (&G)[4]) {
   const int64_t t0 = f0 + D2_KF * lane;
   if (HIST || PARTIAL) {
@@ -462,19 +464,25 @@ __device__ __forceinline__ void d2_body(const ZabBatch& b, const ZabAudio& a, in
   DDT_STAMP_DECL
 
   // The HBM read of a wave's next chunk is issued a whole iteration ahead of its use.
-  float4 pf0 = make_float4(0.f, 0.f, 0.f, 0.f), pf1 = pf0;
-  // Unconditional per lane (addresses clamped into the buffer; what a lane does not need it never looks at): a load under a
-  // lane condition goes to a temporary and is copied -- with a full s_waitcnt vmcnt(0) right behind the load.
+  d2_f4 pf0 = {0.f, 0.f, 0.f, 0.f}, pf1 = pf0;
+  // The loads are inline asm writing straight into the two 128-bit tuples that live across the loop (unconditional per
+  // lane: addresses clamped into the buffer, what a lane does not need it never looks at). Left to the compiler a load
+  // under a lane condition -- or one whose result it wants in other registers -- goes through a temporary and is copied,
+  // behind a full s_waitcnt right after the load: a whole HBM round trip per chunk (measured: 14 % of the kernel). The
+  // matching wait is D2_PF_WAIT (the compiler does not count an asm's memory operations; its own waits only get stricter).
   auto prefetch = [&](const int64_t c) __attribute__((always_inline)) {
     if (C.vec_ok) {                                        // wave-uniform
       int64_t t0 = f_first + D2_CH * (c - nh) + D2_KF * lane;
       t0 = t0 < 0 ? 0 : (t0 > frames - D2_KF ? frames - D2_KF : t0);
-      pf0 = *reinterpret_cast<const float4*>(C.in0 + t0);
-      pf1 = *reinterpret_cast<const float4*>(C.in1 + t0);
+      const float* a0 = C.in0 + t0;
+      const float* a1 = C.in1 + t0;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pf0) : "v"(a0) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pf1) : "v"(a1) : "memory");
     }
   };
+#define D2_PF_WAIT asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf0), "+v"(pf1) : : "memory")
   if (nh == 0) prefetch(wave);
-  asm volatile("" : "+v"(pf0.x), "+v"(pf0.y), "+v"(pf0.z), "+v"(pf0.w), "+v"(pf1.x), "+v"(pf1.y), "+v"(pf1.z), "+v"(pf1.w));
+  D2_PF_WAIT;
 
   // per-lane meter state: only the metered iterations touch it
   double accM[6] = {0, 0, 0, 0, 0, 0}, accC = 0.0;
@@ -579,7 +587,7 @@ __device__ __forceinline__ void d2_body(const ZabBatch& b, const ZabAudio& a, in
     // The next chunk's audio (issued at the top of this iteration) is waited for HERE, on every path, before this chunk's
     // stores join the queue: vmcnt retires in order, and where paths merge at the top of the loop the compiler can only
     // wait for everything (vmcnt(0)) -- which would include these stores' trip to HBM, every chunk.
-    asm volatile("" : "+v"(pf0.x), "+v"(pf0.y), "+v"(pf0.z), "+v"(pf0.w), "+v"(pf1.x), "+v"(pf1.y), "+v"(pf1.z), "+v"(pf1.w));
+    D2_PF_WAIT;
     if (!HIST && active) {
       float* q0 = C.out0 + f0;
       float* q1 = C.out1 + f0;
@@ -715,6 +723,8 @@ __device__ __forceinline__ void d2_body(const ZabBatch& b, const ZabAudio& a, in
   }
 }
 
+#undef D2_PF_WAIT
+
 // _nwK: K wavefronts per instance; W = ring length (frames), nh = history chunks filtered before the launch's first chunk
 #define D2_KERNEL(name, NW)                                                                                     \
   extern "C" __global__ void __launch_bounds__(64 * NW, D2_MINW) name(ZabBatch b, ZabAudio a, int W, int nh) { \
@@ -787,6 +797,12 @@ static hipError_t za_launch_fast(const ZabBatch* b, const ZabAudio* a, hipStream
   });
   const dim3 grid(b->n_inst), block(64 * nw);
   snprintf(ddt_kernel_name, sizeof ddt_kernel_name, nw == 1 ? "zab_ddt_fast" : "zab_ddt_fast_nw%d", nw);
+  if (getenv("ZAB_DDT_DEBUG")) {                           // geometry and residency of the launch
+    const void* fn = nw == 1 ? (const void*)zab_ddt_fast : nw == 2 ? (const void*)zab_ddt_fast_nw2 : nw == 4 ? (const void*)zab_ddt_fast_nw4 : (const void*)zab_ddt_fast_nw8;
+    int wgs = -1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs, fn, 64 * nw, lds);
+    fprintf(stderr, "zab_ddt_fast: nw %d W %d nh %d lds %zu B -> %d workgroups (%d waves) per CU\n", nw, W, nh, lds, wgs, wgs * nw);
+  }
   switch (nw) {
     case 1: hipLaunchKernelGGL(zab_ddt_fast, grid, block, lds, st, *b, *a, W, nh); break;
     case 2: hipLaunchKernelGGL(zab_ddt_fast_nw2, grid, block, lds, st, *b, *a, W, nh); break;
