@@ -12,8 +12,8 @@ pytestmark = pytest.mark.gpu
 
 DDT_CASES = ["DDT_default", "DDT_far_extreme", "DDT_near_eco_direct", "DDT_diffuse_ragged"]
 # the fast kernels run NW wavefronts per instance (picked from the batch size); ZAB_DDT_NW pins it so every variant is covered.
-# fastN: zab_ddt_fast (filtered rings); wideN[p|d]: zab_ddt_wide, the single-history-ring kernel that takes over when the
-# delays are too long for two rings (ZAB_DDT_KERNEL=wide pins it; p / d pin its ring addressing mode)
+# fastN: zab_ddt_fast (filtered rings, long launches); wideN[p|d]: zab_ddt_wide, the single-history-ring kernel that takes
+# short launches and delays too long for two rings (ZAB_DDT_KERNEL pins either; p / d pin wide's ring addressing mode)
 FAST_VARIANTS = ["fast1", "fast2", "fast4", "fast8", "wide1", "wide2", "wide8", "wide1p", "wide2p", "wide1d"]
 
 
@@ -30,9 +30,7 @@ def _paths(zabatch, monkeypatch):
         if name.startswith(("fast", "wide")):
             monkeypatch.setenv("ZAB_DDT_NW", name[4])
             monkeypatch.delenv("ZAB_DDT_RING", raising=False)
-            monkeypatch.delenv("ZAB_DDT_KERNEL", raising=False)
-            if name.startswith("wide"):
-                monkeypatch.setenv("ZAB_DDT_KERNEL", "wide")
+            monkeypatch.setenv("ZAB_DDT_KERNEL", name[:4])          # (unpinned, the launch length picks the kernel)
             if name[5:]:          # power-of-two ring with masked offsets / doubled ring without wrap
                 monkeypatch.setenv("ZAB_DDT_RING", {"p": "pow2", "d": "dbl"}[name[5:]])
             return zabatch.ZAB_PATH_FAST

@@ -484,8 +484,9 @@ __device__ __forceinline__ void d2_body(const ZabBatch& b, const ZabAudio& a, in
   if (nh == 0) prefetch(wave);
   D2_PF_WAIT;
 
-  // per-lane meter state: only the metered iterations touch it
+  // per-lane meter state and weights: only the metered iterations touch them (defined just before those run)
   double accM[6] = {0, 0, 0, 0, 0, 0}, accC = 0.0;
+  double wMd = 0.0, wM = 0.0, wC = 0.0;
 
   auto iteration = [&](auto part_c, auto hist_c, auto met_c, const int64_t it) __attribute__((always_inline)) {
     constexpr bool PART = decltype(part_c)::value, HIST = decltype(hist_c)::value, MET = decltype(met_c)::value;
@@ -532,7 +533,6 @@ __device__ __forceinline__ void d2_body(const ZabBatch& b, const ZabAudio& a, in
       for (int s = S0; s < 4; ++s) carry[s] = run[s];      // state after this iteration's last chunk (same in every wave)
     }
     DDT_STAMP(1)
-    const double wMd = MET ? ddt_ipow((aM * aM) * (aM * aM), 63 - lane) : 0.0;
     if (active) d2_filter_publish<HIST, MET>(C, lane, pos, cw, wave != 0, x0, x1, y, G, accM[0], wMd, want_last);
     DDT_STAMP(2)
     if (NW > 1) ddt_barrier();                             // rings hold every frame of this iteration
@@ -577,7 +577,6 @@ __device__ __forceinline__ void d2_body(const ZabBatch& b, const ZabAudio& a, in
         }
       }
       if (active) {
-        const double wM = MET ? ddt_ipow(aM, 63 - lane) : 0.0, wC = MET ? ddt_ipow(aC, 63 - lane) : 0.0;
         const bool corr = f0 < corr_until;
         if (part) d2_tap_phase<true, MET>(C, R, lane, f0, corr, accM, accC, wM, wC, want_last, o0, o1 DDT_STAMP_PASS);
         else d2_tap_phase<false, MET>(C, R, lane, f0, corr, accM, accC, wM, wC, want_last, o0, o1 DDT_STAMP_PASS);
@@ -603,13 +602,18 @@ __device__ __forceinline__ void d2_body(const ZabBatch& b, const ZabAudio& a, in
   {
     const std::false_type no{};
     const std::true_type yes{};
+    auto meter_weights = [&]() __attribute__((always_inline)) {
+      wMd = ddt_ipow((aM * aM) * (aM * aM), 63 - lane);    // filter phase: lane = KF consecutive frames
+      wM = ddt_ipow(aM, 63 - lane); wC = ddt_ipow(aC, 63 - lane);   // tap phase: lane = frames 64 apart
+    };
     int64_t it = 0;
     for (; it < it0; ++it) iteration(no, yes, no, it);
     if (f_first < 0) {                                     // workgroup-uniform
-      if (it >= it_m) iteration(yes, no, yes, it); else iteration(yes, no, no, it);
+      if (it >= it_m) { meter_weights(); iteration(yes, no, yes, it); } else iteration(yes, no, no, it);
       ++it;
     }
     for (; it < it_m; ++it) iteration(no, no, no, it);
+    meter_weights();
     for (; it < niter; ++it) iteration(no, no, yes, it);
   }
 #ifdef DDT_STAMPS
@@ -768,13 +772,27 @@ static void d2_geometry(const ZabBatch* b, int64_t frames, int& W, int& nw, int&
   nw = 1;
 }
 
-static bool d2_forced_wide() { const char* e = getenv("ZAB_DDT_KERNEL"); return e && !strcmp(e, "wide"); }
+// Which kernel takes a launch. zab_ddt_fast filters the history a tap can reach (Dmax frames) before the launch's first
+// chunk and its metered chunks (the last 57 344 frames) cost more than its plain ones, so short launches are zab_ddt_wide's.
+// Measured on MI355X at the default sliders (fast / wide, ms): 1024 instances x 9 600 frames 0.25 / 0.16, 48 000: 0.67 / 0.65,
+// 96 000: 1.13 / 1.24, 192 000: 2.12 / 2.31, 480 000: 4.50 / 5.44; 4096 instances x 48 000: 2.60 / 2.35, 96 000: 4.36 / 4.31,
+// 192 000: 7.58 / 8.03, 480 000: 18.2 / 19.6. ZAB_DDT_KERNEL = fast | wide pins it (tests cover both on every fixture).
+#ifndef D2_MIN_FRAMES
+#define D2_MIN_FRAMES 96000
+#endif
+static bool d2_wanted(int64_t frames) {
+  if (const char* e = getenv("ZAB_DDT_KERNEL")) {
+    if (!strcmp(e, "wide")) return false;
+    if (!strcmp(e, "fast")) return true;
+  }
+  return frames >= D2_MIN_FRAMES;
+}
 
 static int32_t za_fast_applies(const ZabBatch* b, const ZabAudio* a) {
   if (!b->instance_major || b->var_se != 1 || b->mem_se != 1 || b->sl_se != 1) return 0;
   if (a->frames <= 0) return 0;
   int W, nw, nh;
-  if (!d2_forced_wide()) {
+  if (d2_wanted(a->frames)) {
     d2_geometry(b, a->frames, W, nw, nh);
     if (W != 0) return 1;
   }
@@ -784,7 +802,7 @@ static int32_t za_fast_applies(const ZabBatch* b, const ZabAudio* a) {
 
 static hipError_t za_launch_fast(const ZabBatch* b, const ZabAudio* a, hipStream_t st) {
   int W = 0, nw, nh;
-  if (!d2_forced_wide()) d2_geometry(b, a->frames, W, nw, nh);
+  if (d2_wanted(a->frames)) d2_geometry(b, a->frames, W, nw, nh);
   if (W == 0) return ddt_wide_launch(b, a, st);
   const size_t lds = d2_lds_bytes(W, nw);
   static std::once_flag once;

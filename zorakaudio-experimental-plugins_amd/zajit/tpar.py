@@ -1570,6 +1570,13 @@ def emit_hip(plan: Plan, prog: Program, kernel_macro: str = "ZA_KERNEL(tpar)") -
     L.append("  // the audio of a chunk is read one iteration ahead, so that its HBM latency is hidden behind the previous chunk's work")
     for n in plan.inputs:
         L.append(f"  float x{n.i} = lane < frames ? in_[{int(n.val)} * a.frame_stride + lane] : 0.0f;")
+    # ZT_PIN: an empty asm that takes the prefetched registers, i.e. the point where the compiler waits for their loads. It
+    # sits before the loop and, in the loop, before the chunk's stores: the loads have had the whole chunk to land, and no
+    # path reaches the top of the loop with them pending -- there the wait would be a full vmcnt(0), taken right after the
+    # NEXT chunk's loads were issued (every chunk would pay an HBM round trip).
+    pin = ", ".join(f'"+v"(x{n.i})' for n in plan.inputs)
+    if pin:
+        L.append(f"  asm volatile(\"\" : {pin});")
     L.append("  for (int64_t f0 = 0; f0 < frames; f0 += 64) {")
     L.append("    const int tn = (int)(frames - f0 < 64 ? frames - f0 : 64);")
     L.append("    const int last = tn - 1;")
@@ -1890,6 +1897,8 @@ def emit_hip(plan: Plan, prog: Program, kernel_macro: str = "ZA_KERNEL(tpar)") -
     retire(final=True)
     if has_mem:
         L.append("    if (fin && lane == last) { b.mem_high[inst] = zt_high > zt_hc ? zt_high : zt_hc; b.resume[inst] = frames; }")
+    if pin:
+        L.append(f"    asm volatile(\"\" : {pin});   // the next chunk's audio has landed; its wait comes before this chunk's stores")
     L.append("    if (valid) {")
     for ch in range(plan.nch):
         L.append(f"      out_[{ch} * a.frame_stride + f0 + lane] = (float){ref(plan.spl_out[ch])};")
