@@ -60,7 +60,10 @@ def test_full_size_fast_kernel_equals_serial_kernel_and_split_launches():
     es, ds = _run(zabatch, zabatch.ZAB_PATH_FAST, splits=10)
     err = _max_diff(ef, df, es, ds, N, FRAMES)
     print(f"one launch vs ten launches: max |diff| = {err:.3e}")
-    assert err <= 1e-9
+    # The ten 48 000-frame launches go to zab_ddt_wide, the single launch to zab_ddt_fast (the launch length picks): the two
+    # order their f64 sums differently (~1e-16 relative), which moves a float sample by one ulp about once in 1e9 samples;
+    # a state lost or doubled at a launch boundary would show at 1e-4 and above.
+    assert err <= 2.5e-7
     ef.close(); es.close()
 
 

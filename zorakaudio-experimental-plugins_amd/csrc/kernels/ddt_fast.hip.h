@@ -55,6 +55,7 @@ static char ddt_kernel_name[24] = "zab_ddt_fast";   /* zab_ddt_{fast,wide}[_nw2|
 // magnitude -- under the rounding of the sums it would be added to -- so only the launch's last 224 chunks feed the meters.
 #define DDT_METER_FRAMES 57344
 
+typedef float ddt_f4 __attribute__((ext_vector_type(4)));   // a float4 the register allocator keeps as ONE 128-bit tuple
 struct DdtTap { int32_t dL8, dR8; double gL, gR; };          // 8*delay (bytes) and gains of one tap (wave-uniform when used)
 struct DdtTapRegs { int dpack; double gL, gR; };             // lane j of every wave keeps staged tap j: dL | dR << 16, gains
 struct DdtPole {
@@ -180,23 +181,28 @@ struct DdtChunk {  // per-lane registers that live across the two workgroup barr
 
 // Phase A: read the chunk's audio, publish M to the shared ring (and the f64 L/R rings of mem[] when they survive).
 template <bool PARTIAL, bool DBL>
-__device__ __forceinline__ void ddt_phase_a(const DdtCtx& C, DdtChunk& K, int lane, int64_t f0, int nb, const float4& p0, const float4& p1) {
+__device__ __forceinline__ void ddt_phase_a(const DdtCtx& C, DdtChunk& K, int lane, int64_t f0, int nb, const ddt_f4& p0, const ddt_f4& p1) {
   const int64_t t0 = f0 + DDT_KF * lane;
   if (!PARTIAL && C.vec_ok) {                              // prefetched one iteration ahead (ddt_prefetch)
     K.x0[0] = p0.x; K.x0[1] = p0.y; K.x0[2] = p0.z; K.x0[3] = p0.w;
     K.x1[0] = p1.x; K.x1[1] = p1.y; K.x1[2] = p1.z; K.x1[3] = p1.w;
-  } else if (C.vec_ok && t0 >= 0) {
-    const float4 v0 = *reinterpret_cast<const float4*>(C.in0 + t0);
-    const float4 v1 = *reinterpret_cast<const float4*>(C.in1 + t0);
-    K.x0[0] = v0.x; K.x0[1] = v0.y; K.x0[2] = v0.z; K.x0[3] = v0.w;
-    K.x1[0] = v1.x; K.x1[1] = v1.y; K.x1[2] = v1.z; K.x1[3] = v1.w;
   } else {
+    // (these loads are waited for inside their branch: a wait at the merge with the prefetched path would be a vmcnt(0)
+    //  for that path too, i.e. for the previous chunk's stores)
+    if (C.vec_ok && t0 >= 0) {
+      const float4 v0 = *reinterpret_cast<const float4*>(C.in0 + t0);
+      const float4 v1 = *reinterpret_cast<const float4*>(C.in1 + t0);
+      K.x0[0] = v0.x; K.x0[1] = v0.y; K.x0[2] = v0.z; K.x0[3] = v0.w;
+      K.x1[0] = v1.x; K.x1[1] = v1.y; K.x1[2] = v1.z; K.x1[3] = v1.w;
+    } else {
 #pragma unroll
-    for (int k = 0; k < DDT_KF; ++k) {
-      const bool ok = t0 + k >= 0;
-      K.x0[k] = ok ? C.in0[t0 + k] : 0.0f;
-      K.x1[k] = ok ? C.in1[t0 + k] : 0.0f;
+      for (int k = 0; k < DDT_KF; ++k) {
+        const bool ok = t0 + k >= 0;
+        K.x0[k] = ok ? C.in0[t0 + k] : 0.0f;
+        K.x1[k] = ok ? C.in1[t0 + k] : 0.0f;
+      }
     }
+    asm volatile("" : "+v"(K.x0[0]), "+v"(K.x0[1]), "+v"(K.x0[2]), "+v"(K.x0[3]), "+v"(K.x1[0]), "+v"(K.x1[1]), "+v"(K.x1[2]), "+v"(K.x1[3]));
   }
   // nb = ring position of the chunk's first frame (uniform)
 #pragma unroll
@@ -571,15 +577,18 @@ __device__ __forceinline__ void ddt_fast_body(const ZabBatch& b, const ZabAudio&
   int64_t my_last_chunk = -1;
   int pos = DBL ? ddt_pos(C.wofs0 + f_first + (int64_t)DDT_CHUNK * wave, W) : 0;
   // The HBM read of a wave's next chunk is issued a whole iteration ahead of its use.
-  float4 pf0 = make_float4(0.f, 0.f, 0.f, 0.f), pf1 = pf0;
+  // (unconditional per lane, addresses clamped into the buffer: see ddt_ring2.hip.h on what a conditional load costs)
+  ddt_f4 pf0 = {0.f, 0.f, 0.f, 0.f}, pf1 = pf0;
   auto prefetch = [&](const int64_t c) __attribute__((always_inline)) {
-    const int64_t t0 = f_first + DDT_CHUNK * c + DDT_KF * lane;
-    if (C.vec_ok && c < nchunks && t0 >= 0) {
-      pf0 = *reinterpret_cast<const float4*>(C.in0 + t0);
-      pf1 = *reinterpret_cast<const float4*>(C.in1 + t0);
+    if (C.vec_ok) {
+      int64_t t0 = f_first + DDT_CHUNK * c + DDT_KF * lane;
+      t0 = t0 < 0 ? 0 : (t0 > frames - DDT_KF ? frames - DDT_KF : t0);
+      pf0 = *reinterpret_cast<const ddt_f4*>(C.in0 + t0);
+      pf1 = *reinterpret_cast<const ddt_f4*>(C.in1 + t0);
     }
   };
   if (f_first >= 0) prefetch(wave);
+  asm volatile("" : "+v"(pf0), "+v"(pf1));
   // One iteration = NW consecutive chunks, one per wave. PART: the launch's first chunk starts before frame 0.
   auto iteration = [&](auto part_c, const int64_t it) __attribute__((always_inline)) {
     constexpr bool PART = decltype(part_c)::value;
@@ -626,6 +635,9 @@ __device__ __forceinline__ void ddt_fast_body(const ZabBatch& b, const ZabAudio&
 #pragma unroll
       for (int s = 0; s < 6; ++s) carry[s] = run[s];       // state after this iteration's last chunk (same in every wave)
     }
+    // the next chunk's audio is waited for here, before this chunk's stores join the (in-order) queue -- not at the top of the
+    // loop, where the wait would be a full vmcnt(0) that includes the stores' trip to HBM
+    asm volatile("" : "+v"(pf0), "+v"(pf1));
     if (active) {
       if (f0 + DDT_CHUNK > frames - DDT_METER_FRAMES)     // wave-uniform
         ddt_phase_c<PART, true>(C, K, lane, f0, cw, wave != 0, ql, accM, accC, dMi, dCi, wM, wC, cwM, cwC, want_last);
