@@ -145,17 +145,20 @@ def test_port_stft_fixture_matches_reference_vm():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("leaf", ["fx_fftkat", "fx_fftkat_full"])   # default: 1024-point LDS buffer, larger complex transforms sliced; _full: all of it in LDS
 @pytest.mark.parametrize("n", SIZES)
-def test_gpu_fft_known_answers(n):
+def test_gpu_fft_known_answers(n, leaf):
     """Every op on 70 instances at once (two waves), each instance with its own scaled copy of the input."""
     import zabatch
+    if not zabatch.module_path(leaf).exists():
+        pytest.skip(f"{leaf} not built")
     inst = 70
     scale = 1.0 + np.arange(inst)[:, None] * 0.125
-    if n > 4096:
-        inst = 6                                    # (8192 and up take the serial device transform: keep the batch small)
+    if n > 4096 or (not leaf.endswith("_full") and n > 2048):
+        inst = 6                                    # (some ops of these sizes take the serial device transform: keep the batch small)
         scale = 1.0 + np.arange(inst)[:, None] * 0.125
     for op, x, want, src in _cases(n):
-        with zabatch.Engine("fx_fftkat", inst, mem_cap=1 << 18) as e:
+        with zabatch.Engine(leaf, inst, mem_cap=1 << 18) as e:
             e.set_sliders([0, n, 0, SRC_BASE]); e.prepare()
             e.write_mem(0, scale * x[None, :])
             if src is not None:

@@ -3,8 +3,13 @@ import sys; from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path[:0] = [str(ROOT / "zorakaudio-experimental-plugins_amd"), str(ROOT)]
 import zabatch, numpy as np
-for n, size, K in ((2048, 4096, 4), (2048, 1024, 4), (256, 4096, 4)):
-    with zabatch.Engine("fx_fftbench", n, mem_cap=1<<17) as e:
+import os
+CASES = [("fx_fftbench", 2048, 4096, 4), ("fx_fftbench", 2048, 2048, 4), ("fx_fftbench", 2048, 1024, 4), ("fx_fftbench", 256, 4096, 4),
+         ("fx_fftbench_full", 2048, 4096, 4), ("fx_fftbench_full", 2048, 1024, 4), ("fx_fftbench_full", 256, 4096, 4)]
+for leaf, n, size, K in CASES:
+    if not zabatch.module_path(leaf).exists():
+        continue
+    with zabatch.Engine(leaf, n, mem_cap=1<<17) as e:
         row = np.zeros(64); row[0]=size; row[1]=K; row[2]=15
         e.set_sliders(row); e.prepare()
         nch = e.nch; frames = 64
@@ -14,7 +19,9 @@ for n, size, K in ((2048, 4096, 4), (2048, 1024, 4), (256, 4096, 4)):
         for _ in range(2): e.process_device(di, do, frames, block=64); e.sync()
         ms,_ = e.last_timing()
         flops = 2*5*size*np.log2(size)
-        print(f"size={size} buffers={n} K={K}: {ms:.2f} ms -> {ms/K*1e3:.1f} us per round trip of the batch, {n*K*flops/ms/1e6:.1f} GFLOP/s, {n*K*4*2*size*16/ms/1e6:.1f} GB/s (4 ops x r+w)", flush=True)
+        print(f"{leaf} size={size} buffers={n} K={K}: {ms:.2f} ms -> {ms/K*1e3:.1f} us per round trip of the batch, {n*K*flops/ms/1e6:.1f} GFLOP/s, {n*K*4*2*size*16/ms/1e6:.1f} GB/s (4 ops x r+w)", flush=True)
+if os.environ.get("FFT_BENCH_ONLY_KERNELS"):
+    sys.exit(0)
 from zajit import noise
 ir = (noise.white_noise([321], 24000)[0].T * np.exp(-np.arange(24000) / 4000.0)[:, None]).reshape(-1).astype(np.float64)   # 0.5 s stereo
 for leaf, n, frames in (("fx_stft4k", 1024, 16384), ("fx_stft", 1024, 16384), ("DOT", 1024, 16384), ("PsychoConvolver", 1024, 16384),

@@ -296,7 +296,15 @@ int zab_create(const char* module, const zab_config* cfg, zab_engine** out) {
     // 75 ms at ipw 4 / 8 / 16; TSEQ x1024: 417 / 274 / 294 / 486 ms at ipw 1 / 2 / 4 / 8, x4096: 329 / 227 / 328 at 2 / 4 / 8,
     // x16384: 457 / 385 / 340 / 480 at 4 / 8 / 16 / 32.
     if (m->prefer_instance_major == 2) {
-      const int64_t target = m->fft_scratch_doubles > 0 ? 256 : 1024;
+      // An FFT leaf built with the 1024-point LDS buffer (zart_fft.h, the default since round 2) holds 24 KB per wavefront, six
+      // fit a CU, and it gets the 1024 target too. Measured (2048 buffers, fft + permute + ipermute + ifft round trip, target
+      // 256 / 1024 / 2048 / 4096 wavefronts): 1024 points 349 / 126 / 126 / 127 us, 4096 points (sliced) 2564 / 991 / 1001 / 992 us;
+      // DOT x1024 161 / 144 / 144 / 145 ms; the STFT fixtures and PsychoConvolver do not move (their serial script loops
+      // dominate). ZAB_FFT_WAVES overrides the target (experiments).
+      int lds_points = 4096;
+      if (auto fp = (int (*)(void))dlsym(dl, "zab_module_fft_lds_points")) lds_points = fp();
+      const char* tw = getenv("ZAB_FFT_WAVES");
+      const int64_t target = m->fft_scratch_doubles > 0 ? (lds_points <= 1024 ? (tw ? atoi(tw) : 1024) : 256) : 1024;
       ipw = 2;
       while (ipw < 64 && (int64_t)cfg->n_instances > target * ipw) ipw <<= 1;
     }

@@ -32,9 +32,23 @@
 // cos/sin(2*pi*j/ZA_FFT_MAX), j < ZA_FFT_MAX/2; filled once per process by za_fft_table_init (host) / init kernel (device)
 #if defined(__HIPCC__)
 #define ZA_FFT_COOP_MAX 4096
+// Complex points a wave keeps in LDS at a time (a module build knob). 1024 (default) = 16 KiB + 8 KiB of twiddles, six
+// wavefronts per CU; complex transforms of 2048 / 4096 points then run SLICED: 1024-point blocks through LDS, the last one
+// or two radix-2 stages from registers, the pieces meeting in the instance's HBM scratch (za_fft_coop); real transforms
+// above 2048 reals take the serial path. -DZA_FFT_LDS_POINTS=4096 = the whole of the largest cooperative transform in LDS
+// (64 KiB + 32 KiB: ONE wavefront per CU; round 1's layout, kept as the fixtures' *_full builds). Every size any leaf of
+// the catalog asks for (1024 complex, 2048 real) fits the small buffer. Measured (MI355X, 2048 buffers, fft + permute +
+// ipermute + ifft): 1024 points 357 -> 126 us, 4096 points 1421 -> 940 us (tools/fft_bench.py).
+#ifndef ZA_FFT_LDS_POINTS
+#define ZA_FFT_LDS_POINTS 1024
+#endif
+#if !defined(__HIP_DEVICE_COMPILE__)
+extern "C" int zab_module_fft_lds_points(void) { return ZA_FFT_LDS_POINTS; }   // read by the runtime (wavefronts per batch)
+#endif
 __device__ double za_fft_cos[ZA_FFT_MAX / 2];
 __device__ double za_fft_sin[ZA_FFT_MAX / 2];
 __device__ uint16_t za_fft_perm[2 * ZA_FFT_COOP_MAX];     // [n + i] = natural bin stored at position i of an n-point transform
+__device__ uint16_t za_fft_iperm[2 * ZA_FFT_COOP_MAX];    // [n + k] = position that holds natural bin k
 #else
 static double za_fft_cos[ZA_FFT_MAX / 2];
 static double za_fft_sin[ZA_FFT_MAX / 2];
@@ -88,7 +102,9 @@ extern "C" __global__ void za_fft_table_kernel() {
   if (j >= 2 && j < 2 * ZA_FFT_COOP_MAX) {      // j = n + i with n the largest power of two <= j (real transforms use sizes from 8)
     uint32_t n = 2;
     while (2 * n <= (uint32_t)j) n <<= 1;
-    za_fft_perm[j] = (uint16_t)za_fft_bin_of_pos((uint32_t)j - n, n);
+    const uint32_t bin = za_fft_bin_of_pos((uint32_t)j - n, n);
+    za_fft_perm[j] = (uint16_t)bin;
+    za_fft_iperm[n + bin] = (uint16_t)((uint32_t)j - n);
   }
 }
 #endif
@@ -120,10 +136,10 @@ ZA_FN bool za_fft_region(S& s, double baseD, int64_t span, int64_t& base, int64_
 #define ZA_F(a) s.fft[(a) * s.fft_stride]
 
 #if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
-// twiddles (cos, sin)(2 pi j / ZA_FFT_COOP_MAX), j < ZA_FFT_COOP_MAX / 2, staged in LDS by the first cooperative transform of
+// twiddles (cos, sin)(2 pi j / ZA_FFT_LDS_POINTS), j < ZA_FFT_LDS_POINTS / 2, staged in LDS by the first cooperative transform of
 // a workgroup. LDS is neither cleared nor private between launches, so every kernel of an FFT leaf resets the flag on
 // entry (ZA_KERNEL_ENTRY in zab_generic.hip.h) instead of trusting whatever an earlier workgroup left behind.
-__shared__ double za_fft_tw[ZA_FFT_COOP_MAX];
+__shared__ double za_fft_tw[ZA_FFT_LDS_POINTS];
 __shared__ int za_fft_tw_ready;
 #define ZA_KERNEL_ENTRY() do { za_fft_tw_ready = 0; __builtin_amdgcn_wave_barrier(); } while (0)
 enum { ZA_COOP_FFT = 0, ZA_COOP_IFFT = 1, ZA_COOP_PERMUTE = 2, ZA_COOP_IPERMUTE = 3, ZA_COOP_FFT_REAL = 4, ZA_COOP_IFFT_REAL = 5,
@@ -132,16 +148,52 @@ __device__ __forceinline__ int64_t za_readlane64(int64_t v, int l) {
   const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffff), l), hi = __builtin_amdgcn_readlane((int)(v >> 32), l);
   return ((int64_t)hi << 32) | (uint32_t)lo;
 }
+// The radix-2 passes of an nlp-point transform whose points sit bit-reversed in `buf` (LDS), butterflies spread over the nact
+// participating lanes. Four independent butterflies per trip: all their LDS reads are issued before the first store, which
+// the compiler cannot do by itself (it must assume the stores alias the next reads).
+__device__ __forceinline__ void za_fft_lds_stages(double* buf, const double* tw, int nlp, int sign, int rank, int nact) {
+  for (int len = 2; len <= nlp; len <<= 1) {
+    const int half = len >> 1, step = ZA_FFT_LDS_POINTS / len;
+    for (int idx0 = rank; idx0 < (nlp >> 1); idx0 += 4 * nact) {
+      double ar[4], ai[4], br[4], bi[4], wr[4], wi[4];
+      int pa[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = idx0 + u * nact;
+        const int ix = idx < (nlp >> 1) ? idx : 0;
+        const int j = ix & (half - 1), i = ((ix - j) << 1) + j;          // butterfly (i, i + half) of group ix / half
+        pa[u] = idx < (nlp >> 1) ? 2 * i : -1;
+        wr[u] = tw[2 * j * step]; wi[u] = tw[2 * j * step + 1];
+        ar[u] = buf[2 * i]; ai[u] = buf[2 * i + 1];
+        br[u] = buf[2 * (i + half)]; bi[u] = buf[2 * (i + half) + 1];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double w_i = sign < 0 ? -wi[u] : wi[u];
+        const double tr = br[u] * wr[u] - bi[u] * w_i, ti = br[u] * w_i + bi[u] * wr[u];
+        if (pa[u] >= 0) {
+          const int a = pa[u], b = pa[u] + 2 * half;
+          buf[a] = ar[u] + tr; buf[a + 1] = ai[u] + ti;
+          buf[b] = ar[u] - tr; buf[b + 1] = ai[u] - ti;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // Every lane that reached the builtin calls this (converged at the call site); `ok` says whether this lane has a valid
 // request (base, n). Returns true for the lanes whose request was served here.
 // Real transforms (n reals = n / 2 complex points, so n up to 2 * ZA_FFT_COOP_MAX) and convolve_c (n = complex pairs, base2 = its
 // second operand) take the same route; the arithmetic per element is the serial form's, hence the same bits.
 template <class S>
 __device__ __noinline__ bool za_fft_coop(S& s, bool ok, int64_t base, int n, int op, int64_t base2 = 0) {
-  __shared__ double buf[2 * ZA_FFT_COOP_MAX];
+  __shared__ double buf[2 * ZA_FFT_LDS_POINTS];
   double* const tw = za_fft_tw;
   const bool is_real = op == ZA_COOP_FFT_REAL || op == ZA_COOP_IFFT_REAL;
-  const bool coop = ok && (op == ZA_COOP_CONVOLVE || n <= (is_real ? 2 * ZA_FFT_COOP_MAX : ZA_FFT_COOP_MAX));
+  // what runs here: anything that fits the LDS buffer; complex transforms and permutations beyond it run sliced (below);
+  // real transforms beyond it take the serial path
+  const bool coop = ok && (op == ZA_COOP_CONVOLVE || (is_real ? n <= 2 * ZA_FFT_LDS_POINTS : n <= ZA_FFT_COOP_MAX));
   const bool mine = coop && !s.replica;            // replica lanes help with their primary's request, they add none
   const uint64_t active = __ballot(1);
   uint64_t todo = __ballot(mine);
@@ -150,9 +202,9 @@ __device__ __noinline__ bool za_fft_coop(S& s, bool ok, int64_t base, int n, int
   const int rank = __popcll(active & below), nact = __popcll(active);
   if (todo && (op == ZA_COOP_FFT || op == ZA_COOP_IFFT || is_real) && za_fft_tw_ready != 1) {
     // twiddles of the largest cooperative size, staged once per workgroup launch (the HBM table is 1 us away per read)
-    for (int j = rank; j < ZA_FFT_COOP_MAX / 2; j += nact) {
-      tw[2 * j] = za_fft_cos[j * (ZA_FFT_MAX / ZA_FFT_COOP_MAX)];
-      tw[2 * j + 1] = za_fft_sin[j * (ZA_FFT_MAX / ZA_FFT_COOP_MAX)];
+    for (int j = rank; j < ZA_FFT_LDS_POINTS / 2; j += nact) {
+      tw[2 * j] = za_fft_cos[j * (ZA_FFT_MAX / ZA_FFT_LDS_POINTS)];
+      tw[2 * j + 1] = za_fft_sin[j * (ZA_FFT_MAX / ZA_FFT_LDS_POINTS)];
     }
     __builtin_amdgcn_wave_barrier();
     if (rank == 0) za_fft_tw_ready = 1;
@@ -187,6 +239,97 @@ __device__ __noinline__ bool za_fft_coop(S& s, bool ok, int64_t base, int n, int
         ZA_G(2 * i + 1) = ar * bi + ai * br;
       }
       __builtin_amdgcn_wave_barrier();
+      continue;
+    }
+    if (nl > ZA_FFT_LDS_POINTS) {
+      // ---- sliced: the transform does not fit the LDS buffer (complex fft / ifft / permutations of 2048 or 4096 points) ----
+      // Same butterflies, same twiddles, same order of operations per element as the in-LDS form, hence the same bits.
+      double* const fp = (double*)za_readlane64((int64_t)(uintptr_t)s.fft, l);
+      const int64_t fs = za_readlane64(s.fft_stride, l);
+#define ZA_S(a) fp[(int64_t)(a) * fs]
+#define ZA_SLICE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); \
+                             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
+      constexpr int P = ZA_FFT_LDS_POINTS, PB = 31 - __builtin_clz(P);
+      const int B = nl / P, q = bits - PB;                     // blocks of P points; B = 2^q
+      if (op == ZA_COOP_PERMUTE || op == ZA_COOP_IPERMUTE) {
+        // through the scratch. Position i of a WDL-ordered buffer holds natural bin perm[i]:
+        //   fft_permute  (WDL order -> natural): out[k] = in[iperm[k]];   fft_ipermute (natural -> WDL order): out[i] = in[perm[i]]
+        for (int i = rank; i < 2 * nl; i += nact) ZA_S(i) = ZA_G(i);
+        ZA_SLICE_SYNC();
+        for (int i = rank; i < nl; i += nact) {
+          const int src = op == ZA_COOP_PERMUTE ? (int)za_fft_iperm[nl + i] : (int)za_fft_perm[nl + i];
+          ZA_G(2 * i) = ZA_S(2 * src);
+          ZA_G(2 * i + 1) = ZA_S(2 * src + 1);
+        }
+        ZA_SLICE_SYNC();
+        continue;
+      }
+      const int sign = op == ZA_COOP_FFT ? -1 : +1;
+      for (int b = 0; b < B; ++b) {
+        // block b of the bit-reversed array: its position m takes natural element k = bitrev_P(m) * B + bitrev_q(b)
+        const int rb = (int)za_bitrev((uint32_t)b, q);
+        for (int t0 = rank; t0 < P; t0 += 8 * nact) {
+          double vr[8], vi[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int t = t0 + u * nact;
+            const int k = (t < P ? t : 0) * B + rb;
+            const int src = op == ZA_COOP_FFT ? k : (int)za_fft_iperm[nl + k];   // ifft: the position that holds bin k
+            vr[u] = ZA_G(2 * src); vi[u] = ZA_G(2 * src + 1);
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int t = t0 + u * nact;
+            if (t < P) {
+              const uint32_t m = za_bitrev((uint32_t)t, PB);
+              buf[2 * m] = vr[u]; buf[2 * m + 1] = vi[u];
+            }
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        za_fft_lds_stages(buf, tw, P, sign, rank, nact);
+        for (int m = rank; m < P; m += nact) {
+          ZA_S(2 * (P * b + m)) = buf[2 * m];
+          ZA_S(2 * (P * b + m) + 1) = buf[2 * m + 1];
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      ZA_SLICE_SYNC();
+      // the last q passes (len = 2P [, 4P]) on the B elements j, j + P, ... of the scratch, from registers
+      for (int j = rank; j < P; j += nact) {
+        double er[4], ei[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (k < B) { er[k] = ZA_S(2 * (j + P * k)); ei[k] = ZA_S(2 * (j + P * k) + 1); }
+        auto bfly = [&](int a, int c, int widx) __attribute__((always_inline)) {   // (a, c) <- (a + w c, a - w c), w = W_MAX^widx
+          const double wr = za_fft_cos[widx], wi0 = za_fft_sin[widx];
+          const double w_i = sign < 0 ? -wi0 : wi0;
+          const double tr = er[c] * wr - ei[c] * w_i, ti = er[c] * w_i + ei[c] * wr;
+          const double xr = er[a], xi = ei[a];
+          er[a] = xr + tr; ei[a] = xi + ti;
+          er[c] = xr - tr; ei[c] = xi - ti;
+        };
+        {
+          const int st = ZA_FFT_MAX / (2 * P);                 // len = 2P, half = P: butterflies (j, j + P) [and (j + 2P, j + 3P)]
+          bfly(0, 1, j * st);
+          if (B == 4) bfly(2, 3, j * st);
+        }
+        if (B == 4) {
+          const int st = ZA_FFT_MAX / (4 * P);                 // len = 4P, half = 2P: (j, j + 2P) and (j + P, j + 3P)
+          bfly(0, 2, j * st);
+          bfly(1, 3, (j + P) * st);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (k < B) {
+            const int pbin = j + P * k;                        // natural index of the result
+            const int dst = op == ZA_COOP_FFT ? (int)za_fft_iperm[nl + pbin] : pbin;   // fft: stored in WDL_fft_permute order
+            ZA_G(2 * dst) = er[k]; ZA_G(2 * dst + 1) = ei[k];
+          }
+      }
+      ZA_SLICE_SYNC();
+#undef ZA_S
+#undef ZA_SLICE_SYNC
       continue;
     }
     // ---- stage the request's buffer in LDS, in the order its transform wants ----------------------------------------
@@ -257,36 +400,7 @@ __device__ __noinline__ bool za_fft_coop(S& s, bool ok, int64_t base, int n, int
     }
     if (op == ZA_COOP_FFT || op == ZA_COOP_IFFT || is_real) {
       const int sign = (op == ZA_COOP_FFT || op == ZA_COOP_FFT_REAL) ? -1 : +1;
-      for (int len = 2; len <= nl; len <<= 1) {
-        const int half = len >> 1, step = ZA_FFT_COOP_MAX / len;
-        // four independent butterflies per trip: all their LDS reads are issued before the first store, which the
-        // compiler cannot do by itself (it must assume the stores alias the next reads)
-        for (int idx0 = rank; idx0 < (nl >> 1); idx0 += 4 * nact) {
-          double ar[4], ai[4], br[4], bi[4], wr[4], wi[4];
-          int pa[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int idx = idx0 + u * nact;
-            const int ix = idx < (nl >> 1) ? idx : 0;
-            const int j = ix & (half - 1), i = ((ix - j) << 1) + j;          // butterfly (i, i + half) of group ix / half
-            pa[u] = idx < (nl >> 1) ? 2 * i : -1;
-            wr[u] = tw[2 * j * step]; wi[u] = tw[2 * j * step + 1];
-            ar[u] = buf[2 * i]; ai[u] = buf[2 * i + 1];
-            br[u] = buf[2 * (i + half)]; bi[u] = buf[2 * (i + half) + 1];
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const double w_i = sign < 0 ? -wi[u] : wi[u];
-            const double tr = br[u] * wr[u] - bi[u] * w_i, ti = br[u] * w_i + bi[u] * wr[u];
-            if (pa[u] >= 0) {
-              const int a = pa[u], b = pa[u] + 2 * half;
-              buf[a] = ar[u] + tr; buf[a + 1] = ai[u] + ti;
-              buf[b] = ar[u] - tr; buf[b + 1] = ai[u] - ti;
-            }
-          }
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
+      za_fft_lds_stages(buf, tw, nl, sign, rank, nact);
     }
     if (op == ZA_COOP_FFT_REAL) {
       // Z (natural order in buf) -> the packed spectrum of the real input, position i holds bin perm_h(i), scaled by 2

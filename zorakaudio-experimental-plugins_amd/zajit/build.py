@@ -44,6 +44,8 @@ FAST_KERNEL_DEPS = {"DDT": ["kernels/ddt_fast.hip.h"]}     # headers the hand-wr
 # load is branch-free by default (better or equal on 20 leaves, up to 14 %); these four delay-line / FIR style scripts run
 # faster with the bounds check as a branch around the load (Roomalizer 1.76x, TSEQ 1.07x, DOT 1.05x, DPT 1.03x).
 LEAF_FLAGS = {"fx_dynkat_s1": ["-DZT_SPEC_MAX=1"],       # test variant: switched recurrences mostly fall back to their serial loop
+              # FFT builtins with the whole 4096-point transform in LDS (zart_fft.h: ZA_FFT_LDS_POINTS; default 1024 + slicing)
+              "fx_fftkat_full": ["-DZA_FFT_LDS_POINTS=4096"], "fx_fftbench_full": ["-DZA_FFT_LDS_POINTS=4096"],
               "Roomalizer": ["-DZA_LD_BRANCH"], "TSEQ": ["-DZA_LD_BRANCH"], "DOT": ["-DZA_LD_BRANCH"], "DPT": ["-DZA_LD_BRANCH"]}
 # leaves whose state the hand-written kernel wants contiguous per instance
 INSTANCE_MAJOR = {"DDT"}
