@@ -5,12 +5,15 @@ sys.path[:0] = [str(ROOT / "zorakaudio-experimental-plugins_amd"), str(ROOT)]
 import zabatch, numpy as np
 import os
 CASES = [("fx_fftbench", 2048, 4096, 4), ("fx_fftbench", 2048, 2048, 4), ("fx_fftbench", 2048, 1024, 4), ("fx_fftbench", 256, 4096, 4),
+         ("fx_fftbench+fused", 2048, 4096, 4), ("fx_fftbench+fused", 2048, 1024, 4),
          ("fx_fftbench_full", 2048, 4096, 4), ("fx_fftbench_full", 2048, 1024, 4), ("fx_fftbench_full", 256, 4096, 4)]
 for leaf, n, size, K in CASES:
+    fused = leaf.endswith("+fused")      # the four builtins as adjacent calls: fft;permute and ipermute;ifft run as one transform each
+    label, leaf = leaf, leaf.split("+")[0]
     if not zabatch.module_path(leaf).exists():
         continue
     with zabatch.Engine(leaf, n, mem_cap=1<<17) as e:
-        row = np.zeros(64); row[0]=size; row[1]=K; row[2]=15
+        row = np.zeros(64); row[0]=size; row[1]=K; row[2]=31 if fused else 15
         e.set_sliders(row); e.prepare()
         nch = e.nch; frames = 64
         nb = n*nch*frames*4
@@ -19,7 +22,7 @@ for leaf, n, size, K in CASES:
         for _ in range(2): e.process_device(di, do, frames, block=64); e.sync()
         ms,_ = e.last_timing()
         flops = 2*5*size*np.log2(size)
-        print(f"{leaf} size={size} buffers={n} K={K}: {ms:.2f} ms -> {ms/K*1e3:.1f} us per round trip of the batch, {n*K*flops/ms/1e6:.1f} GFLOP/s, {n*K*4*2*size*16/ms/1e6:.1f} GB/s (4 ops x r+w)", flush=True)
+        print(f"{label} size={size} buffers={n} K={K}: {ms:.2f} ms -> {ms/K*1e3:.1f} us per round trip of the batch, {n*K*flops/ms/1e6:.1f} GFLOP/s, {n*K*4*2*size*16/ms/1e6:.1f} GB/s (4 ops x r+w)", flush=True)
 if os.environ.get("FFT_BENCH_ONLY_KERNELS"):
     sys.exit(0)
 from zajit import noise

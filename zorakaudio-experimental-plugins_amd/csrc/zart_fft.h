@@ -143,7 +143,9 @@ __shared__ double za_fft_tw[ZA_FFT_LDS_POINTS];
 __shared__ int za_fft_tw_ready;
 #define ZA_KERNEL_ENTRY() do { za_fft_tw_ready = 0; __builtin_amdgcn_wave_barrier(); } while (0)
 enum { ZA_COOP_FFT = 0, ZA_COOP_IFFT = 1, ZA_COOP_PERMUTE = 2, ZA_COOP_IPERMUTE = 3, ZA_COOP_FFT_REAL = 4, ZA_COOP_IFFT_REAL = 5,
-       ZA_COOP_CONVOLVE = 6 };
+       ZA_COOP_CONVOLVE = 6,
+       ZA_COOP_FFT_NAT = 7,      // fft(b, n); fft_permute(b, n)    -> natural order in, natural-order spectrum out
+       ZA_COOP_IFFT_NAT = 8 };   // fft_ipermute(b, n); ifft(b, n)  -> natural-order spectrum in, natural order out
 __device__ __forceinline__ int64_t za_readlane64(int64_t v, int l) {
   const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffff), l), hi = __builtin_amdgcn_readlane((int)(v >> 32), l);
   return ((int64_t)hi << 32) | (uint32_t)lo;
@@ -200,7 +202,8 @@ __device__ __noinline__ bool za_fft_coop(S& s, bool ok, int64_t base, int n, int
   const int lane = (int)(threadIdx.x & 63);
   const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
   const int rank = __popcll(active & below), nact = __popcll(active);
-  if (todo && (op == ZA_COOP_FFT || op == ZA_COOP_IFFT || is_real) && za_fft_tw_ready != 1) {
+  const bool is_nat = op == ZA_COOP_FFT_NAT || op == ZA_COOP_IFFT_NAT;
+  if (todo && (op == ZA_COOP_FFT || op == ZA_COOP_IFFT || is_real || is_nat) && za_fft_tw_ready != 1) {
     // twiddles of the largest cooperative size, staged once per workgroup launch (the HBM table is 1 us away per read)
     for (int j = rank; j < ZA_FFT_LDS_POINTS / 2; j += nact) {
       tw[2 * j] = za_fft_cos[j * (ZA_FFT_MAX / ZA_FFT_LDS_POINTS)];
@@ -264,7 +267,7 @@ __device__ __noinline__ bool za_fft_coop(S& s, bool ok, int64_t base, int n, int
         ZA_SLICE_SYNC();
         continue;
       }
-      const int sign = op == ZA_COOP_FFT ? -1 : +1;
+      const int sign = (op == ZA_COOP_FFT || op == ZA_COOP_FFT_NAT) ? -1 : +1;
       for (int b = 0; b < B; ++b) {
         // block b of the bit-reversed array: its position m takes natural element k = bitrev_P(m) * B + bitrev_q(b)
         const int rb = (int)za_bitrev((uint32_t)b, q);
@@ -274,7 +277,7 @@ __device__ __noinline__ bool za_fft_coop(S& s, bool ok, int64_t base, int n, int
           for (int u = 0; u < 8; ++u) {
             const int t = t0 + u * nact;
             const int k = (t < P ? t : 0) * B + rb;
-            const int src = op == ZA_COOP_FFT ? k : (int)za_fft_iperm[nl + k];   // ifft: the position that holds bin k
+            const int src = op == ZA_COOP_IFFT ? (int)za_fft_iperm[nl + k] : k;  // ifft: the position that holds bin k
             vr[u] = ZA_G(2 * src); vi[u] = ZA_G(2 * src + 1);
           }
 #pragma unroll
@@ -323,7 +326,7 @@ __device__ __noinline__ bool za_fft_coop(S& s, bool ok, int64_t base, int n, int
         for (int k = 0; k < 4; ++k)
           if (k < B) {
             const int pbin = j + P * k;                        // natural index of the result
-            const int dst = op == ZA_COOP_FFT ? (int)za_fft_iperm[nl + pbin] : pbin;   // fft: stored in WDL_fft_permute order
+            const int dst = op == ZA_COOP_FFT ? (int)za_fft_iperm[nl + pbin] : pbin;   // fft alone: stored in WDL_fft_permute order
             ZA_G(2 * dst) = er[k]; ZA_G(2 * dst + 1) = ei[k];
           }
       }
@@ -350,7 +353,7 @@ __device__ __noinline__ bool za_fft_coop(S& s, bool ok, int64_t base, int n, int
         const int i = i0 + u * nact;
         if (i < nl) {
           uint32_t dst;
-          if (op == ZA_COOP_FFT || op == ZA_COOP_FFT_REAL) dst = za_bitrev((uint32_t)i, bits);
+          if (op == ZA_COOP_FFT || op == ZA_COOP_FFT_REAL || is_nat) dst = za_bitrev((uint32_t)i, bits);
           else if (op == ZA_COOP_IFFT) dst = za_bitrev(pm[u], bits);
           else if (op == ZA_COOP_PERMUTE || op == ZA_COOP_IFFT_REAL) dst = pm[u];      // (ifft_real: natural bin order first)
           else dst = (uint32_t)i;
@@ -398,8 +401,8 @@ __device__ __noinline__ bool za_fft_coop(S& s, bool ok, int64_t base, int n, int
       }
       __builtin_amdgcn_wave_barrier();
     }
-    if (op == ZA_COOP_FFT || op == ZA_COOP_IFFT || is_real) {
-      const int sign = (op == ZA_COOP_FFT || op == ZA_COOP_FFT_REAL) ? -1 : +1;
+    if (op == ZA_COOP_FFT || op == ZA_COOP_IFFT || is_real || is_nat) {
+      const int sign = (op == ZA_COOP_FFT || op == ZA_COOP_FFT_REAL || op == ZA_COOP_FFT_NAT) ? -1 : +1;
       za_fft_lds_stages(buf, tw, nl, sign, rank, nact);
     }
     if (op == ZA_COOP_FFT_REAL) {
@@ -517,6 +520,30 @@ template <class S> ZA_NOINLINE double za_ifft(S& s, double baseD, double sizeD) 
   const bool ok = za_fft_pow2(n) && za_fft_region(s, baseD, 2 * n, base, 2 * n);
   ZA_FFT_TRY_COOP(ZA_COOP_IFFT);
   if (!ok) return 0.0;
+  za_fft_inv_core(s, base, (int)n);
+  return 0.0;
+}
+template <class S> ZA_NOINLINE double za_fft_permute(S& s, double baseD, double sizeD);
+template <class S> ZA_NOINLINE double za_fft_ipermute(S& s, double baseD, double sizeD);
+// fft(b, n); fft_permute(b, n) and fft_ipermute(b, n); ifft(b, n) with identical arguments, fused by the translator (zajit/emit.py
+// e_Seq): the permutations are exact moves, so a natural-order transform gives the same bits with one pass over the buffer
+// fewer. The serial form (CPU port; device beyond the cooperative sizes) simply runs the two builtins.
+template <class S> ZA_NOINLINE double za_fft_nat(S& s, double baseD, double sizeD) {
+  const int64_t n = za_round_idx(sizeD);
+  int64_t base = 0;
+  const bool ok = za_fft_pow2(n) && za_fft_region(s, baseD, 2 * n, base, 2 * n);
+  ZA_FFT_TRY_COOP(ZA_COOP_FFT_NAT);
+  if (!ok) return 0.0;
+  za_fft_fwd_core(s, base, (int)n);
+  return za_fft_permute(s, baseD, sizeD);
+}
+template <class S> ZA_NOINLINE double za_ifft_nat(S& s, double baseD, double sizeD) {
+  const int64_t n = za_round_idx(sizeD);
+  int64_t base = 0;
+  const bool ok = za_fft_pow2(n) && za_fft_region(s, baseD, 2 * n, base, 2 * n);
+  ZA_FFT_TRY_COOP(ZA_COOP_IFFT_NAT);
+  if (!ok) return 0.0;
+  za_fft_ipermute(s, baseD, sizeD);
   za_fft_inv_core(s, base, (int)n);
   return 0.0;
 }

@@ -311,9 +311,38 @@ class Emitter:
         self.dyn_spl = True
         return "s.spl", 0
 
+    @staticmethod
+    def _plain_arg(a) -> bool:
+        """An argument that can be evaluated twice or once alike: numbers, variables and arithmetic on them."""
+        if isinstance(a, (S.Num, S.Var)):
+            return True
+        if isinstance(a, S.Unary):
+            return Emitter._plain_arg(a.a)
+        if isinstance(a, S.Binary):
+            return Emitter._plain_arg(a.l) and Emitter._plain_arg(a.r)
+        return False
+
+    def _fuse_fft_pairs(self, items):
+        """fft(b, n); fft_permute(b, n)  ->  __fft_nat(b, n)   and   fft_ipermute(b, n); ifft(b, n)  ->  __ifft_nat(b, n)
+        when both calls have the same side-effect-free arguments (zart_fft.h za_fft_nat: same bits, one pass fewer)."""
+        out, i = [], 0
+        while i < len(items):
+            a, b = items[i], items[i + 1] if i + 1 < len(items) else None
+            if (isinstance(a, S.Call) and isinstance(b, S.Call) and len(a.args) == 2 and len(b.args) == 2
+                    and (a.fn, b.fn) in (("fft", "fft_permute"), ("fft_ipermute", "ifft"))
+                    and repr(a.args) == repr(b.args) and all(self._plain_arg(x) for x in a.args)):
+                out.append(S.Call("__fft_nat" if a.fn == "fft" else "__ifft_nat", a.args, line=a.line, col=a.col))
+                i += 2
+                continue
+            out.append(a)
+            i += 1
+        return out
+
     def e_Seq(self, n):
         if not n.items:
             return "0.0"
+        if len(n.items) > 1:
+            n = S.Seq(self._fuse_fft_pairs(n.items), line=n.line, col=n.col)
         parts = []
         for it in n.items[:-1]:
             parts.append(self.stmt(it))
@@ -659,6 +688,9 @@ class Emitter:
             self.nargs(n, 2)
             self.features.add("fft")
             return self.call_rt(n, "za_" + fn)
+        if fn in ("__fft_nat", "__ifft_nat"):          # fused pairs (_fuse_fft_pairs)
+            self.features.add("fft")
+            return self.call_rt(n, "za_" + fn[2:])
         if fn == "convolve_c":
             self.nargs(n, 3)
             self.features.add("fft")
