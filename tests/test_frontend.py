@@ -180,13 +180,28 @@ COOP_CASES = [
     ("s = 0; i = 0; loop(64, s += mem[100 + i] * mem[i]; i += 1;); spl0 = s;", 1),                     # FIR
     ("a = 0; b = 0; i = 0; loop(32, c = mem[i]; a += c * spl0; b -= c; i += 2;); spl0 = a + b;", 1),       # two sums, temp, step 2
     ("function tap(k) local(j) ( j = (k + 3) & 63; mem[j]; ); s = 0; i = 0; loop(64, s += tap(i); i += 1;); spl0 = s;", 1),
-    ("s = 0; i = 0; loop(64, mem[i] = s; s += 1; i += 1;);", 0),                                         # arena store
+    ("s = 0; i = 0; loop(64, mem[i] = s; s += 1; i += 1;);", 1),                                         # arena store: a map loop, two counters
     ("s = 0; i = 0; loop(64, s += mem[i] * s; i += 1;);", 0),                                            # sum read in the trip
     ("s = 0; i = 0; y = 0; loop(64, s += y; y = mem[i]; i += 1;);", 0),                                  # y carried between trips
     ("s = 0; i = 0; loop(64, s += mem[i]; i += 0.5;);", 0),                                              # non-integer step
     ("s = 0; i = 0; loop(64, s += mem[i]; mem[i] > 0 ? i += 1;);", 0),                                   # conditional counter
     ("s = 0; i = 0; loop(64, s += rand(1); i += 1;);", 0),                                               # impure builtin
     ("s = 0; i = 0; loop(8, j = 0; loop(8, s += mem[i + j]; j += 1;); i += 1;);", 1),                    # only the inner loop
+]
+
+
+COOP_CASES += [
+    # elementwise ("map") loops: _map_plan. Whether the trips are independent is decided at run time (za_map_ok).
+    ("i = 0; loop(64, mem[200 + i] = mem[i] * 2; i += 1;);", 1),
+    ("i = 0; loop(64, mem[i + 1] = mem[i]; i += 1;);", 1),                                               # (the guard refuses it when it runs)
+    ("i = 0; loop(64, x = mem[i]; x < 0 ? x = 0; mem[i] = x; i += 1;);", 1),                             # conditional write after a definition
+    ("i = 0; while (i < 64) ( mem[2 * i] += mem[2 * i + 1]; i += 1; );", 1),                             # while form
+    ("b = 64; function add(d, r, n) local(i) ( i = 0; while (i < n) ( d[i] += r[i]; i += 1; ); ); add(0, b, 32); add(b, 0, 32);", 1),
+    ("i = 0; p = 0; loop(64, t = mem[i]; mem[i] = t + p; p = t; i += 1;);", 0),                          # p carried between trips
+    ("i = 0; loop(64, mem[i] > 0 ? y = 1; mem[i] = y; i += 1;);", 0),                                    # y only written conditionally
+    ("i = 0; loop(64, mem[i] = rand(1); i += 1;);", 0),                                                  # impure builtin
+    ("i = 0; loop(64, mem[mem[i]] = 1; i += 1;);", 0),                                                   # address not affine in the counter
+    ("i = 0; n = 64; while (i < n) ( mem[i] = 0; n -= 1; i += 1; );", 0),                                # the bound moves
 ]
 
 

@@ -173,6 +173,69 @@ template <class S>
 ZA_FN double za_coop_sum(S& s, double x) { (void)s; return x; }
 #endif
 
+// Elementwise ("map") loops shared by the replica lanes of an instance (zajit/emit.py _map_plan): one row per arena access of
+// a trip. kind 0 load / 1 store at a0 + sig * trip; kind 2 a load somewhere in [a0, a0 + ext).
+struct ZaMapAcc { double a0, ext; int32_t sig, kind; };
+// Are the c trips independent -- no store of one trip at an address another trip touches? Conservative: a store and another
+// access either never meet (disjoint address ranges), or walk in step and meet only inside one trip (same stride, first
+// addresses equal) or never (first addresses differ by less than a multiple of the stride: re / im interleave).
+ZA_FN bool za_map_ok(const ZaMapAcc* A, int n, int64_t c) {
+  if (c < 2) return false;
+  double lo[24], hi[24];
+  for (int j = 0; j < n; ++j) {
+    if (!za_coop_int(A[j].a0)) return false;
+    if (A[j].kind == 2) {
+      if (!za_coop_int(A[j].ext) || A[j].ext < 1.0) return false;
+      lo[j] = A[j].a0; hi[j] = A[j].a0 + A[j].ext - 1.0;
+    } else {
+      const double e = A[j].a0 + (double)A[j].sig * (double)(c - 1);
+      lo[j] = A[j].a0 < e ? A[j].a0 : e; hi[j] = A[j].a0 < e ? e : A[j].a0;
+    }
+    if (lo[j] < 0.0 || hi[j] > 2147483000.0) return false;
+  }
+  for (int j = 0; j < n; ++j) {
+    if (A[j].kind != 1) continue;
+    if (A[j].sig == 0) return false;                         // every trip stores to the same cell
+    for (int k = 0; k < n; ++k) {
+      if (k == j) continue;
+      if (hi[j] < lo[k] || hi[k] < lo[j]) continue;          // never meet
+      if (A[k].kind == 2 || A[k].sig != A[j].sig) return false;
+      const double d = A[k].a0 - A[j].a0;
+      if (d == 0.0) continue;                                // the same cell, in the same trip only
+      if (fmod(d, (double)A[j].sig) != 0.0) continue;        // interleaved, never the same cell
+      return false;
+    }
+  }
+  return true;
+}
+// trips of `while (v < bound) ( ...; v += step; )`, step > 0
+ZA_FN int64_t za_map_trips(double bound, double v, double step) {
+  const double d = (bound - v) / step;
+  if (!(d > 0.0)) return 0;
+  if (!(d < 1.0e9)) return (int64_t)1 << 40;
+  return (int64_t)ceil(d);
+}
+#if defined(__HIPCC__)
+// after the shared trips: what the replica lanes stored becomes visible to each other, and the per-lane bookkeeping of those
+// stores (high-water mark, overflow report) is merged so that every lane -- the primary one, which is written back -- has it
+template <class S>
+ZA_FN void za_map_sync(S& s) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  for (uint32_t off = s.rep_stride; off < 64u; off <<= 1) {
+    const int64_t h = __shfl_xor(s.mem_high, (int)off, 64), nd = __shfl_xor(s.mem_need, (int)off, 64);
+    const uint32_t e = (uint32_t)__shfl_xor((int)s.err, (int)off, 64);
+    s.mem_high = h > s.mem_high ? h : s.mem_high;
+    s.mem_need = nd > s.mem_need ? nd : s.mem_need;
+    s.err |= e;
+  }
+}
+#else
+template <class S>
+ZA_FN void za_map_sync(S& s) { (void)s; }
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // mem[]
 // ---------------------------------------------------------------------------------------------
@@ -251,6 +314,15 @@ ZA_FN double za_memset(S& s, double dest, double value, double len) {
   int64_t e = d + n;
   if (e > s.mem_cap) e = s.mem_cap;
   int64_t i = d;
+#if defined(__HIPCC__)
+  if (ZA_COOP_ON(s) && e - d >= 2 * (int64_t)s.rep_n) {    // the instance's replica lanes share the range
+    for (i = d + s.rep_i; i < e; i += s.rep_n) {
+      if (ZA_LM_HIT(s, i)) ZA_LM_REF(s, i) = value; else s.mem[i * s.mem_stride] = value;
+    }
+    za_map_sync(s);
+    return dest;
+  }
+#endif
   for (; i < e && ZA_LM_HIT(s, i); ++i) ZA_LM_REF(s, i) = value;
   for (; i < e; ++i) s.mem[i * s.mem_stride] = value;
   return dest;
@@ -275,6 +347,13 @@ ZA_FN double za_memcpy(S& s, double destD, double srcD, double lenD) {
   const int64_t st = s.mem_stride;
 #define ZA_CP1(i) do { const double x_ = ZA_LM_HIT(s, r + (i)) ? ZA_LM_REF(s, r + (i)) : s.mem[(r + (i)) * st];                    \
                        if (ZA_LM_HIT(s, d + (i))) ZA_LM_REF(s, d + (i)) = x_; else s.mem[(d + (i)) * st] = x_; } while (0)
+#if defined(__HIPCC__)
+  if (ZA_COOP_ON(s) && n >= 2 * (int64_t)s.rep_n && (d + n <= r || r + n <= d)) {   // disjoint: the replica lanes share the range
+    for (int64_t i = s.rep_i; i < n; i += s.rep_n) ZA_CP1(i);
+    za_map_sync(s);
+    return 0.0;
+  }
+#endif
   if (d <= r) for (int64_t i = 0; i < n; ++i) ZA_CP1(i);
   else for (int64_t i = n - 1; i >= 0; --i) ZA_CP1(i);
 #undef ZA_CP1

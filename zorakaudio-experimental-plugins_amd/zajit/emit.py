@@ -362,9 +362,45 @@ class Emitter:
             return s
         if isinstance(n, S.While):
             c = self.t("w")
+            shared = self._map_while(n)
+            if shared:
+                return shared
             return (f"{{ int64_t {c} = 0; while (za_truthy({self.expr(n.cond)})) {{ {self.stmt(n.body)} "
                     f"if (++{c} >= ZA_LOOP_CAP) {{ s.err |= ZA_ERR_LOOP_CAP; break; }} }} }}")
         return f"(void)({self.expr(n)});"
+
+    def _map_while(self, n):
+        """`while (v < X) ( body; v += <positive integer>; )` with X loop-invariant, as a map loop (_map_plan) when the trips
+        turn out independent where it runs; the serial form otherwise."""
+        hot = self.cur_sec in ("block", "sample")
+        if not (hot and self.coop and not self.redirect) or self._nodes(n.body) > 400:
+            return None
+        if any(isinstance(x, (S.Loop, S.While)) for x in _walk(n.body)):
+            return None
+        cd = n.cond
+        if not (isinstance(cd, S.Binary) and cd.op == "<" and isinstance(cd.l, S.Var)):
+            return None
+        items = n.body.items if isinstance(n.body, S.Seq) else [n.body]
+        plan = self._map_plan(items, set(self.scope[-1]) if self.scope else set())
+        if not plan:
+            return None
+        ind = plan[0]
+        v = cd.l.name
+        if ind.get(v, 0.0) <= 0.0:
+            return None
+        written = {x.target.name for it in items for x in _walk(it) if isinstance(x, S.Assign) and isinstance(x.target, S.Var)}
+        for x in _walk(cd.r):                                # the bound must not move while the loop runs
+            if isinstance(x, (S.Index, S.Assign, S.Call, S.Cond)) or (isinstance(x, S.Var) and x.name in written):
+                return None
+        c, w = self.t("n"), self.t("w")
+        body = self.expr(n.body)
+        pro, okx, shared = self._map_loop(plan, c, body)
+        serial = (f"{{ int64_t {w} = 0; while (za_truthy({self.expr(n.cond)})) {{ {self.stmt(n.body)} "
+                  f"if (++{w} >= ZA_LOOP_CAP) {{ s.err |= ZA_ERR_LOOP_CAP; break; }} }} }}")
+        count = f"za_map_trips({self.expr(cd.r)}, {self.var_ref(v)}, {c_double(ind[v])})"
+        return (f"{{ bool z_ = false; if (ZA_COOP_ON(s)) {{ const int64_t {c} = {count}; "
+                f"if ({c} >= 2 * (int64_t)s.rep_n && {c} < ZA_LOOP_CAP) {{ {pro} z_ = {okx}; if (z_) {{ {shared} }} }} }} "
+                f"if (!z_) {serial} }}")
 
     def e_If(self, n):
         return "({ " + self.stmt(n) + " 0.0; })"
@@ -481,6 +517,223 @@ class Emitter:
                 return None
         return sorted(acc), ind
 
+
+    # -- elementwise ("map") loops shared by replica lanes ----------------------------------------
+    class _Aff:
+        """address = sum(coef[v] * v over induction variables) + const + sum(terms), terms = loop-invariant expressions"""
+        __slots__ = ("coef", "const", "terms")
+
+        def __init__(self, coef=None, const=0.0, terms=None):
+            self.coef, self.const, self.terms = dict(coef or {}), float(const), list(terms or [])
+
+        def add(self, o, sign=1.0):
+            c = dict(self.coef)
+            for k, v in o.coef.items():
+                c[k] = c.get(k, 0.0) + sign * v
+            t = self.terms + ([x for x in o.terms] if sign > 0 else [S.Unary("-", x) for x in o.terms])
+            return Emitter._Aff(c, self.const + sign * o.const, t)
+
+        def scale(self, f):
+            return Emitter._Aff({k: v * f for k, v in self.coef.items()}, self.const * f,
+                                [S.Binary("*", S.Num(float(f)), x) for x in self.terms])
+
+    def _map_plan(self, items, scope_params):
+        """Is one trip of a loop a map over mem[]: every arena access at an address that is affine in the loop's counters
+        (`k += <integer>` as the trip's LAST statements) with loop-invariant rest, every other variable written in the trip
+        assigned before it is read in that trip, no calls besides pure maths, no nested loops, no gmem / spl / slider
+        stores? Returns (ind {name: step}, accesses [(kind, _Aff | (_Aff base, modulus ast))]) or None. Whether the trips
+        are independent is decided where the loop runs (za_map_ok): from the accesses' first addresses and strides."""
+        written = set()
+        for it in items:
+            for x in _walk(it):
+                if isinstance(x, (S.Loop, S.While, S.FuncDef, S.Str)):
+                    return None
+                if isinstance(x, S.Call) and x.fn not in self._COOP_PURE:
+                    return None
+                if isinstance(x, S.Index) and self._is_gmem(x):
+                    return None
+                if isinstance(x, S.Assign):
+                    t = x.target
+                    if isinstance(t, S.Var):
+                        if t.name in scope_params or is_spl_name(t.name) is not None or is_slider_name(t.name) is not None \
+                                or t.name in ("mem", "gmem") or t.name.startswith("$"):
+                            return None
+                        written.add(t.name)
+                    elif not isinstance(t, S.Index):
+                        return None
+        # counters: the trailing `v += n` / `v -= n` statements, each variable written nowhere else
+        ind, tail = {}, len(items)
+        while tail > 0:
+            it = items[tail - 1]
+            if (isinstance(it, S.Assign) and it.op in ("+=", "-=") and isinstance(it.target, S.Var) and isinstance(it.value, S.Num)
+                    and float(it.value.value) == int(it.value.value) and int(it.value.value) != 0 and it.target.name not in ind):
+                ind[it.target.name] = (1.0 if it.op == "+=" else -1.0) * float(it.value.value)
+                tail -= 1
+            else:
+                break
+        if not ind or tail == 0:
+            return None
+        body = items[:tail]
+        for it in body:
+            for x in _walk(it):
+                if isinstance(x, S.Assign) and isinstance(x.target, S.Var) and x.target.name in ind:
+                    return None
+        temps = written - set(ind)
+
+        def invariant(node):
+            for x in _walk(node):
+                if isinstance(x, S.Index) or (isinstance(x, S.Var) and (x.name in written)) or isinstance(x, (S.Assign, S.Call, S.Cond)):
+                    return False
+            return True
+
+        env = {}                                            # temp -> _Aff while it holds an affine value
+
+        def aff(node):
+            if isinstance(node, S.Num):
+                return self._Aff(const=float(node.value))
+            if isinstance(node, S.Var):
+                if node.name in ind:
+                    return self._Aff({node.name: 1.0})
+                if node.name in temps:
+                    return env.get(node.name)
+                if node.name == "mem":
+                    return self._Aff()
+                return self._Aff(terms=[node])
+            if isinstance(node, S.Unary) and node.op in ("+", "-"):
+                a = aff(node.a)
+                return None if a is None else (a if node.op == "+" else a.scale(-1.0))
+            if isinstance(node, S.Binary) and node.op in ("+", "-"):
+                a, b = aff(node.l), aff(node.r)
+                return None if a is None or b is None else a.add(b, 1.0 if node.op == "+" else -1.0)
+            if isinstance(node, S.Binary) and node.op == "*":
+                for u, v in ((node.l, node.r), (node.r, node.l)):
+                    if isinstance(u, S.Num) and float(u.value) == int(u.value):
+                        a = aff(v)
+                        return None if a is None else a.scale(float(u.value))
+            if invariant(node):
+                return self._Aff(terms=[node])
+            return None
+
+        accesses, defined, ok = [], set(), [True]
+
+        def access(node, kind):
+            a = aff(S.Binary("+", node.base, node.index))
+            if a is not None:
+                accesses.append((kind, a))
+                return
+            # base[(affine) % M] with M invariant: a load somewhere in [base, base + M)
+            ix = node.index
+            if kind == 0 and isinstance(ix, S.Binary) and ix.op == "%" and invariant(ix.r):
+                b = aff(node.base)
+                if b is not None and not b.coef:
+                    accesses.append((2, (b, ix.r)))
+                    return
+            ok[0] = False
+
+        def walk(node, cond):
+            if not ok[0]:
+                return
+            if isinstance(node, (S.Num,)):
+                return
+            if isinstance(node, S.Var):
+                if node.name in temps and node.name not in defined:
+                    ok[0] = False                            # would read the previous trip's value
+                return
+            if isinstance(node, S.Index):
+                walk(node.base, cond); walk(node.index, cond)
+                access(node, 0)
+                return
+            if isinstance(node, S.Assign):
+                t = node.target
+                walk(node.value, cond)
+                if isinstance(t, S.Var):
+                    if node.op != "=":
+                        if t.name not in defined:
+                            ok[0] = False
+                        env.pop(t.name, None)
+                        return
+                    if cond:
+                        if t.name not in defined:
+                            ok[0] = False                    # a conditional write must follow an unconditional one in the same trip
+                        env.pop(t.name, None)
+                        return
+                    a = aff(node.value)
+                    defined.add(t.name)
+                    if a is not None:
+                        env[t.name] = a
+                    else:
+                        env.pop(t.name, None)
+                    return
+                walk(t.base, cond); walk(t.index, cond)
+                access(t, 1)
+                return
+            if isinstance(node, S.Cond):
+                walk(node.cond, cond); walk(node.then, True)
+                if node.els is not None:
+                    walk(node.els, True)
+                return
+            if isinstance(node, S.If):
+                walk(node.cond, cond); walk(node.then, True)
+                if node.els is not None:
+                    walk(node.els, True)
+                return
+            if isinstance(node, S.Binary):
+                walk(node.l, cond); walk(node.r, cond or node.op in ("&&", "||"))
+                return
+            if isinstance(node, S.Unary):
+                return walk(node.a, cond)
+            if isinstance(node, S.Seq):
+                for it in node.items:
+                    walk(it, cond)
+                return
+            if isinstance(node, S.Call):
+                for a in node.args:
+                    walk(a, cond)
+                return
+            ok[0] = False
+
+        for it in body:
+            walk(it, False)
+        if not ok[0] or not any(k == 1 for k, _ in accesses) or len(accesses) > 24:
+            return None
+        return ind, accesses
+
+    def _map_guard(self, plan, c, start):
+        """C++ that fills the access table of a planned map loop and asks za_map_ok whether its `c` trips are independent."""
+        ind, accesses = plan
+        rows = []
+        for kind, a in accesses:
+            if kind == 2:
+                b, m = a
+                base = " + ".join([c_double(b.const)] + [self.expr(t) for t in b.terms])
+                rows.append(f"{{ {base}, {self.expr(m)}, 0, 2 }}")
+                continue
+            a0 = " + ".join([c_double(a.const)] + [self.expr(t) for t in a.terms]
+                            + [f"{c_double(cf)} * {start[v]}" for v, cf in a.coef.items() if cf != 0.0])
+            sig = int(sum(cf * ind[v] for v, cf in a.coef.items()))
+            rows.append(f"{{ {a0}, 0.0, {sig}, {kind} }}")
+        tab = self.t("m")
+        return f"const ZaMapAcc {tab}[] = {{ {', '.join(rows)} }};", f"za_map_ok({tab}, {len(rows)}, {c})"
+
+    def _map_loop(self, plan, c, body_expr, last_value=None):
+        """The shared form of a planned map loop of `c` trips: lane r of the instance's R replica lanes runs trips r, r + R, ...
+        of the first c - 1 (really storing: za_st only stores from the primary lane otherwise), the lanes exchange what
+        those trips left behind (za_map_sync), and every lane runs the last trip, so that the script's temporaries, its
+        counters and the loop's value end as they would serially. Returns (prologue, guard expression, shared code)."""
+        ind, _ = plan
+        start = {v: self.t("i") for v in ind}
+        k, rp = self.t("k"), self.t("q")
+        seti = lambda kk: " ".join(f"{self.var_ref(v)} = {start[v]} + (double)({kk}) * {c_double(st)};" for v, st in ind.items())
+        table, okx = self._map_guard(plan, c, start)
+        pro = " ".join(f"const double {start[v]} = {self.var_ref(v)};" for v in ind) + " " + table
+        ints = " && ".join(f"za_coop_int({start[v]})" for v in ind)
+        shared = (f"const uint32_t {rp} = s.replica; s.replica = 0u; "
+                  f"for (int64_t {k} = s.rep_i; {k} < {c} - 1; {k} += s.rep_n) {{ {seti(k)} (void)({body_expr}); }} "
+                  f"s.replica = {rp}; za_map_sync(s); {seti(c + ' - 1')} "
+                  + (f"{last_value} = {body_expr};" if last_value else f"(void)({body_expr});"))
+        self.features.add("coop")
+        return pro, f"{ints} && {okx}", shared
+
     def e_Loop(self, n):
         c, l, i = self.t("n"), self.t("l"), self.t("k")
         count = self.expr(n.count)
@@ -513,6 +766,12 @@ class Emitter:
                         + " " + " ".join(f"{self.var_ref(a)} = {self.var_ref(a)} + {part[a]};" for a in accs)
                         + f" {{ " + " ".join(f"double {part[a]} = 0.0;" for a in accs) + f" {seti(c + ' - 1')} {l} = {body_r}; "
                         + " ".join(f"(void){part[a]};" for a in accs) + " } } else ")
+        if not coop and inner and hot and self.coop and not self.redirect and self._nodes(n.body) <= 400:
+            items = n.body.items if isinstance(n.body, S.Seq) else [n.body]
+            plan = self._map_plan(items, set(self.scope[-1]) if self.scope else set())
+            if plan:
+                pro, okx, shared = self._map_loop(plan, c, self.expr(n.body), last_value=l)
+                coop = f"if (ZA_COOP_ON(s) && {c} >= 2 * (int64_t)s.rep_n && ({{ {pro} bool z_ = {okx}; if (z_) {{ {shared} }} z_; }})) {{ }} else "
         body = self.expr(n.body)
         if (inner and hot and self.unroll and self.unrolled < self.UNROLL_MAX_LOOPS
                 and self._nodes(n.body) <= self.UNROLL_MAX_NODES):
