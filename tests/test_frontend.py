@@ -211,4 +211,4 @@ def test_accumulation_loop_recognition(body, expected):
     from zajit import codegen, program
     unit = codegen.make_unit(program.analyse("desc:t\n@sample\n" + body + "\n"))
     assert unit.code.count("ZA_COOP_ON(s)") == expected, unit.code
-    assert ("coop" in unit.features) == (expected > 0)
+    assert bool({"coop", "coopmap"} & set(unit.features)) == (expected > 0)

@@ -731,7 +731,9 @@ class Emitter:
                   f"for (int64_t {k} = s.rep_i; {k} < {c} - 1; {k} += s.rep_n) {{ {seti(k)} (void)({body_expr}); }} "
                   f"s.replica = {rp}; za_map_sync(s); {seti(c + ' - 1')} "
                   + (f"{last_value} = {body_expr};" if last_value else f"(void)({body_expr});"))
-        self.features.add("coop")
+        # ("coopmap", not "coop": a map loop uses replica lanes where a leaf has them -- FFT builtins or accumulation loops on its
+        #  audio path -- but is no reason to give a leaf thin wavefronts: NeuroCV x1024 went from 105 to 173 ms when it did)
+        self.features.add("coopmap")
         return pro, f"{ints} && {okx}", shared
 
     def e_Loop(self, n):
