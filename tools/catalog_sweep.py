@@ -27,9 +27,12 @@ def main() -> int:
     ap.add_argument("--frames", type=int, default=48000)
     ap.add_argument("--block", type=int, default=512)
     ap.add_argument("--out", default="")
+    ap.add_argument("--only", default="", help="comma-separated leaf names (default: every built leaf)")
     args = ap.parse_args()
     lib = ROOT / "zorakaudio-experimental-plugins_amd" / "lib"
     leaves = sorted(p.stem for p in lib.glob("*.json") if not p.stem.startswith("fx_"))
+    if args.only:
+        leaves = [x for x in leaves if x in set(args.only.split(","))]
     rows = []
     for leaf in leaves:
         meta = zabatch.leaf_meta(leaf)

@@ -106,6 +106,19 @@ struct ZfClickBeGone {
     base = env * c.base_a + st[S_BASE] * c.one_m_base_a;
     st[S_BASE] = base;
   }
+  // detect() with the inputs' product a * u already formed (the wave kernel forms it frame-parallel); the two channels'
+  // multiply and add are written as 2-vectors so that they issue as one packed instruction each (same IEEE operations)
+  ZF_FN static void detect_scaled(float* st, const Ctl& c, float vL, float vR, float& env, float& base) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 v = {vL, vR}, hp0 = {st[S_HPL], st[S_HPR]}, a2 = {c.a, c.a};
+    const f2 hp = v + a2 * hp0;
+    st[S_HPL] = hp.x; st[S_HPR] = hp.y;
+    const float ehf = zf_max(fabsf(hp.x), fabsf(hp.y));
+    env = zf_max(st[S_ENV] * c.env_rel, ehf);
+    st[S_ENV] = env;
+    base = env * c.base_a + st[S_BASE] * c.one_m_base_a;
+    st[S_BASE] = base;
+  }
   ZF_FN static float trigger(const Ctl& c, float env, float base, float e_norm) {                // :77,95 (feed-forward)
     const float ratio = env / (base + 1e-12f);
     return (float)((int)(ratio > c.ratio_thr) * (int)(e_norm > c.err_thr));

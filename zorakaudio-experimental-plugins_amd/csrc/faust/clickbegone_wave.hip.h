@@ -21,11 +21,14 @@
 template <int G>
 __global__ void __launch_bounds__(64) zf_cbg_wave(ZabBatch b, ZabAudio a) {
   using L = ZfClickBeGone;
+  // rows read or written by ONE lane over a chunk (the recursions) are 16-byte aligned when the wave serves one instance, so
+  // that lane moves four frames per LDS instruction; with G > 1 the odd row length keeps the G lanes on different banks
+  constexpr int RP = G == 1 ? 68 : 65;
   __shared__ float xs[G][2][96];        // [0..31]: the previous chunk's last 32 frames, [32..95]: this chunk
-  __shared__ float us[G][2][65];        // HPF input x - x@1
+  __shared__ __attribute__((aligned(16))) float us[G][2][RP];   // HPF input, already scaled: a * (x - x@1)
   __shared__ float pp[G][5][64];        // Pred fields per frame
-  __shared__ float eb[G][2][65];        // env, base per frame
-  __shared__ float th[G][65];           // trigger, then hold, per frame
+  __shared__ __attribute__((aligned(16))) float eb[G][2][RP];   // env, base per frame
+  __shared__ __attribute__((aligned(16))) float th[G][RP];      // trigger, then hold, per frame
   __shared__ L::Ctl ctls[G];
   const int lane = threadIdx.x;
   const int inst0 = blockIdx.x * G;
@@ -87,8 +90,8 @@ __global__ void __launch_bounds__(64) zf_cbg_wave(ZabBatch b, ZabAudio a) {
       const L::RowHist aL{&xs[g][0][32 + lane]}, aR{&xs[g][1][32 + lane]};
       const L::Pred q = L::predict(c, aL, aR);
       pp[g][0][lane] = q.xC_L; pp[g][1][lane] = q.xC_R; pp[g][2][lane] = q.pred_L; pp[g][3][lane] = q.pred_R; pp[g][4][lane] = q.e_norm;
-      us[g][0][lane] = aL(0) - aL(1);
-      us[g][1][lane] = aR(0) - aR(1);
+      us[g][0][lane] = c.a * (aL(0) - aL(1));          // (the recursion's first product, frame-parallel: same operands, same bits)
+      us[g][1][lane] = c.a * (aR(0) - aR(1));
     }
     zf_wave_sync();
     // ---- C: recursion 1, lane = instance -------------------------------------------------------------------------------
@@ -100,13 +103,13 @@ __global__ void __launch_bounds__(64) zf_cbg_wave(ZabBatch b, ZabAudio a) {
 #pragma unroll
         for (int n = 0; n < 64; ++n) {
           float env, base;
-          L::detect(st, myc, ul[n], ur[n], env, base);
+          L::detect_scaled(st, myc, ul[n], ur[n], env, base);
           eb[lane][0][n] = env; eb[lane][1][n] = base;
         }
       } else {
         for (int n = 0; n < tn; ++n) {
           float env, base;
-          L::detect(st, myc, us[lane][0][n], us[lane][1][n], env, base);
+          L::detect_scaled(st, myc, us[lane][0][n], us[lane][1][n], env, base);
           eb[lane][0][n] = env; eb[lane][1][n] = base;
         }
       }
