@@ -56,6 +56,7 @@ CASES = [
     ("fx_ringabort", "default", {}, 3000, 512),       # the write position skips every 1000 frames: those chunks go to the generic code
     ("fx_ringabort", "stride2", {0: 50000, 1: 1}, 1500, 500),     # never a unit step: the whole launch does
     ("fx_delaytaps", "far", {0: 90, 1: 24, 2: 80, 3: -6.0, 4: 100}, 3000, 500),
+    ("fx_mapkat", "default", {}, 1500, 500),          # elementwise loops / memcpy / memset shared by replica lanes (zajit/emit.py _map_plan)
     # random programs over the constructs the AOT lowering and the EEL2 VM agree on (tests/fixtures/make_fuzz.py)
     ("fx_fuzz0", "default", {0: 3.0}, 600, 128), ("fx_fuzz1", "default", {0: 7.5}, 600, 128),
     ("fx_fuzz2", "default", {0: 0.0}, 600, 128), ("fx_fuzz3", "default", {0: 10.0}, 600, 128),

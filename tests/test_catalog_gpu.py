@@ -321,6 +321,45 @@ def test_accumulation_loops_on_replica_lanes(ipw, monkeypatch):
         assert_state_close(names, v[i], p.vars(), what=f"coopkat vars[{i}] taps {rows[i][0]}")
 
 
+@pytest.mark.parametrize("ipw", ["auto", "1", "4", "16", "64"])
+def test_map_loops_on_replica_lanes(ipw, monkeypatch):
+    """tests/fixtures/mapkat.jsfx: every variant of the elementwise-loop form (zajit/emit.py _map_plan, zart.h za_map_ok) and the
+    shared memcpy / memset against the CPU port, which runs the same loops serially: independent trips (disjoint buffers, one
+    cell per trip, interleaved pairs, modulo loads, aliasing function arguments, downward and double counters) and trips that
+    depend on each other (overlapping shifts, which the guard must send to the serial form), lengths from fewer trips than
+    lanes to 400, at 64 ... 1 lanes per instance. Same operations per element: the arena must match to the state tolerance
+    (a trip run twice, skipped or out of order shows at the size of the data)."""
+    import zabatch
+    from oracle import port
+    from zajit import noise
+    if ipw != "auto":
+        monkeypatch.setenv("ZAB_IPW", ipw)
+        monkeypatch.setenv("ZAB_LMEM", "0")
+    else:
+        monkeypatch.delenv("ZAB_IPW", raising=False)
+    meta = zabatch.leaf_meta("fx_mapkat")
+    assert "coopmap" in meta["features"] and "coop" in meta["features"]
+    n, frames = 7, 700
+    rows = np.tile(np.array(meta["default_sliders"], dtype=np.float64), (n, 1))
+    rows[:, 0] = [1, 3, 8, 96, 129, 256, 400]
+    x = noise.white_noise(range(n), frames)
+    with zabatch.Engine("fx_mapkat", n) as e:
+        e.set_sliders(rows); e.prepare()
+        y = e.process_host(x, block=256)
+        v = e.read_vars(); names = e.var_names()
+        mem = e.read_mem(0, 4608)
+        high = e.mem_high()
+    for i in range(n):
+        p = port.Port("fx_mapkat", 48000.0)
+        p.set_sliders(rows[i]); p.prepare()
+        ref = p.process(x[i], 256)
+        bad = np.flatnonzero(np.abs(mem[i] - p.mem(0, 4608)) > SCALAR_EPS)       # (@init's sin / cos differ by an ulp between device and host)
+        assert bad.size == 0, (i, rows[i][0], bad[:8])
+        assert np.abs(y[i].astype(np.float64) - ref).max() <= AUDIO_EPS, (i, rows[i][0])
+        assert_state_close(names, v[i], p.vars(), what=f"mapkat vars[{i}] length {rows[i][0]}")
+        assert high[i] == p.mem_high, (i, high[i], p.mem_high)
+
+
 def test_script_originated_slider_changes_reach_the_host_mirror():
     """consumeDspSliderChanges / pushParamsToStateSliders (src/JSFXJuceProcessor.cpp:5665-5739, 9286-9357) through
     JsfxBatchProcessor: a slider the script sets and announces with sliderchange() becomes the host parameter and is not
