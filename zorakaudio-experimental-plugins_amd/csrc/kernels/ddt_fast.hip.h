@@ -765,11 +765,16 @@ extern "C" int zab_ddt_stamps(unsigned long long* out, int reset) {      // [16]
 #endif
 struct DdtPlan { uint64_t epoch; int dmax; bool ok; };
 static std::mutex ddt_mu;
-static std::map<const void*, DdtPlan> ddt_plans;
+// one plan per engine: keyed by device AND state pointer (device pointers of different GPUs can coincide: zab_group runs one
+// engine per GPU in one process) and valid for the engine's current epoch only (sliders / state uploads bump it)
+static std::map<std::pair<int, const void*>, DdtPlan> ddt_plans;
 
 static DdtPlan ddt_plan(const ZabBatch* b) {
   std::lock_guard<std::mutex> lk(ddt_mu);
-  auto it = ddt_plans.find(b->vars);
+  int dev = -1;
+  (void)hipGetDevice(&dev);
+  const auto key = std::make_pair(dev, (const void*)b->vars);
+  auto it = ddt_plans.find(key);
   if (it != ddt_plans.end() && it->second.epoch == b->epoch) return it->second;
   int zero[2] = {0, 0}, res[2] = {0, 1};
   DdtPlan p{b->epoch, 0, false};
@@ -777,7 +782,7 @@ static DdtPlan ddt_plan(const ZabBatch* b) {
     hipLaunchKernelGGL(zab_ddt_plan, dim3((b->n_inst + 255) / 256), dim3(256), 0, 0, *b);
     if (hipMemcpyFromSymbol(res, HIP_SYMBOL(ddt_plan_word), sizeof res) == hipSuccess) { p.dmax = res[0]; p.ok = !res[1]; }
   }
-  ddt_plans[b->vars] = p;
+  ddt_plans[key] = p;
   return p;
 }
 
