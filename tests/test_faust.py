@@ -19,6 +19,7 @@ NCH = {"RED": 6}
 # Bit-exact where the device keeps the restatement's operation order and rounds its libm calls the same way (f64, once): four
 # of the five leaves. GTS evaluates ~130 expf per sample whose device and host versions differ in the last bit: a few ulp.
 TOL = {"ClickBeGoneSG": 0.0, "ModTilt": 0.0, "GTS": 5e-7, "VAR": 0.0, "RED": 0.0}
+WAVE_SCAN_TOL = 1e-6       # ModTilt's wave kernel (measured 1.8e-7 = 3 ulp at unity); its lane-per-instance kernel stays at TOL
 
 
 def _input(leaf, ids, frames):
@@ -144,6 +145,8 @@ def test_gpu_matches_restatement(leaf, variant, monkeypatch):
         st = e.read_vars()
     y = np.concatenate([y1, y2], axis=2)
     tol = TOL[leaf]
+    if (leaf, variant) == ("ModTilt", "wave"):                # its five one-poles run as f32 wave scans: sums re-associated, no gates downstream
+        tol = WAVE_SCAN_TOL
     for i in (range(n) if leaf != "GTS" else range(0, n, 6)):     # (the GTS restatement costs ~130 expf per sample)
         r = fr.FaustRef(leaf, 48000)
         want = r.compute(x[i], rows[i, :8].astype(np.float32))
@@ -202,4 +205,4 @@ def test_mydsp_adapter_runs_the_leaf(key, tmp_path):
     assert r.returncode == 0 and not r.stderr, r.stderr
     y = np.frombuffer((tmp_path / "out.f32").read_bytes(), dtype=np.float32).reshape(NCH.get(key, 2), frames)
     want = fr.FaustRef(key, 48000).compute(x, np.array(zones, np.float32), block=block)
-    assert np.abs(y.astype(np.float64) - want).max() <= TOL[key]
+    assert np.abs(y.astype(np.float64) - want).max() <= (WAVE_SCAN_TOL if key == "ModTilt" else TOL[key])   # (the adapter takes the wave kernel)

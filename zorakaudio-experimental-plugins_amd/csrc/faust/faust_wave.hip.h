@@ -43,3 +43,41 @@ __device__ __forceinline__ void zf_serial64_rows(float (*rows)[64], int lane, in
   }
   zf_wave_sync();
 }
+
+// ---- constant-coefficient one-pole over the 64 frames of a chunk as a wave scan (f32) ---------------------------------------------
+// y[n] = u[n] + q * y[n-1] with lane = frame: a Kogge-Stone scan with DPP (row_shr 1/2/4/8, row_bcast15, row_bcast31) on the lane
+// values, weights q^(2^j) and two per-lane powers, then q^(lane+1) times the state carried into the chunk. The additions are
+// re-associated against the serial order (~1e-7 relative in f32), so it is only used where what follows is continuous in
+// the filter's output (no hard gates downstream): the tests hold such a kernel to a tolerance, not to the bits.
+struct ZfPoleScan {
+  float q1, q2, q4, q8;      // q^1, q^2, q^4, q^8            (uniform)
+  float cb1, cb2, pl;        // per lane: q^((l&15)+1), q^(l-31) (lanes >= 32, else unused), q^(l+1)
+};
+__device__ __forceinline__ ZfPoleScan zf_pole_scan_init(float q, int lane) {
+  auto ipow = [](double b, int e) { double r = 1.0; while (e) { if (e & 1) r *= b; b *= b; e >>= 1; } return r; };
+  ZfPoleScan w;
+  const double Q = (double)q;
+  w.q1 = q; w.q2 = (float)(Q * Q); w.q4 = (float)ipow(Q, 4); w.q8 = (float)ipow(Q, 8);
+  w.cb1 = (float)ipow(Q, (lane & 15) + 1);
+  w.cb2 = (float)ipow(Q, lane >= 32 ? lane - 31 : 0);
+  w.pl = (float)ipow(Q, lane + 1);
+  return w;
+}
+template <int CTRL, int ROWS>
+__device__ __forceinline__ float zf_dpp(float v) {       // lanes without a source (or masked out by ROWS) receive 0
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWS, 0xF, true));
+}
+// u = the lane's input term (already scaled), carry = the state before the chunk; returns y of every lane
+__device__ __forceinline__ float zf_pole_scan(const ZfPoleScan& w, float u, float carry) {
+  float g = u;
+  g = __builtin_fmaf(w.q1, zf_dpp<0x111, 0xF>(g), g);
+  g = __builtin_fmaf(w.q2, zf_dpp<0x112, 0xF>(g), g);
+  g = __builtin_fmaf(w.q4, zf_dpp<0x114, 0xF>(g), g);
+  g = __builtin_fmaf(w.q8, zf_dpp<0x118, 0xF>(g), g);
+  g = __builtin_fmaf(w.cb1, zf_dpp<0x142, 0xA>(g), g);
+  g = __builtin_fmaf(w.cb2, zf_dpp<0x143, 0xC>(g), g);
+  return __builtin_fmaf(w.pl, carry, g);
+}
+__device__ __forceinline__ float zf_readlane_f(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
