@@ -23,6 +23,10 @@ struct ZfGts {
 
 #define ZF_GTS_KERNEL_NAME "zf_gts_wave"
 
+__device__ __forceinline__ float zf_readlane_f32(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
 __global__ void __launch_bounds__(64) zf_gts_prepare(ZabBatch b) {      // dsp->init(): instanceClear
   const int inst = blockIdx.x;
   for (int k = threadIdx.x; k < ZfGts::NSTATE; k += 64) b.vars[k * b.var_se + inst * b.var_si] = 0.0;
@@ -33,6 +37,7 @@ __global__ void __launch_bounds__(64) zf_gts_wave(ZabBatch b, ZabAudio a) {
   using L = ZfGts;
   __shared__ float xs[2][L::HIST + 64];      // [0..255]: x@256..x@1 of the chunk's first frame, [256..319]: this chunk
   __shared__ float sm[5][64];                // smoothed parameters per frame
+  __shared__ float gsh[ZfGts::R + 1];        // the Gaussian taps of a chunk whose 64 frames share one sigma
   const int lane = threadIdx.x;
   const int inst = blockIdx.x;
   const float SR = zf_sr(b.srate);
@@ -73,10 +78,24 @@ __global__ void __launch_bounds__(64) zf_gts_wave(ZabBatch b, ZabAudio a) {
     const float sigmaMs = sm[0][lane], attackDB = sm[1][lane], sustainDB = sm[2][lane], mix = sm[3][lane], outGain = sm[4][lane];
     const float sigmaSamples = zf_max(0.25f, sigmaMs * SR * 0.001f);    // :69-70
     float g[L::R + 1];
+    // Once the sigma smoother has settled (f32: it stops moving after a few thousand frames) all 64 frames of a chunk have
+    // the same 129 taps: then each is computed once, by one lane, and read back by all (the same expf of the same argument,
+    // so the same bits as computing all of them in every lane) -- 129 exp per chunk instead of 129 per frame.
+    const bool same_sigma = __ballot(sigmaSamples != zf_readlane_f32(sigmaSamples, 0)) == 0ull;
+    if (same_sigma) {
+      for (int j = lane; j <= L::R; j += 64) {
+        const float q = (float)j / sigmaSamples;
+        gsh[j] = expf(-0.5f * (q * q));
+      }
+      zf_wave_sync();
 #pragma unroll
-    for (int j = 0; j <= L::R; ++j) {                                   // g(i) = exp(-0.5 * (i/sigma)^2)   (:27)
-      const float q = (float)j / sigmaSamples;
-      g[j] = expf(-0.5f * (q * q));
+      for (int j = 0; j <= L::R; ++j) g[j] = gsh[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j <= L::R; ++j) {                                 // g(i) = exp(-0.5 * (i/sigma)^2)   (:27)
+        const float q = (float)j / sigmaSamples;
+        g[j] = expf(-0.5f * (q * q));
+      }
     }
     float sumRest = g[1];                                               // :31
 #pragma unroll
