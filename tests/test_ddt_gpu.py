@@ -145,6 +145,48 @@ def test_multi_call_continuity_and_slider_change(monkeypatch):
             assert_state_close(names, v[i], p.vars(), what=f"vars[{i}] path {path}")
 
 
+def test_long_launches_pick_the_filtered_ring_kernel_and_match_the_port():
+    """Unpinned: a 100 000-frame launch goes to zab_ddt_fast (>= 96 000 frames), a 5 000-frame one to zab_ddt_wide. Random slider rows
+    per instance (distances, sizes, tap densities, monitor modes), a slider move between two long launches (the a^n K term
+    carries a real state into changed taps), then a short launch: audio and every var against the CPU port."""
+    import zabatch
+    from oracle import port
+    from zajit import noise, sliders as zs
+    meta = zabatch.leaf_meta("DDT")
+    rng = np.random.default_rng(20261004)
+    n, f1, f2, f3 = 6, 100_000, 96_000, 5_000
+    rows = np.tile(np.array(meta["default_sliders"]), (n, 1))
+    rows2 = rows.copy()
+    for r in (rows, rows2):
+        r[:, 0] = rng.uniform(0, 100, n); r[:, 1] = rng.uniform(0, 100, n); r[:, 2] = rng.uniform(0, 100, n)
+        r[:, 3] = rng.uniform(0, 100, n); r[:, 4] = rng.integers(0, 5, n); r[:, 8] = rng.uniform(0, 100, n)
+    rows[:, 7] = [0, 1, 2, 3, 0, 0]; rows2[:, 7] = rows[:, 7]
+    x = noise.white_noise(range(300, 300 + n), f1 + f2 + f3)
+    with zabatch.Engine("DDT", n) as e:
+        e.set_sliders(rows); e.prepare()
+        ys = [e.process_host(x[:, :, :f1], block=512)]
+        k1 = e.last_kernel_name()
+        e.set_sliders(rows2)
+        ys.append(e.process_host(x[:, :, f1:f1 + f2], block=512))
+        k2 = e.last_kernel_name()
+        ys.append(e.process_host(x[:, :, f1 + f2:], block=512))
+        k3 = e.last_kernel_name()
+        v = e.read_vars(); names = e.var_names()
+    assert k1.startswith("zab_ddt_fast") and k2.startswith("zab_ddt_fast") and k3.startswith("zab_ddt_wide"), (k1, k2, k3)
+    y = np.concatenate(ys, axis=2)
+    for i in range(n):
+        p = port.Port("DDT", 48000.0)
+        p.set_sliders(rows[i]); p.prepare()
+        r = [p.process(x[i, :, :f1], 512)]
+        p.set_sliders(rows2[i]); p.run_slider()
+        r.append(p.process(x[i, :, f1:f1 + f2], 512))
+        r.append(p.process(x[i, :, f1 + f2:], 512))
+        ref = np.concatenate(r, axis=1)
+        err = np.abs(y[i].astype(np.float64) - ref).max()
+        assert err <= AUDIO_EPS, (i, err)
+        assert_state_close(names, v[i], p.vars(), what=f"vars[{i}]")
+
+
 def test_device_resident_buffers_and_noise_generator():
     import zabatch
     from zajit import noise
