@@ -21,7 +21,7 @@ SRC = '''
 #include "%s"
 extern "C" int map_ok(const double* a0, const double* ext, const int* sig, const int* kind, int n, long long c) {
   ZaMapAcc A[24];
-  for (int i = 0; i < n; ++i) { A[i].a0 = a0[i]; A[i].ext = ext[i]; A[i].sig = sig[i]; A[i].kind = kind[i]; }
+  for (int i = 0; i < n; ++i) { A[i].a0 = a0[i]; A[i].ext = ext[i]; A[i].sig = sig[i]; A[i].kind = kind[i]; A[i].ord = i; }
   return za_map_ok(A, n, c) ? 1 : 0;
 }
 extern "C" long long map_trips(double bound, double v, double step) { return za_map_trips(bound, v, step); }
@@ -54,8 +54,9 @@ def ok(L, rows, c):
 def test_rules(lib):
     c = 100
     assert ok(lib, [(0, 1, 0), (1000, 1, 1)], c)                      # disjoint buffers
-    assert ok(lib, [(50, 1, 0), (50, 1, 1)], c)                       # dest[i] op= dest[i]: one cell per trip
-    assert ok(lib, [(0, 2, 1), (1, 2, 1), (0, 2, 0), (1, 2, 0)], c)   # re / im interleave through idx = 2 k
+    assert ok(lib, [(50, 1, 0), (50, 1, 1)], c)                       # dest[i] op= dest[i]: one cell per trip, read then written
+    assert not ok(lib, [(50, 1, 1), (50, 1, 0)], c)                   # written then read back inside the trip (stores are deferred)
+    assert ok(lib, [(0, 2, 0), (0, 2, 1), (1, 2, 0), (1, 2, 1)], c)   # re / im interleave through idx = 2 k: buf[idx] *= g; buf[idx + 1] *= -g
     assert not ok(lib, [(0, 1, 0), (1, 1, 1)], c)                     # a[i + 1] = f(a[i]): each trip reads its neighbour's store
     assert not ok(lib, [(1, 1, 0), (0, 1, 1)], c)                     # a[i] = f(a[i + 1])
     assert ok(lib, [(0, 1, 0), (100, 1, 1)], c)                       # shift by the whole length: the ranges just miss
@@ -98,6 +99,8 @@ def test_accepted_tables_have_no_cross_trip_conflict(lib):
                     touched.append((k, r[0] + r[1] * k, r[2] == 1))
         for (k1, a1, s1), (k2, a2, s2) in itertools.combinations(touched, 2):
             assert not (k1 != k2 and a1 == a2 and (s1 or s2)), (rows, c, (k1, a1, s1), (k2, a2, s2))
+            # inside one trip (list order = program order): no load of a cell after a store to it
+            assert not (k1 == k2 and a1 == a2 and s1 and not s2), (rows, c, (k1, a1, s1), (k2, a2, s2))
     assert accepted > 200
 
 

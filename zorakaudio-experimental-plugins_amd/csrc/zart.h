@@ -175,7 +175,7 @@ ZA_FN double za_coop_sum(S& s, double x) { (void)s; return x; }
 
 // Elementwise ("map") loops shared by the replica lanes of an instance (zajit/emit.py _map_plan): one row per arena access of
 // a trip. kind 0 load / 1 store at a0 + sig * trip; kind 2 a load somewhere in [a0, a0 + ext).
-struct ZaMapAcc { double a0, ext; int32_t sig, kind; };
+struct ZaMapAcc { double a0, ext; int32_t sig, kind, ord; };   // ord: position of the access within a trip
 // Are the c trips independent -- no store of one trip at an address another trip touches? Conservative: a store and another
 // access either never meet (disjoint address ranges), or walk in step and meet only inside one trip (same stride, first
 // addresses equal) or never (first addresses differ by less than a multiple of the stride: re / im interleave).
@@ -201,7 +201,10 @@ ZA_FN bool za_map_ok(const ZaMapAcc* A, int n, int64_t c) {
       if (hi[j] < lo[k] || hi[k] < lo[j]) continue;          // never meet
       if (A[k].kind == 2 || A[k].sig != A[j].sig) return false;
       const double d = A[k].a0 - A[j].a0;
-      if (d == 0.0) continue;                                // the same cell, in the same trip only
+      if (d == 0.0) {                                        // the same cell, in the same trip only
+        if (A[k].kind == 0 && A[k].ord > A[j].ord) return false;   // ... read back after the store
+        continue;
+      }
       if (fmod(d, (double)A[j].sig) != 0.0) continue;        // interleaved, never the same cell
       return false;
     }
@@ -349,7 +352,22 @@ ZA_FN double za_memcpy(S& s, double destD, double srcD, double lenD) {
                        if (ZA_LM_HIT(s, d + (i))) ZA_LM_REF(s, d + (i)) = x_; else s.mem[(d + (i)) * st] = x_; } while (0)
 #if defined(__HIPCC__)
   if (ZA_COOP_ON(s) && n >= 2 * (int64_t)s.rep_n && (d + n <= r || r + n <= d)) {   // disjoint: the replica lanes share the range
-    for (int64_t i = s.rep_i; i < n; i += s.rep_n) ZA_CP1(i);
+    // eight loads in flight per lane before their stores (the compiler must assume a store aliases the next load and would
+    // pay one memory latency per element)
+    const int64_t R = s.rep_n;
+    for (int64_t i0 = s.rep_i; i0 < n; i0 += 8 * R) {
+      double v_[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t i = i0 + u * R, ic = i < n ? i : i0;
+        v_[u] = ZA_LM_HIT(s, r + ic) ? ZA_LM_REF(s, r + ic) : s.mem[(r + ic) * st];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t i = i0 + u * R;
+        if (i < n) { if (ZA_LM_HIT(s, d + i)) ZA_LM_REF(s, d + i) = v_[u]; else s.mem[(d + i) * st] = v_[u]; }
+      }
+    }
     za_map_sync(s);
     return 0.0;
   }

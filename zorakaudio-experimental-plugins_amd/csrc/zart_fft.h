@@ -234,12 +234,25 @@ __device__ __noinline__ bool za_fft_coop(S& s, bool ok, int64_t base, int n, int
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       }
-      for (int i = rank; i < nl; i += nact) {
-        const double ar = ZA_G(2 * i), ai = ZA_G(2 * i + 1);
-        const double br = overlap ? fp[(int64_t)(2 * i) * fs] : mp[(rl + 2 * i) * ms];
-        const double bi = overlap ? fp[(int64_t)(2 * i + 1) * fs] : mp[(rl + 2 * i + 1) * ms];
-        ZA_G(2 * i) = ar * br - ai * bi;
-        ZA_G(2 * i + 1) = ar * bi + ai * br;
+      // four pairs per lane and trip, all their loads before the first store (the compiler must assume the stores alias the
+      // next loads: one memory latency per pair otherwise)
+      for (int i0 = rank; i0 < nl; i0 += 4 * nact) {
+        double ar[4], ai[4], br[4], bi[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * nact < nl ? i0 + u * nact : i0;
+          ar[u] = ZA_G(2 * i); ai[u] = ZA_G(2 * i + 1);
+          br[u] = overlap ? fp[(int64_t)(2 * i) * fs] : mp[(rl + 2 * i) * ms];
+          bi[u] = overlap ? fp[(int64_t)(2 * i + 1) * fs] : mp[(rl + 2 * i + 1) * ms];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * nact;
+          if (i < nl) {
+            ZA_G(2 * i) = ar[u] * br[u] - ai[u] * bi[u];
+            ZA_G(2 * i + 1) = ar[u] * bi[u] + ai[u] * br[u];
+          }
+        }
       }
       __builtin_amdgcn_wave_barrier();
       continue;

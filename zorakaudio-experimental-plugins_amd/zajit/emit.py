@@ -85,6 +85,7 @@ class Emitter:
         self.cur_sec = "sample"
         self.redirect: Dict[str, str] = {}
         self.coop = not os.environ.get("ZA_NO_COOP")
+        self.defer = None                          # map loops: arena stores of the trip being emitted go to named slots (_map_loop)
         self._fn_nodes: Dict[str, int] = {}
         self.tmp = 0
         self.strings: List[str] = []
@@ -287,10 +288,14 @@ class Emitter:
             r, a = self.t("r"), self.t("a")
             pre, (b, i) = self.ordered([tgt.base, tgt.index])
             addr = f"{pre} int64_t {a} = za_addr({b}, {i});"
-            if bop is None:
-                self.features.add("mem")
-                return f"({{ double {r} = {rhs}; {addr} za_st(s, {a}, {r}); }})"
             self.features.add("mem")
+            if self.defer is not None:             # a trip of a shared map loop: the store is made after the group's loads
+                da, dv, do = self.t("da"), self.t("dv"), self.t("do")
+                self.defer.append((da, dv, do))
+                val = r if bop is None else self.binop(bop, f"za_ld(s, {a})", r)
+                return f"({{ double {r} = {rhs}; {addr} {dv} = {val}; {da} = {a}; {do} = true; {dv}; }})"
+            if bop is None:
+                return f"({{ double {r} = {rhs}; {addr} za_st(s, {a}, {r}); }})"
             return f"({{ double {r} = {rhs}; {addr} za_st(s, {a}, {self.binop(bop, f'za_ld(s, {a})', r)}); }})"
         if isinstance(tgt, S.Call) and tgt.fn in ("slider", "spl") and len(tgt.args) == 1:
             arr, off = self._dyn(tgt.fn)
@@ -393,8 +398,7 @@ class Emitter:
             if isinstance(x, (S.Index, S.Assign, S.Call, S.Cond)) or (isinstance(x, S.Var) and x.name in written):
                 return None
         c, w = self.t("n"), self.t("w")
-        body = self.expr(n.body)
-        pro, okx, shared = self._map_loop(plan, c, body)
+        pro, okx, shared = self._map_loop(plan, c, n.body)
         serial = (f"{{ int64_t {w} = 0; while (za_truthy({self.expr(n.cond)})) {{ {self.stmt(n.body)} "
                   f"if (++{w} >= ZA_LOOP_CAP) {{ s.err |= ZA_ERR_LOOP_CAP; break; }} }} }}")
         count = f"za_map_trips({self.expr(cd.r)}, {self.var_ref(v)}, {c_double(ind[v])})"
@@ -619,7 +623,7 @@ class Emitter:
         def access(node, kind):
             a = aff(S.Binary("+", node.base, node.index))
             if a is not None:
-                accesses.append((kind, a))
+                accesses.append((kind, a))           # (list order = order within the trip)
                 return
             # base[(affine) % M] with M invariant: a load somewhere in [base, base + M)
             ix = node.index
@@ -665,6 +669,8 @@ class Emitter:
                         env.pop(t.name, None)
                     return
                 walk(t.base, cond); walk(t.index, cond)
+                if node.op != "=":
+                    access(t, 0)                     # a compound store reads its cell first
                 access(t, 1)
                 return
             if isinstance(node, S.Cond):
@@ -706,29 +712,41 @@ class Emitter:
             if kind == 2:
                 b, m = a
                 base = " + ".join([c_double(b.const)] + [self.expr(t) for t in b.terms])
-                rows.append(f"{{ {base}, {self.expr(m)}, 0, 2 }}")
+                rows.append(f"{{ {base}, {self.expr(m)}, 0, 2, {len(rows)} }}")
                 continue
             a0 = " + ".join([c_double(a.const)] + [self.expr(t) for t in a.terms]
                             + [f"{c_double(cf)} * {start[v]}" for v, cf in a.coef.items() if cf != 0.0])
             sig = int(sum(cf * ind[v] for v, cf in a.coef.items()))
-            rows.append(f"{{ {a0}, 0.0, {sig}, {kind} }}")
+            rows.append(f"{{ {a0}, 0.0, {sig}, {kind}, {len(rows)} }}")
         tab = self.t("m")
         return f"const ZaMapAcc {tab}[] = {{ {', '.join(rows)} }};", f"za_map_ok({tab}, {len(rows)}, {c})"
 
-    def _map_loop(self, plan, c, body_expr, last_value=None):
+    MAP_GROUP = 4
+
+    def _map_loop(self, plan, c, body_node, last_value=None):
         """The shared form of a planned map loop of `c` trips: lane r of the instance's R replica lanes runs trips r, r + R, ...
         of the first c - 1 (really storing: za_st only stores from the primary lane otherwise), the lanes exchange what
         those trips left behind (za_map_sync), and every lane runs the last trip, so that the script's temporaries, its
-        counters and the loop's value end as they would serially. Returns (prologue, guard expression, shared code)."""
+        counters and the loop's value end as they would serially. A lane's trips run in groups of MAP_GROUP whose arena stores
+        are made after the whole group's loads: the device compiler must assume that a store aliases the next trip's loads, so
+        trip by trip every trip would wait a full memory latency (the guard refuses a trip that reads back what it stored).
+        Returns (prologue, guard expression, shared code)."""
         ind, _ = plan
         start = {v: self.t("i") for v in ind}
-        k, rp = self.t("k"), self.t("q")
+        k, rp, G = self.t("k"), self.t("q"), self.MAP_GROUP
         seti = lambda kk: " ".join(f"{self.var_ref(v)} = {start[v]} + (double)({kk}) * {c_double(st)};" for v, st in ind.items())
         table, okx = self._map_guard(plan, c, start)
         pro = " ".join(f"const double {start[v]} = {self.var_ref(v)};" for v in ind) + " " + table
         ints = " && ".join(f"za_coop_int({start[v]})" for v in ind)
-        shared = (f"const uint32_t {rp} = s.replica; s.replica = 0u; "
-                  f"for (int64_t {k} = s.rep_i; {k} < {c} - 1; {k} += s.rep_n) {{ {seti(k)} (void)({body_expr}); }} "
+        self.defer = []
+        trips = [f"{{ {seti(f'{k} + {u} * (int64_t)s.rep_n')} (void)({self.expr(body_node)}); }}" for u in range(G)]
+        slots, self.defer = self.defer, None
+        decl = " ".join(f"int64_t {a} = 0; double {v} = 0.0; bool {o} = false;" for a, v, o in slots)
+        flush = " ".join(f"if ({o}) za_st(s, {a}, {v});" for a, v, o in slots)
+        body_expr = self.expr(body_node)
+        shared = (f"const uint32_t {rp} = s.replica; s.replica = 0u; int64_t {k} = s.rep_i; "
+                  f"for (; {k} + {G - 1} * (int64_t)s.rep_n < {c} - 1; {k} += {G} * (int64_t)s.rep_n) {{ {decl} {' '.join(trips)} {flush} }} "
+                  f"for (; {k} < {c} - 1; {k} += s.rep_n) {{ {seti(k)} (void)({body_expr}); }} "
                   f"s.replica = {rp}; za_map_sync(s); {seti(c + ' - 1')} "
                   + (f"{last_value} = {body_expr};" if last_value else f"(void)({body_expr});"))
         # ("coopmap", not "coop": a map loop uses replica lanes where a leaf has them -- FFT builtins or accumulation loops on its
@@ -772,7 +790,7 @@ class Emitter:
             items = n.body.items if isinstance(n.body, S.Seq) else [n.body]
             plan = self._map_plan(items, set(self.scope[-1]) if self.scope else set())
             if plan:
-                pro, okx, shared = self._map_loop(plan, c, self.expr(n.body), last_value=l)
+                pro, okx, shared = self._map_loop(plan, c, n.body, last_value=l)
                 coop = f"if (ZA_COOP_ON(s) && {c} >= 2 * (int64_t)s.rep_n && ({{ {pro} bool z_ = {okx}; if (z_) {{ {shared} }} z_; }})) {{ }} else "
         body = self.expr(n.body)
         if (inner and hot and self.unroll and self.unrolled < self.UNROLL_MAX_LOOPS
