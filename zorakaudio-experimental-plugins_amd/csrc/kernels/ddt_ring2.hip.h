@@ -22,7 +22,7 @@
 // (not doubled) with W a multiple of 8 and a copy of their first chunk behind the end; a tap's wrap is scalar arithmetic.
 // Registers: the chunk loop is split by what a chunk needs (history / first / plain / metered), launch constants that only
 // one of them uses live in LDS (D2Uni), and the last frame's @sample temporaries are rebuilt after the loop from six
-// stashed values -- so the plain loop fits the register budget of three waves per SIMD.
+// stashed values: 194 VGPRs, no scratch (two waves per SIMD; three were measured and did not pay).
 // Differences from the serial order are re-association of linear terms (~1e-16 relative): tests/test_ddt_gpu.py.
 #pragma once
 
