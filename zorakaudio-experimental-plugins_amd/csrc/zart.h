@@ -351,20 +351,27 @@ ZA_FN double za_memcpy(S& s, double destD, double srcD, double lenD) {
 #define ZA_CP1(i) do { const double x_ = ZA_LM_HIT(s, r + (i)) ? ZA_LM_REF(s, r + (i)) : s.mem[(r + (i)) * st];                    \
                        if (ZA_LM_HIT(s, d + (i))) ZA_LM_REF(s, d + (i)) = x_; else s.mem[(d + (i)) * st] = x_; } while (0)
 #if defined(__HIPCC__)
-  if (ZA_COOP_ON(s) && n >= 2 * (int64_t)s.rep_n && (d + n <= r || r + n <= d)) {   // disjoint: the replica lanes share the range
-    // eight loads in flight per lane before their stores (the compiler must assume a store aliases the next load and would
-    // pay one memory latency per element)
-    const int64_t R = s.rep_n;
-    for (int64_t i0 = s.rep_i; i0 < n; i0 += 8 * R) {
+  if (ZA_COOP_ON(s) && n >= 2 * (int64_t)s.rep_n && d != r) {
+    // The replica lanes share the range, eight elements per lane and batch, ALL of a batch's loads before its stores (they
+    // are one wave: the stores wait for every lane's loads). That is also what makes overlapping ranges safe: moving down
+    // (d < r) the batches ascend, so a cell is always read by the batch that owns it or an earlier one before the batch
+    // that overwrites it stores -- the serial memmove order; moving up (d > r) they descend. (Trip by trip the device
+    // compiler must assume that a store aliases the next load and pays a memory latency per element: an STFT's
+    // `memcpy(ola, ola + HOP, N - HOP)` was most of its time.)
+    const int64_t R = s.rep_n, B = 8 * R, nb = (n + B - 1) / B;
+    for (int64_t q = 0; q < nb; ++q) {
+      const int64_t b0 = (d < r ? q : nb - 1 - q) * B + s.rep_i;
       double v_[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int64_t i = i0 + u * R, ic = i < n ? i : i0;
+        const int64_t i = b0 + u * R, ic = i < n ? i : 0;
         v_[u] = ZA_LM_HIT(s, r + ic) ? ZA_LM_REF(s, r + ic) : s.mem[(r + ic) * st];
       }
+      // (every load of the batch has returned before its first store is issued -- not just each store's own)
+      asm volatile("" : "+v"(v_[0]), "+v"(v_[1]), "+v"(v_[2]), "+v"(v_[3]), "+v"(v_[4]), "+v"(v_[5]), "+v"(v_[6]), "+v"(v_[7]));
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int64_t i = i0 + u * R;
+        const int64_t i = b0 + u * R;
         if (i < n) { if (ZA_LM_HIT(s, d + i)) ZA_LM_REF(s, d + i) = v_[u]; else s.mem[(d + i) * st] = v_[u]; }
       }
     }
