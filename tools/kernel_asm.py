@@ -6,7 +6,7 @@ from pathlib import Path
 leaf, kern, out = sys.argv[1], sys.argv[2], sys.argv[3]
 # (Faust leaves: their kernels are templates, so `kern` is matched as a substring of the mangled name)
 from zajit import faust
-l = build.discover(Path('/root/reference/plugins'))
+l = build.discover(Path("/root/reference/plugins")); l.update({p.stem if p.stem[:3] == "fx_" else "fx_" + p.stem: {"entry": p} for p in (Path(__file__).resolve().parent.parent / "tests/fixtures").glob("*.jsfx")})
 if leaf in faust.FAUST_LEAVES:
     faust.build_faust_module(l[leaf]['entry'], leaf, force=True)
 else:

@@ -54,12 +54,17 @@ struct ZaPoolView;   // zart_pool.h
 struct ZaFileView;   // zart_file.h
 struct ZaBusView;    // zart_msg.h
 
-template <int NV, bool LM = false>
-struct ZaState {
+// The state of one instance while a section runs is split in two. ZaEnv is everything the runtime's out-of-line builtins (FFT,
+// rand refill, msg_*, gmem block moves, file_*, pool export) may touch; ZaState adds the script's own variables, sliders and
+// sample registers. An out-of-line builtin is entered through an inline stub (ZA_OUTCALL below) that hands it a COPY of the
+// ZaEnv part and copies it back afterwards, so the address of the ZaState object itself never leaves the kernel: on the device
+// that is what lets the compiler keep v[] / spl[] / sl[] in registers. (With `S& s` passed to one real call anywhere in a
+// kernel, the whole object lives in scratch memory for the whole kernel and every variable access of the per-sample code is
+// a scratch round trip: ~0.8 us per frame measured on an FFT leaf's otherwise empty @sample, tools/ring_io.py.)
+template <bool LM>
+struct ZaEnv {
+  using Env = ZaEnv<LM>;
   static constexpr bool kLm = LM;   // this instantiation routes mem[0, lm_words) to LDS (device process kernel only)
-  double v[NV];
-  double sl[64];
-  double spl[64];
   double srate, samplesblock, midi_bus, ext_midi_bus;
   double* mem;           // element a lives at mem[a * mem_stride]
   int64_t mem_stride;
@@ -94,6 +99,17 @@ struct ZaState {
   uint32_t lm_stride;    // word a of this lane at za_lmem[a * lm_stride + lm_off]
   uint32_t lm_off;
 };
+
+template <int NV, bool LM = false>
+struct ZaState : ZaEnv<LM> {
+  double v[NV];
+  double sl[64];
+  double spl[64];
+};
+
+// body of an inline stub around an out-of-line builtin `call` (which names the environment copy `e`)
+#define ZA_OUTCALL(call) typename S::Env e = s; auto r_ = (call); static_cast<typename S::Env&>(s) = e; return r_
+#define ZA_OUTCALL_VOID(call) typename S::Env e = s; (call); static_cast<typename S::Env&>(s) = e
 
 // ---------------------------------------------------------------------------------------------
 // scalars
@@ -388,30 +404,29 @@ ZA_FN double za_memcpy(S& s, double destD, double srcD, double lenD) {
 // ---------------------------------------------------------------------------------------------
 // rand()
 // ---------------------------------------------------------------------------------------------
-template <class S>
-ZA_NOINLINE uint32_t za_mt_next(S& s) {
+// The seeding / 624-word refill is the out-of-line part (by value: no state object behind it); the draw itself is inline.
+inline ZA_NOINLINE void za_mt_refill(uint32_t* mt, int64_t st, uint32_t i) {
   const int N = 624, M = 397;
-  uint32_t* mt = s.mt;
-  const int64_t st = s.mt_stride;
-  uint32_t i = s.mti;
   if (i == 0) {
     uint32_t prev = 0x4141F00Du;
     mt[0] = prev;
     for (int k = 1; k < N; ++k) { prev = 1812433253u * (prev ^ (prev >> 30)) + (uint32_t)k; mt[k * st] = prev; }
-    i = N;
   }
-  if (i >= (uint32_t)N) {
-    for (int k = 0; k < N; ++k) {
-      uint32_t a = mt[k * st], b = mt[((k + 1) % N) * st];
-      uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
-      mt[k * st] = mt[((k + M) % N) * st] ^ (y >> 1) ^ ((y & 1u) ? 0x9908B0DFu : 0u);
-    }
-    s.mti = 1;
+  for (int k = 0; k < N; ++k) {
+    uint32_t a = mt[k * st], b = mt[((k + 1) % N) * st];
+    uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+    mt[k * st] = mt[((k + M) % N) * st] ^ (y >> 1) ^ ((y & 1u) ? 0x9908B0DFu : 0u);
+  }
+}
+template <class S>
+ZA_FN uint32_t za_mt_next(S& s) {
+  uint32_t i = s.mti;
+  if (i == 0 || i >= 624u) {
+    za_mt_refill(s.mt, s.mt_stride, i);
     i = 0;
-  } else {
-    s.mti = i + 1;
   }
-  uint32_t y = mt[i * st];
+  s.mti = i + 1;
+  uint32_t y = s.mt[i * s.mt_stride];
   y ^= y >> 11;
   y ^= (y << 7) & 0x9D2C5680u;
   y ^= (y << 15) & 0xEFC60000u;

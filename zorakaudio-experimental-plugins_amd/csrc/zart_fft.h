@@ -518,7 +518,7 @@ ZA_FN void za_fft_inv_core(S& s, int64_t base, int n) {
   for (int i = 0; i < 2 * n; ++i) ZA_M(base + i) = ZA_F(i);
 }
 
-template <class S> ZA_NOINLINE double za_fft(S& s, double baseD, double sizeD) {
+template <class S> ZA_NOINLINE double za_fft_o(S& s, double baseD, double sizeD) {
   const int64_t n = za_round_idx(sizeD);
   int64_t base = 0;
   const bool ok = za_fft_pow2(n) && za_fft_region(s, baseD, 2 * n, base, 2 * n);
@@ -527,7 +527,7 @@ template <class S> ZA_NOINLINE double za_fft(S& s, double baseD, double sizeD) {
   za_fft_fwd_core(s, base, (int)n);
   return 0.0;
 }
-template <class S> ZA_NOINLINE double za_ifft(S& s, double baseD, double sizeD) {
+template <class S> ZA_NOINLINE double za_ifft_o(S& s, double baseD, double sizeD) {
   const int64_t n = za_round_idx(sizeD);
   int64_t base = 0;
   const bool ok = za_fft_pow2(n) && za_fft_region(s, baseD, 2 * n, base, 2 * n);
@@ -536,31 +536,31 @@ template <class S> ZA_NOINLINE double za_ifft(S& s, double baseD, double sizeD) 
   za_fft_inv_core(s, base, (int)n);
   return 0.0;
 }
-template <class S> ZA_NOINLINE double za_fft_permute(S& s, double baseD, double sizeD);
-template <class S> ZA_NOINLINE double za_fft_ipermute(S& s, double baseD, double sizeD);
+template <class S> ZA_NOINLINE double za_fft_permute_o(S& s, double baseD, double sizeD);
+template <class S> ZA_NOINLINE double za_fft_ipermute_o(S& s, double baseD, double sizeD);
 // fft(b, n); fft_permute(b, n) and fft_ipermute(b, n); ifft(b, n) with identical arguments, fused by the translator (zajit/emit.py
 // e_Seq): the permutations are exact moves, so a natural-order transform gives the same bits with one pass over the buffer
 // fewer. The serial form (CPU port; device beyond the cooperative sizes) simply runs the two builtins.
-template <class S> ZA_NOINLINE double za_fft_nat(S& s, double baseD, double sizeD) {
+template <class S> ZA_NOINLINE double za_fft_nat_o(S& s, double baseD, double sizeD) {
   const int64_t n = za_round_idx(sizeD);
   int64_t base = 0;
   const bool ok = za_fft_pow2(n) && za_fft_region(s, baseD, 2 * n, base, 2 * n);
   ZA_FFT_TRY_COOP(ZA_COOP_FFT_NAT);
   if (!ok) return 0.0;
   za_fft_fwd_core(s, base, (int)n);
-  return za_fft_permute(s, baseD, sizeD);
+  return za_fft_permute_o(s, baseD, sizeD);
 }
-template <class S> ZA_NOINLINE double za_ifft_nat(S& s, double baseD, double sizeD) {
+template <class S> ZA_NOINLINE double za_ifft_nat_o(S& s, double baseD, double sizeD) {
   const int64_t n = za_round_idx(sizeD);
   int64_t base = 0;
   const bool ok = za_fft_pow2(n) && za_fft_region(s, baseD, 2 * n, base, 2 * n);
   ZA_FFT_TRY_COOP(ZA_COOP_IFFT_NAT);
   if (!ok) return 0.0;
-  za_fft_ipermute(s, baseD, sizeD);
+  za_fft_ipermute_o(s, baseD, sizeD);
   za_fft_inv_core(s, base, (int)n);
   return 0.0;
 }
-template <class S> ZA_NOINLINE double za_fft_permute(S& s, double baseD, double sizeD) {   // WDL order -> natural
+template <class S> ZA_NOINLINE double za_fft_permute_o(S& s, double baseD, double sizeD) {   // WDL order -> natural
   const int64_t n = za_round_idx(sizeD);
   int64_t base = 0;
   const bool ok = za_fft_pow2(n) && za_fft_region(s, baseD, 2 * n, base, 2 * n);
@@ -574,7 +574,7 @@ template <class S> ZA_NOINLINE double za_fft_permute(S& s, double baseD, double 
   for (int i = 0; i < 2 * (int)n; ++i) ZA_M(base + i) = ZA_F(i);
   return 0.0;
 }
-template <class S> ZA_NOINLINE double za_fft_ipermute(S& s, double baseD, double sizeD) {  // natural -> WDL order
+template <class S> ZA_NOINLINE double za_fft_ipermute_o(S& s, double baseD, double sizeD) {  // natural -> WDL order
   const int64_t n = za_round_idx(sizeD);
   int64_t base = 0;
   const bool ok = za_fft_pow2(n) && za_fft_region(s, baseD, 2 * n, base, 2 * n);
@@ -593,7 +593,7 @@ template <class S> ZA_NOINLINE double za_fft_ipermute(S& s, double baseD, double
 //   forward:  Z = FFT_{N/2}(z) (natural bins), X[k] = 0.5*(Z[k] + conj Z[h-k]) - 0.5i e^{-2 pi i k/N} (Z[k] - conj Z[h-k]),
 //             stored 2*X[k] at position perm_h(k); position 0 holds (2*X[0], 2*X[N/2]).
 //   inverse:  the exact reverse, then an unscaled inverse FFT_{N/2}.
-template <class S> ZA_NOINLINE double za_fft_real(S& s, double baseD, double sizeD) {
+template <class S> ZA_NOINLINE double za_fft_real_o(S& s, double baseD, double sizeD) {
   const int64_t n = za_round_idx(sizeD);
   int64_t base = 0;
   const bool ok = za_fft_pow2(n) && za_fft_region(s, baseD, n, base, 2 * n);
@@ -627,7 +627,7 @@ template <class S> ZA_NOINLINE double za_fft_real(S& s, double baseD, double siz
   }
   return 0.0;
 }
-template <class S> ZA_NOINLINE double za_ifft_real(S& s, double baseD, double sizeD) {
+template <class S> ZA_NOINLINE double za_ifft_real_o(S& s, double baseD, double sizeD) {
   const int64_t n = za_round_idx(sizeD);
   int64_t base = 0;
   const bool ok = za_fft_pow2(n) && za_fft_region(s, baseD, n, base, 2 * n);
@@ -667,7 +667,7 @@ template <class S> ZA_NOINLINE double za_ifft_real(S& s, double baseD, double si
 }
 
 // convolve_c(dest, src, size): dest[i] *= src[i] for `size` complex pairs, src read before dest is written on overlap.
-template <class S> ZA_NOINLINE double za_convolve_c(S& s, double destD, double srcD, double sizeD) {
+template <class S> ZA_NOINLINE double za_convolve_c_o(S& s, double destD, double srcD, double sizeD) {
   const int64_t cnt = za_round_idx(sizeD);
   int64_t d = 0, r = 0;
   const bool okc = cnt > 0 && cnt <= ZA_FFT_PAGE / 2 && za_fft_region(s, destD, 2 * cnt, d, 2 * cnt) && za_fft_region(s, srcD, 2 * cnt, r, 2 * cnt);
@@ -685,6 +685,12 @@ template <class S> ZA_NOINLINE double za_convolve_c(S& s, double destD, double s
   }
   return 0.0;
 }
+
+// Inline stubs (zart.h ZA_OUTCALL): the out-of-line bodies above see a copy of the instance's environment, never the state object.
+#define ZA_X(name) template <class S> ZA_FN double name(S& s, double baseD, double sizeD) { ZA_OUTCALL(name##_o(e, baseD, sizeD)); }
+ZA_X(za_fft) ZA_X(za_ifft) ZA_X(za_fft_permute) ZA_X(za_fft_ipermute) ZA_X(za_fft_nat) ZA_X(za_ifft_nat) ZA_X(za_fft_real) ZA_X(za_ifft_real)
+#undef ZA_X
+template <class S> ZA_FN double za_convolve_c(S& s, double destD, double srcD, double sizeD) { ZA_OUTCALL(za_convolve_c_o(e, destD, srcD, sizeD)); }
 
 #undef ZA_M
 #undef ZA_F

@@ -47,7 +47,7 @@ template <class S> ZA_FN const ZaFileSlot* za_file_data(S& s, int k) {     // th
   const ZaFileSlot* f = &s.files->slot[sl];
   return (f->assigned && f->items) ? f : nullptr;
 }
-template <class S> ZA_NOINLINE double za_file_open(S& s, double indexOrSlot, double mode) {
+template <class S> ZA_NOINLINE double za_file_open_o(S& s, double indexOrSlot, double mode) {
   (void)mode;
   if (!s.files || !s.fh) return -1.0;
   const int64_t sl = za_f2i64(indexOrSlot + 1.0e-5);
@@ -66,8 +66,9 @@ template <class S> ZA_NOINLINE double za_file_open(S& s, double indexOrSlot, dou
   ZA_FH(8 + k) = 0;
   return (double)(k + 1);
 }
+template <class S> ZA_FN double za_file_open(S& s, double indexOrSlot, double mode) { ZA_OUTCALL(za_file_open_o(e, indexOrSlot, mode)); }
 template <class S> ZA_FN double za_file_open_multi(S& s, double a, double b) { return za_file_open(s, a, b); }
-template <class S> ZA_NOINLINE double za_file_close(S& s, double handle) {
+template <class S> ZA_NOINLINE double za_file_close_o(S& s, double handle) {
   const int k = za_file_h(s, handle);
   if (k < 0) return 0.0;
   ZA_FH(k) = 0; ZA_FH(8 + k) = 0;
@@ -76,6 +77,7 @@ template <class S> ZA_NOINLINE double za_file_close(S& s, double handle) {
   ZA_FH(17) = nf + 1;
   return 0.0;
 }
+template <class S> ZA_FN double za_file_close(S& s, double handle) { ZA_OUTCALL(za_file_close_o(e, handle)); }
 template <class S> ZA_FN double za_file_rewind(S& s, double handle) {
   const int k = za_file_h(s, handle);
   if (k >= 0) ZA_FH(8 + k) = 0;
@@ -120,7 +122,7 @@ template <class S> ZA_FN double za_file_var(S& s, double handle, double* out) {
   *out = v;
   return v;
 }
-template <class S> ZA_NOINLINE double za_file_mem(S& s, double handle, double destIndex, double length) {
+template <class S> ZA_NOINLINE double za_file_mem_o(S& s, double handle, double destIndex, double length) {
   const int k = za_file_h(s, handle);
   if (k < 0) return 0.0;
   const ZaFileSlot* f = za_file_data(s, k);
@@ -141,6 +143,7 @@ template <class S> ZA_NOINLINE double za_file_mem(S& s, double handle, double de
   ZA_FH(8 + k) = cur + n;
   return (double)n;
 }
+template <class S> ZA_FN double za_file_mem(S& s, double handle, double destIndex, double length) { ZA_OUTCALL(za_file_mem_o(e, handle, destIndex, length)); }
 template <class S> ZA_FN double za_file_multi_count(S& s, double handle) {
   const int k = za_file_h(s, handle);
   return (k >= 0 && za_file_data(s, k)) ? 1.0 : 0.0;

@@ -103,7 +103,7 @@ template <class S> ZA_FN double za_gmem_seq(S& s, double page) {
 }
 
 // mem[dstBase ..] <- cells[srcIdx ..]
-template <class S> ZA_NOINLINE double za_gmem_get(S& s, double dstBaseD, double srcIdxD, double countD) {
+template <class S> ZA_NOINLINE double za_gmem_get_o(S& s, double dstBaseD, double srcIdxD, double countD) {
   const ZaGmemView* g = za_gmem_view(s);
   const int32_t dst = za_gmem_int(dstBaseD), src = za_gmem_int(srcIdxD), cnt = za_gmem_int(countD);
   if (!g || cnt <= 0 || dst < 0 || src < 0 || (uint64_t)src >= g->cell_count) return 0.0;
@@ -118,8 +118,9 @@ template <class S> ZA_NOINLINE double za_gmem_get(S& s, double dstBaseD, double 
   for (uint64_t i = 0; i < n; ++i) s.mem[((int64_t)dst + (int64_t)i) * s.mem_stride] = za_bits2d(ZA_ALOAD(&g->cells[(uint64_t)src + i]));
   return (double)(int32_t)n;
 }
+template <class S> ZA_FN double za_gmem_get(S& s, double dstBaseD, double srcIdxD, double countD) { ZA_OUTCALL(za_gmem_get_o(e, dstBaseD, srcIdxD, countD)); }
 // cells[dstIdx ..] <- mem[srcBase ..]
-template <class S> ZA_NOINLINE double za_gmem_put(S& s, double dstIdxD, double srcBaseD, double countD) {
+template <class S> ZA_NOINLINE double za_gmem_put_o(S& s, double dstIdxD, double srcBaseD, double countD) {
   const ZaGmemView* g = za_gmem_view(s);
   const int32_t dst = za_gmem_int(dstIdxD), src = za_gmem_int(srcBaseD), cnt = za_gmem_int(countD);
   if (!g || cnt <= 0 || dst < 0 || src < 0) return 0.0;
@@ -135,7 +136,8 @@ template <class S> ZA_NOINLINE double za_gmem_put(S& s, double dstIdxD, double s
   }
   return (double)(int32_t)n;
 }
-template <class S> ZA_NOINLINE double za_gmem_fill(S& s, double dstIdxD, double value, double countD) {
+template <class S> ZA_FN double za_gmem_put(S& s, double dstIdxD, double srcBaseD, double countD) { ZA_OUTCALL(za_gmem_put_o(e, dstIdxD, srcBaseD, countD)); }
+template <class S> ZA_NOINLINE double za_gmem_fill_o(S& s, double dstIdxD, double value, double countD) {
   const ZaGmemView* g = za_gmem_view(s);
   const int32_t dst = za_gmem_int(dstIdxD), cnt = za_gmem_int(countD);
   if (!g || cnt <= 0 || dst < 0 || (uint64_t)dst >= g->cell_count) return 0.0;
@@ -150,9 +152,10 @@ template <class S> ZA_NOINLINE double za_gmem_fill(S& s, double dstIdxD, double 
   }
   return (double)(int32_t)n;
 }
+template <class S> ZA_FN double za_gmem_fill(S& s, double dstIdxD, double value, double countD) { ZA_OUTCALL(za_gmem_fill_o(e, dstIdxD, value, countD)); }
 template <class S> ZA_FN double za_gmem_zero(S& s, double dstIdxD, double countD) { return za_gmem_fill(s, dstIdxD, 0.0, countD); }
 // cells[dst ..] <- cells[src ..] as if through a temporary (overlap-safe)
-template <class S> ZA_NOINLINE double za_gmem_copy(S& s, double dstIdxD, double srcIdxD, double countD) {
+template <class S> ZA_NOINLINE double za_gmem_copy_o(S& s, double dstIdxD, double srcIdxD, double countD) {
   const ZaGmemView* g = za_gmem_view(s);
   const int32_t dst = za_gmem_int(dstIdxD), src = za_gmem_int(srcIdxD), cnt = za_gmem_int(countD);
   if (!g || cnt <= 0 || dst < 0 || src < 0 || (uint64_t)dst >= g->cell_count || (uint64_t)src >= g->cell_count) return 0.0;
@@ -171,3 +174,4 @@ template <class S> ZA_NOINLINE double za_gmem_copy(S& s, double dstIdxD, double 
   }
   return (double)(int32_t)n;
 }
+template <class S> ZA_FN double za_gmem_copy(S& s, double dstIdxD, double srcIdxD, double countD) { ZA_OUTCALL(za_gmem_copy_o(e, dstIdxD, srcIdxD, countD)); }

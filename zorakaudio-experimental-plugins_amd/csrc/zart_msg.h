@@ -97,7 +97,7 @@ template <class S> ZA_FN void za_msg_drop(S& s, uint64_t chan) {
   if (k >= 0) s.bus->ch_dropped[(int64_t)s.inst_index * ZA_MSG_CHANNELS + k] += 1u;
 }
 
-template <class S> ZA_NOINLINE double za_comm_join(S& s, double domainH) {
+template <class S> ZA_NOINLINE double za_comm_join_o(S& s, double domainH) {
   if (!s.bus) return 0.0;
   uint64_t d = za_msg_key(domainH);
   if (d == 0) d = ZA_MSG_DEFAULT_DOMAIN;
@@ -108,19 +108,22 @@ template <class S> ZA_NOINLINE double za_comm_join(S& s, double domainH) {
   s.bus->domain[s.inst_index] = d;
   return 1.0;
 }
-template <class S> ZA_NOINLINE double za_msg_subscribe(S& s, double chanH) {
+template <class S> ZA_FN double za_comm_join(S& s, double domainH) { ZA_OUTCALL(za_comm_join_o(e, domainH)); }
+template <class S> ZA_NOINLINE double za_msg_subscribe_o(S& s, double chanH) {
   if (!s.bus) return 0.0;
   const int k = za_msg_slot(s, za_msg_key(chanH), true);
   if (k >= 0) s.bus->ch_flags[(int64_t)s.inst_index * ZA_MSG_CHANNELS + k] |= 1u;
   return 1.0;
 }
-template <class S> ZA_NOINLINE double za_msg_unsubscribe(S& s, double chanH) {
+template <class S> ZA_FN double za_msg_subscribe(S& s, double chanH) { ZA_OUTCALL(za_msg_subscribe_o(e, chanH)); }
+template <class S> ZA_NOINLINE double za_msg_unsubscribe_o(S& s, double chanH) {
   if (!s.bus) return 0.0;
   const int k = za_msg_slot(s, za_msg_key(chanH), false);
   if (k >= 0) s.bus->ch_flags[(int64_t)s.inst_index * ZA_MSG_CHANNELS + k] &= ~1u;
   return 1.0;
 }
-template <class S> ZA_NOINLINE double za_msg_advertise(S& s, double chanH, double capsD) {
+template <class S> ZA_FN double za_msg_unsubscribe(S& s, double chanH) { ZA_OUTCALL(za_msg_unsubscribe_o(e, chanH)); }
+template <class S> ZA_NOINLINE double za_msg_advertise_o(S& s, double chanH, double capsD) {
   if (!s.bus) return 0.0;
   const int64_t ci = za_f2i64(capsD + (capsD < 0 ? -0.5 : 0.5));
   const uint64_t caps = ci < 0 ? 0 : (uint64_t)ci;
@@ -132,7 +135,8 @@ template <class S> ZA_NOINLINE double za_msg_advertise(S& s, double chanH, doubl
   }
   return 1.0;
 }
-template <class S> ZA_NOINLINE double za_msg_queue(S& s, uint64_t target, bool direct, double chanH, double tag, double a, double b,
+template <class S> ZA_FN double za_msg_advertise(S& s, double chanH, double capsD) { ZA_OUTCALL(za_msg_advertise_o(e, chanH, capsD)); }
+template <class S> ZA_NOINLINE double za_msg_queue_o(S& s, uint64_t target, bool direct, double chanH, double tag, double a, double b,
                                                   double c, double d, int64_t buf_base = -1, int64_t buf_len = 0) {
   if (!s.bus) return 0.0;
   const uint64_t chan = za_msg_key(chanH);
@@ -151,6 +155,7 @@ template <class S> ZA_NOINLINE double za_msg_queue(S& s, uint64_t target, bool d
   s.bus->out_count[s.inst_index] = n + 1;
   return 1.0;
 }
+template <class S> ZA_FN double za_msg_queue(S& s, uint64_t target, bool direct, double chanH, double tag, double a, double b, double c, double d, int64_t buf_base = -1, int64_t buf_len = 0) { ZA_OUTCALL(za_msg_queue_o(e, target, direct, chanH, tag, a, b, c, d, buf_base, buf_len)); }
 // std::llround into int with saturation, non-finite -> 0 (toInt, src/DspJsfxRuntimeBuiltins.cpp:35-44)
 ZA_FN int64_t za_msg_toint(double v) {
   if (!(v == v) || v - v != 0.0) return 0;
@@ -186,7 +191,7 @@ template <class S> ZA_FN int64_t za_msg_front(S& s, uint64_t chan) {
     if (s.bus->inbox[base + i].kind != 0 && s.bus->inbox[base + i].chan == chan) return base + i;
   return -1;
 }
-template <class S> ZA_NOINLINE double za_msg_recv(S& s, double chanH, double* src, double* tag, double* a, double* b, double* c, double* d) {
+template <class S> ZA_NOINLINE double za_msg_recv_o(S& s, double chanH, double* src, double* tag, double* a, double* b, double* c, double* d) {
   if (!s.bus) return 0.0;
   const int64_t at = za_msg_front(s, za_msg_key(chanH));
   if (at < 0 || s.bus->inbox[at].kind != 1) return 0.0;      // (a buffer at the front waits for msg_recv_buf)
@@ -196,7 +201,8 @@ template <class S> ZA_NOINLINE double za_msg_recv(S& s, double chanH, double* sr
   if (s.bus->last_len) s.bus->last_len[s.inst_index] = 0;
   return 1.0;
 }
-template <class S> ZA_NOINLINE double za_msg_recv_buf(S& s, double chanH, double* src, double* tag, double dstBase, double maxLen) {
+template <class S> ZA_FN double za_msg_recv(S& s, double chanH, double* src, double* tag, double* a, double* b, double* c, double* d) { typename S::Env e = s; double o1_ = *src; double o2_ = *tag; double o3_ = *a; double o4_ = *b; double o5_ = *c; double o6_ = *d; const double r_ = za_msg_recv_o(e, chanH, &o1_, &o2_, &o3_, &o4_, &o5_, &o6_); *src = o1_; *tag = o2_; *a = o3_; *b = o4_; *c = o5_; *d = o6_; static_cast<typename S::Env&>(s) = e; return r_; }
+template <class S> ZA_NOINLINE double za_msg_recv_buf_o(S& s, double chanH, double* src, double* tag, double dstBase, double maxLen) {
   if (!s.bus || !s.bus->in_pay) return 0.0;
   int64_t cap = za_msg_toint(maxLen);
   if (cap <= 0) return 0.0;
@@ -219,7 +225,8 @@ template <class S> ZA_NOINLINE double za_msg_recv_buf(S& s, double chanH, double
   m.kind = 0;
   return cap >= n ? (double)n : -(double)n;
 }
-template <class S> ZA_NOINLINE double za_msg_avail(S& s, double chanH) {
+template <class S> ZA_FN double za_msg_recv_buf(S& s, double chanH, double* src, double* tag, double dstBase, double maxLen) { typename S::Env e = s; double o1_ = *src; double o2_ = *tag; const double r_ = za_msg_recv_buf_o(e, chanH, &o1_, &o2_, dstBase, maxLen); *src = o1_; *tag = o2_; static_cast<typename S::Env&>(s) = e; return r_; }
+template <class S> ZA_NOINLINE double za_msg_avail_o(S& s, double chanH) {
   if (!s.bus) return 0.0;
   const uint64_t chan = za_msg_key(chanH);
   const int64_t base = (int64_t)s.inst_index * ZA_MSG_INBOX;
@@ -227,12 +234,13 @@ template <class S> ZA_NOINLINE double za_msg_avail(S& s, double chanH) {
   for (uint32_t i = 0; i < s.bus->in_count[s.inst_index]; ++i) cnt += (s.bus->inbox[base + i].kind != 0 && s.bus->inbox[base + i].chan == chan);
   return (double)cnt;
 }
+template <class S> ZA_FN double za_msg_avail(S& s, double chanH) { ZA_OUTCALL(za_msg_avail_o(e, chanH)); }
 template <class S> ZA_FN double za_msg_kind(S& s, double chanH) {
   if (!s.bus) return 0.0;
   const int64_t at = za_msg_front(s, za_msg_key(chanH));
   return at >= 0 ? (double)s.bus->inbox[at].kind : 0.0;
 }
-template <class S> ZA_NOINLINE double za_msg_clear(S& s, double chanH) {
+template <class S> ZA_NOINLINE double za_msg_clear_o(S& s, double chanH) {
   if (!s.bus) return 0.0;
   const uint64_t chan = za_msg_key(chanH);
   const int64_t base = (int64_t)s.inst_index * ZA_MSG_INBOX;
@@ -241,6 +249,7 @@ template <class S> ZA_NOINLINE double za_msg_clear(S& s, double chanH) {
     if (s.bus->inbox[base + i].kind != 0 && s.bus->inbox[base + i].chan == chan) { s.bus->inbox[base + i].kind = 0; ++cnt; }
   return (double)cnt;
 }
+template <class S> ZA_FN double za_msg_clear(S& s, double chanH) { ZA_OUTCALL(za_msg_clear_o(e, chanH)); }
 template <class S> ZA_FN double za_msg_dropped(S& s, double chanH) {
   if (!s.bus) return 0.0;
   const int k = za_msg_slot(s, za_msg_key(chanH), false);
@@ -258,7 +267,7 @@ ZA_FN bool za_msg_matches(const ZaBusView* B, uint32_t j, uint64_t chan, int rol
   }
   return false;
 }
-template <class S> ZA_NOINLINE double za_msg_peer_count(S& s, double chanH, double roleD) {
+template <class S> ZA_NOINLINE double za_msg_peer_count_o(S& s, double chanH, double roleD) {
   if (!s.bus) return 0.0;
   const uint64_t chan = za_msg_key(chanH), dom = s.bus->domain[s.inst_index];
   const int role = (int)za_f2i64(roleD + (roleD < 0 ? -0.5 : 0.5));
@@ -266,7 +275,8 @@ template <class S> ZA_NOINLINE double za_msg_peer_count(S& s, double chanH, doub
   for (uint32_t j = 0; j < s.bus->n_inst; ++j) cnt += (s.bus->domain[j] == dom && za_msg_matches(s.bus, j, chan, role));
   return (double)cnt;
 }
-template <class S> ZA_NOINLINE double za_msg_peer_id(S& s, double chanH, double roleD, double indexD) {
+template <class S> ZA_FN double za_msg_peer_count(S& s, double chanH, double roleD) { ZA_OUTCALL(za_msg_peer_count_o(e, chanH, roleD)); }
+template <class S> ZA_NOINLINE double za_msg_peer_id_o(S& s, double chanH, double roleD, double indexD) {
   if (!s.bus) return 0.0;
   const uint64_t chan = za_msg_key(chanH), dom = s.bus->domain[s.inst_index];
   const int role = (int)za_f2i64(roleD + (roleD < 0 ? -0.5 : 0.5));
@@ -277,11 +287,12 @@ template <class S> ZA_NOINLINE double za_msg_peer_id(S& s, double chanH, double 
     if (s.bus->domain[j] == dom && za_msg_matches(s.bus, j, chan, role)) { if (cnt == want) return (double)(s.bus->first_id + j); ++cnt; }
   return 0.0;
 }
+template <class S> ZA_FN double za_msg_peer_id(S& s, double chanH, double roleD, double indexD) { ZA_OUTCALL(za_msg_peer_id_o(e, chanH, roleD, indexD)); }
 template <class S> ZA_FN int64_t za_msg_peer_index(S& s, double idD) {
   const int64_t id = za_f2i64(idD + 0.5) - (int64_t)s.bus->first_id;
   return (id >= 0 && id < (int64_t)s.bus->n_inst) ? id : -1;
 }
-template <class S> ZA_NOINLINE double za_msg_peer_caps(S& s, double idD) {     // merged caps of the peer's advertisements
+template <class S> ZA_NOINLINE double za_msg_peer_caps_o(S& s, double idD) {     // merged caps of the peer's advertisements
   if (!s.bus) return 0.0;
   const int64_t j = za_msg_peer_index(s, idD);
   if (j < 0) return 0.0;
@@ -290,10 +301,11 @@ template <class S> ZA_NOINLINE double za_msg_peer_caps(S& s, double idD) {     /
     if (s.bus->ch_flags[j * ZA_MSG_CHANNELS + k] & 2u) caps |= s.bus->ch_caps[j * ZA_MSG_CHANNELS + k];
   return (double)caps;
 }
+template <class S> ZA_FN double za_msg_peer_caps(S& s, double idD) { ZA_OUTCALL(za_msg_peer_caps_o(e, idD)); }
 template <class S> ZA_FN double za_msg_peer_alive(S& s, double idD) { return (s.bus && za_msg_peer_index(s, idD) >= 0) ? 1.0 : 0.0; }
 
 // beginBlock: collect what the ring holds for this instance (DspJsfxMessageBus::collectInbox)
-template <class S> ZA_NOINLINE void za_msg_begin_block(S& s) {
+template <class S> ZA_NOINLINE void za_msg_begin_block_o(S& s) {
   const ZaBusView* B = s.bus;
   if (!B) return;
   const uint32_t me = s.inst_index;
@@ -334,6 +346,7 @@ template <class S> ZA_NOINLINE void za_msg_begin_block(S& s) {
   }
   B->in_count[me] = n;
 }
+template <class S> ZA_FN void za_msg_begin_block(S& s) { ZA_OUTCALL_VOID(za_msg_begin_block_o(e)); }
 
 // endBlock of every instance, in instance order: DspJsfxMessageBus::flushOutbox. One thread on the CPU; one wavefront on
 // the device, where the lanes share the search for a subscriber (the only part that grows with the instance count) and

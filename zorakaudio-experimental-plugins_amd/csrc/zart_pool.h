@@ -110,7 +110,7 @@ template <class S> ZA_FN double za_sample_pool_ram_mb(S& s, double pool) {
 }
 
 // sample_export_mem(pool, id, dst, srcFrame, count): mem[dst+i] = read(id, 0, srcFrame+i); the 2 variant writes L,R pairs.
-template <class S> ZA_NOINLINE double za_pool_export(S& s, double pool, double id, double dstD, double srcD, double cntD, bool stereo) {
+template <class S> ZA_NOINLINE double za_pool_export_o(S& s, double pool, double id, double dstD, double srcD, double cntD, bool stereo) {
   const ZaPoolView* p = za_pool(s, pool);
   if (!p) return 0.0;
   const int64_t dst = (int32_t)za_llround(dstD), start = (int32_t)za_llround(srcD), count = (int32_t)za_llround(cntD);
@@ -136,6 +136,7 @@ template <class S> ZA_NOINLINE double za_pool_export(S& s, double pool, double i
   }
   return (double)count;
 }
+template <class S> ZA_FN double za_pool_export(S& s, double pool, double id, double dstD, double srcD, double cntD, bool stereo) { ZA_OUTCALL(za_pool_export_o(e, pool, id, dstD, srcD, cntD, stereo)); }
 template <class S> ZA_FN double za_sample_export_mem(S& s, double pool, double id, double dst, double src, double cnt) { return za_pool_export(s, pool, id, dst, src, cnt, false); }
 template <class S> ZA_FN double za_sample_export_mem2(S& s, double pool, double id, double dst, double src, double cnt) { return za_pool_export(s, pool, id, dst, src, cnt, true); }
 // host-side setup calls reached from a section: the engine's single pool is always "slot 0 / committed"
