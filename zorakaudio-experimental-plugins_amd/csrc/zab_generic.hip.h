@@ -91,6 +91,10 @@ __device__ __forceinline__ void za_state_bind(SS& s, const ZabBatch& b, int inst
 template <class SS>
 __device__ __forceinline__ void za_state_load(SS& s, const ZabBatch& b, int inst) {
   za_state_bind(s, b, inst);
+  // (Beyond ~1000 variables the compiler declines to unroll this loop and the one in za_state_store -- its limit for "#pragma
+  // unroll" is 16 K instructions -- and one dynamic index into the state object keeps all of it in scratch memory. Measured on
+  // Texture, 1087 variables: forcing the unroll (-mllvm -pragma-unroll-threshold) costs 14 minutes of compile time and the
+  // register-allocated form with its 23 KB of spills runs SLOWER, 973 vs 601 ms at 192 instances. Left as it is.)
 #pragma unroll
   for (int k = 0; k < ZA_NV; ++k) s.v[k] = b.vars[k * b.var_se + inst * b.var_si];
 #define ZA_X(k) s.sl[k] = b.sliders[(k) * b.sl_se + inst * b.sl_si];
