@@ -360,6 +360,35 @@ def test_map_loops_on_replica_lanes(ipw, monkeypatch):
         assert high[i] == p.mem_high, (i, high[i], p.mem_high)
 
 
+def test_modulo_shortcuts_match_the_division():
+    """csrc/zart.h za_mod: the device skips the integer division for 0 <= l < r, l == r and power-of-two divisors; the CPU port
+    always divides. tests/fixtures/modkat.jsfx walks counters through divisors of every sign (and zero) -- the accumulated sum
+    of all results must agree exactly."""
+    import zabatch
+    from oracle import port
+    from zajit import noise
+    meta = zabatch.leaf_meta("fx_modkat")
+    divs = [7, 1, 16, -5, 0, 33, -16, 40]
+    n, frames = len(divs), 3000
+    rows = np.tile(np.array(meta["default_sliders"], dtype=np.float64), (n, 1))
+    rows[:, 0] = divs
+    rows[:, 1] = [0, 5, -37, 100, 3, -100, 64, -1]
+    x = noise.white_noise(range(n), frames)
+    with zabatch.Engine("fx_modkat", n) as e:
+        e.set_sliders(rows); e.prepare()
+        y = e.process_host(x, block=512)
+        v = e.read_vars(); names = e.var_names()
+    for i in range(n):
+        p = port.Port("fx_modkat", 48000.0)
+        p.set_sliders(rows[i]); p.prepare()
+        ref = p.process(x[i], 512)
+        pv = p.vars()
+        for k, nm in enumerate(names):
+            if nm.startswith("m") or nm == "acc":
+                assert v[i][k] == pv[k], (divs[i], nm, v[i][k], pv[k])
+        assert np.abs(y[i].astype(np.float64) - ref).max() <= AUDIO_EPS, (i, divs[i])
+
+
 def test_script_originated_slider_changes_reach_the_host_mirror():
     """consumeDspSliderChanges / pushParamsToStateSliders (src/JSFXJuceProcessor.cpp:5665-5739, 9286-9357) through
     JsfxBatchProcessor: a slider the script sets and announces with sliderchange() becomes the host parameter and is not

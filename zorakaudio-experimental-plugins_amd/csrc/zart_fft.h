@@ -686,11 +686,23 @@ template <class S> ZA_NOINLINE double za_convolve_c_o(S& s, double destD, double
   return 0.0;
 }
 
-// Inline stubs (zart.h ZA_OUTCALL): the out-of-line bodies above see a copy of the instance's environment, never the state object.
-#define ZA_X(name) template <class S> ZA_FN double name(S& s, double baseD, double sizeD) { ZA_OUTCALL(name##_o(e, baseD, sizeD)); }
+// Inline stubs (zart.h ZA_OUTCALL): the out-of-line bodies above never see the state object -- and not the whole environment
+// either, only the ten words the transforms use (a call costs their stores, the three that can change come back).
+struct ZaFftEnv {
+  using Env = ZaFftEnv;
+  double* mem; int64_t mem_stride, mem_cap, mem_high, mem_need;
+  double* fft; int64_t fft_stride, fft_cap;
+  uint32_t err, replica;
+};
+#define ZA_FFT_OUT(call) \
+  ZaFftEnv e; e.mem = s.mem; e.mem_stride = s.mem_stride; e.mem_cap = s.mem_cap; e.mem_high = s.mem_high; e.mem_need = s.mem_need; \
+  e.fft = s.fft; e.fft_stride = s.fft_stride; e.fft_cap = s.fft_cap; e.err = s.err; e.replica = s.replica; \
+  const double r_ = (call); s.mem_high = e.mem_high; s.mem_need = e.mem_need; s.err = e.err; return r_
+#define ZA_X(name) template <class S> ZA_FN double name(S& s, double baseD, double sizeD) { ZA_FFT_OUT(name##_o(e, baseD, sizeD)); }
 ZA_X(za_fft) ZA_X(za_ifft) ZA_X(za_fft_permute) ZA_X(za_fft_ipermute) ZA_X(za_fft_nat) ZA_X(za_ifft_nat) ZA_X(za_fft_real) ZA_X(za_ifft_real)
 #undef ZA_X
-template <class S> ZA_FN double za_convolve_c(S& s, double destD, double srcD, double sizeD) { ZA_OUTCALL(za_convolve_c_o(e, destD, srcD, sizeD)); }
+template <class S> ZA_FN double za_convolve_c(S& s, double destD, double srcD, double sizeD) { ZA_FFT_OUT(za_convolve_c_o(e, destD, srcD, sizeD)); }
+#undef ZA_FFT_OUT
 
 #undef ZA_M
 #undef ZA_F
