@@ -165,7 +165,7 @@ def module_source(unit: codegen.Unit) -> str:
     # leaves with FFT builtins on the audio path (@sample / @block): the wave-cooperative transforms stream one instance's
     # buffer with all lanes, so it must be contiguous (a leaf that only transforms in @init/@slider stays interleaved)
     from .emit import FFT_CALLS
-    fft_hot = bool(_hot_calls(p) & set(FFT_CALLS)) or ("coop" in unit.features and "gmem" not in unit.features)   # replica lanes
+    fft_hot = bool(_hot_calls(p) & set(FFT_CALLS)) or (unit.defines.get("ZA_USES_COOP") == "1" and "gmem" not in unit.features)   # replica lanes
     # (2 = instance-major AND thin wavefronts with replica lanes while the batch is small, see zabatch.hip / zab_generic)
     # leaves whose time-parallel kernel reads delay lines: 64 consecutive frames of ONE instance per access, so its arena must be
     # contiguous (interleaved, those 64 reads would touch 64 cache lines)

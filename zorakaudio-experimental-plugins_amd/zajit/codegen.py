@@ -46,6 +46,11 @@ class Unit:
         }
 
 
+# Leaves whose only cooperative loops are elementwise ("map") loops get replica lanes when that was measured to pay (DESIGN.md
+# section 8.6: Contour 108 -> 82 ms at 384 x 48 000; NeuroCV 109 -> 174 and TextureXY 478 -> 515 do not).
+MAP_REPLICA_LEAVES = {"Contour"}
+
+
 def make_unit(prog: Program) -> Unit:
     em = Emitter(prog)
     code = em.emit()
@@ -78,7 +83,8 @@ def make_unit(prog: Program) -> Unit:
         "ZA_USES_FILE": "1" if "file" in em.features else "0",
         "ZA_USES_MSG": "1" if "msg" in em.features else "0",
         "ZA_USES_FFT": "1" if "fft" in em.features else "0",
-        "ZA_USES_COOP": "1" if "coop" in em.features else "0",      # has accumulation loops shared by replica lanes (emit.py)
+        # has accumulation loops shared by replica lanes (emit.py) -- or only elementwise loops, where that was measured to pay
+        "ZA_USES_COOP": "1" if ("coop" in em.features or ("coopmap" in em.features and prog.name in MAP_REPLICA_LEAVES)) else "0",
         # leaves whose mem[] is touched only by zart.h's load/store/memset/memcpy can keep its low part in LDS (zart.h)
         "ZA_USES_LMEM": "1" if "mem" in em.features and not em.features & {"fft", "gmem", "pool", "file", "msg"} else "0",
         # very large scripts (Sample: 754 specialised functions, 1 MB of expressions) cannot be flattened into one kernel body
