@@ -164,18 +164,24 @@ extern "C" __global__ void __launch_bounds__(64) ZA_KERNEL(prepare)(ZabBatch b) 
   b.flags[inst] = ZAB_FLAG_PREPARED;
 }
 
-#if ZA_NCH > 0
-typedef float ZaTile[64][ZA_TT + 1];
-#else
-typedef float ZaTile;
+#if (ZA_USES_FFT || ZA_USES_COOP) && !ZA_USES_GMEM
+#define ZA_REPLICAS 1
 #endif
+// The audio tile: [NCH][rows][TT + 1] floats in LDS. Lane-per-instance leaves hold 64 rows (static). A replica-lane leaf only
+// ever fills ipw rows -- two, typically -- and its wavefronts also hold a transform buffer, so its tile is sized at launch
+// (dynamic LDS, behind the arena window if there is one): 17 KB -> 0.5 KB per wavefront, six waves per CU instead of three.
+#ifdef ZA_REPLICAS
+#define ZA_TILE_ROWS ipw
+#else
+#define ZA_TILE_ROWS 64
+#endif
+#define ZA_TILE(ch, row, t) tile[((ch) * ZA_TILE_ROWS + (row)) * (ZA_TT + 1) + (t)]
 template <class SS>
-__device__ __forceinline__ void za_process_body(const ZabBatch& b, const ZabAudio& a, ZaTile* tile) {
+__device__ __forceinline__ void za_process_body(const ZabBatch& b, const ZabAudio& a, float* tile) {
   const int lane = threadIdx.x;
   const int ipw = b.ipw;
   const int inst0 = blockIdx.x * ipw;
-#if (ZA_USES_FFT || ZA_USES_COOP) && !ZA_USES_GMEM
-#define ZA_REPLICAS 1
+#ifdef ZA_REPLICAS
   // REPLICA LANES: a thin wavefront (ipw < 64) runs every instance on 64 / ipw lanes at once -- identical state, identical
   // control flow, identical (hence harmless) stores. Nothing is gained for the serial code, but every lane now reaches the
   // FFT builtins, whose wave-cooperative form (zart_fft.h) spreads ONE instance's transform over all of them.
@@ -247,17 +253,17 @@ __device__ __forceinline__ void za_process_body(const ZabBatch& b, const ZabAudi
         for (int u = 0; u < 8; ++u) {
           const int idx = idx0 + 64 * u;
           const int t = idx % ZA_TT, rc = idx / ZA_TT, ch = rc % ZA_NCH, row = rc / ZA_NCH;
-          if (idx < ipw * ZA_NCH * ZA_TT) tile[ch][row][t] = xv[u];
+          if (idx < ipw * ZA_NCH * ZA_TT) ZA_TILE(ch, row, t) = xv[u];
         }
       }
       za_wave_sync();
       if (active) {
         for (int t = 0; t < tn; ++t) {
-#define ZA_X(ch) s.spl[ch] = (double)tile[ch][row][t];
+#define ZA_X(ch) s.spl[ch] = (double)ZA_TILE(ch, row, t);
           ZA_FOR_CH(ZA_X)
 #undef ZA_X
           za_section_sample(s);
-#define ZA_X(ch) tile[ch][row][t] = (float)s.spl[ch];
+#define ZA_X(ch) ZA_TILE(ch, row, t) = (float)s.spl[ch];
           ZA_FOR_CH(ZA_X)
 #undef ZA_X
         }
@@ -266,7 +272,7 @@ __device__ __forceinline__ void za_process_body(const ZabBatch& b, const ZabAudi
       for (int idx = lane; idx < ipw * ZA_NCH * ZA_TT; idx += 64) {
         const int t = idx % ZA_TT, rc = idx / ZA_TT, ch = rc % ZA_NCH, row = rc / ZA_NCH;
         if (t < tn && inst0 + row < b.n_inst)
-          a.out[((int64_t)(inst0 + row) * ZA_NCH + ch) * a.frame_stride + pos + t0 + t] = tile[ch][row][t];
+          a.out[((int64_t)(inst0 + row) * ZA_NCH + ch) * a.frame_stride + pos + t0 + t] = ZA_TILE(ch, row, t);
       }
       za_wave_sync();
     }
@@ -290,11 +296,14 @@ __device__ __forceinline__ void za_process_body(const ZabBatch& b, const ZabAudi
 
 extern "C" __global__ void __launch_bounds__(64) ZA_KERNEL(process)(ZabBatch b, ZabAudio a) {
   ZA_KERNEL_ENTRY();
-#if ZA_NCH > 0
-  __shared__ float tile[ZA_NCH][64][ZA_TT + 1];
-  ZaTile* const tp = tile;
+#if ZA_NCH > 0 && defined(ZA_REPLICAS)
+  extern __shared__ double za_dyn_lds[];                 // [arena window: lmem_words x ipw doubles][tile]
+  float* const tp = (float*)(za_dyn_lds + (size_t)b.lmem_words * (size_t)b.ipw);
+#elif ZA_NCH > 0
+  __shared__ float tile[ZA_NCH * 64 * (ZA_TT + 1)];
+  float* const tp = tile;
 #else
-  ZaTile* const tp = nullptr;
+  float* const tp = nullptr;
 #endif
 #if ZA_USES_LMEM
   if (b.lmem_words > 0) { za_process_body<ZaSLm>(b, a, tp); return; }     // (uniform: a launch runs one body or the other)
@@ -365,6 +374,11 @@ static hipError_t za_launch_process(const ZabBatch* b, const ZabAudio* a, hipStr
   size_t lds = 0;
 #if ZA_USES_LMEM
   lds = (size_t)b->lmem_words * (size_t)b->ipw * sizeof(double);
+#endif
+#if ZA_NCH > 0 && defined(ZA_REPLICAS)
+  lds += (size_t)ZA_NCH * (size_t)b->ipw * (ZA_TT + 1) * sizeof(float);      // the audio tile (za_process_body)
+#endif
+#if ZA_USES_LMEM
   static size_t za_lds_allowed = 0;                 // dynamic LDS beyond the default limit has to be asked for once
   if (lds > za_lds_allowed) {
     const hipError_t e = hipFuncSetAttribute((const void*)ZA_KERNEL(process), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

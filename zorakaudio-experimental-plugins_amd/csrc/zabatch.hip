@@ -289,13 +289,13 @@ int zab_create(const char* module, const zab_config* cfg, zab_engine** out) {
     // of 64 and the chip runs 8x the wavefronts. Measured at 1024-2048 instances (ipw 64 / 16 / 8 / 4 / 1): FFT round trip
     // 11.4 / 2.9 / 1.45 / 1.45 / 1.46 ms, STFT fixture 443 / 276 / 248 / 232 / 780 ms, DOT 642 / 600 / 593 / 593 / 2200 ms --
     // below ~4 the serial parts pay for 64x the memory instructions chip-wide.
-    int ipw = m->prefer_instance_major == 2 ? 8 : (m->nch >= 6 ? 16 : 64);
+    int ipw = m->prefer_instance_major >= 2 ? 8 : (m->nch >= 6 ? 16 : 64);
     // Replica-lane leaves (FFT builtins or accumulation loops on the audio path) want a fixed number of wavefronts rather than
     // a fixed width: ~256 when each wavefront holds a 64 KB LDS transform buffer (two per CU), ~1024 otherwise. Measured:
     // 4096-pt round trips, 256 buffers: 5.6 / 2.8 / 1.4 ms at ipw 8 / 4 / 2, 2048 buffers: 1.44 ms at any; DOT x4096: 133 / 90 /
     // 75 ms at ipw 4 / 8 / 16; TSEQ x1024: 417 / 274 / 294 / 486 ms at ipw 1 / 2 / 4 / 8, x4096: 329 / 227 / 328 at 2 / 4 / 8,
     // x16384: 457 / 385 / 340 / 480 at 4 / 8 / 16 / 32.
-    if (m->prefer_instance_major == 2) {
+    if (m->prefer_instance_major >= 2) {
       // An FFT leaf built with the 1024-point LDS buffer (zart_fft.h, the default since round 2) holds 24 KB per wavefront, six
       // fit a CU, and it gets the 1024 target too. Measured (2048 buffers, fft + permute + ipermute + ifft round trip, target
       // 256 / 1024 / 2048 / 4096 wavefronts): 1024 points 349 / 126 / 126 / 127 us, 4096 points (sliced) 2564 / 991 / 1001 / 992 us;
@@ -305,7 +305,16 @@ int zab_create(const char* module, const zab_config* cfg, zab_engine** out) {
       if (auto fp = (int (*)(void))dlsym(dl, "zab_module_fft_lds_points")) lds_points = fp();
       const char* tw = getenv("ZAB_FFT_WAVES");
       const int64_t target = m->fft_scratch_doubles > 0 ? (lds_points <= 1024 ? (tw ? atoi(tw) : 1024) : 256) : 1024;
-      ipw = 2;
+      // From one instance per wavefront (all 64 lanes on its cooperative transforms, loops and copies) since the audio tile of
+      // these leaves is sized at launch (zab_generic.hip.h: 25 KB of LDS per wavefront, six per CU = 1536 resident) and a loop
+      // needs 64 trips, not two per lane, to be shared (zart.h za_coop_min). Measured at 1024 instances, 1 vs 2 per wavefront:
+      // STFT fixtures 18.3 / 24.1 ms per 16 384 frames, DOT 134 / 159 and TSEQ 1838 / 2188 ms per 48 000, PsychoConvolver with
+      // an impulse response x256 45 / 59 ms; Contour x384 88 / 82, SpectralStabilizer and Texture unchanged; the FFT round trip of
+      // 2048 buffers (beyond the target either way) 1056 / 977 us. Before those two changes one per wavefront lost everywhere
+      // (17 KB tile: three waves per CU; DOT's 100-tap FIR fell back to 64 copies of the serial loop: 749 ms).
+      // (3: FFT builtins on the audio path of a leaf WITHOUT replica lanes -- gmem users, i.e. Sample: two per wavefront as
+      //  before; one lone lane per wavefront took it from 3.8 to 7.9 s.)
+      ipw = m->prefer_instance_major == 2 ? 1 : 2;
       while (ipw < 64 && (int64_t)cfg->n_instances > target * ipw) ipw <<= 1;
     }
     while (ipw < 64 && (int64_t)cfg->n_instances > 2048ll * ipw) ipw <<= 1;
@@ -546,8 +555,10 @@ static int choose_lmem(zab_engine* e) {
   const int64_t K = (top + 7) & ~(int64_t)7;
   if (top <= 0 || K > e->b.mem_cap) return ZAB_OK;
   const int nch = e->mod->nch, tt = nch <= 4 ? 32 : nch <= 8 ? 16 : nch <= 16 ? 8 : nch <= 32 ? 4 : 2;    // ZA_TT
-  const int64_t tile = (int64_t)nch * 64 * (tt + 1) * 4, cu_lds = 160 * 1024, wg_max = 128 * 1024;
+  const int64_t cu_lds = 160 * 1024, wg_max = 128 * 1024;
+  const bool replicas = e->mod->prefer_instance_major == 2;       // (their tile has ipw rows, not 64: zab_generic.hip.h)
   for (int ipw = e->ipw0; ipw >= 1; ipw >>= 1) {
+    const int64_t tile = (int64_t)nch * (replicas ? ipw : 64) * (tt + 1) * 4;
     const int64_t lds = K * ipw * 8 + tile;
     if (lds > wg_max) continue;
     const int64_t waves = (e->b.n_inst + ipw - 1) / ipw;

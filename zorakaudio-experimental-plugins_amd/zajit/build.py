@@ -170,7 +170,8 @@ def module_source(unit: codegen.Unit) -> str:
     # leaves whose time-parallel kernel reads delay lines: 64 consecutive frames of ONE instance per access, so its arena must be
     # contiguous (interleaved, those 64 reads would touch 64 cache lines)
     tp_mem = plan is not None and bool(plan.loads or plan.stores)
-    lines.append(f"  {2 if fft_hot else (1 if (name in INSTANCE_MAJOR or tp_mem) else 0)}, 65536, za_var_names, {2 * 32768 if 'fft' in unit.features else 0}, {(2 if p.options.get('gmem') else 1) if 'gmem' in unit.features else 0}, {1 if 'pool' in unit.features else 0}, {1 if 'file' in unit.features else 0}, {(2 if 'msgbuf' in unit.features else 1) if 'msg' in unit.features else 0},")
+    # (3 = thin wavefronts like 2, but the kernel has no replica lanes: gmem users, zab_generic.hip.h ZA_REPLICAS)
+    lines.append(f"  {(3 if 'gmem' in unit.features else 2) if fft_hot else (1 if (name in INSTANCE_MAJOR or tp_mem) else 0)}, 65536, za_var_names, {2 * 32768 if 'fft' in unit.features else 0}, {(2 if p.options.get('gmem') else 1) if 'gmem' in unit.features else 0}, {1 if 'pool' in unit.features else 0}, {1 if 'file' in unit.features else 0}, {(2 if 'msgbuf' in unit.features else 1) if 'msg' in unit.features else 0},")
     lines.append("  za_launch_prepare, za_launch_process, za_launch_slider,")
     if fast:
         lines.append("  za_fast_applies, za_launch_fast, ZA_FAST_KERNEL_NAME,")

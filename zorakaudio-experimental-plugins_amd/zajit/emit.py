@@ -403,7 +403,7 @@ class Emitter:
                   f"if (++{w} >= ZA_LOOP_CAP) {{ s.err |= ZA_ERR_LOOP_CAP; break; }} }} }}")
         count = f"za_map_trips({self.expr(cd.r)}, {self.var_ref(v)}, {c_double(ind[v])})"
         return (f"{{ bool z_ = false; if (ZA_COOP_ON(s)) {{ const int64_t {c} = {count}; "
-                f"if ({c} >= 2 * (int64_t)s.rep_n && {c} < ZA_LOOP_CAP) {{ {pro} z_ = {okx}; if (z_) {{ {shared} }} }} }} "
+                f"if ({c} >= za_coop_min(s) && {c} < ZA_LOOP_CAP) {{ {pro} z_ = {okx}; if (z_) {{ {shared} }} }} }} "
                 f"if (!z_) {serial} }}")
 
     def e_If(self, n):
@@ -774,7 +774,7 @@ class Emitter:
                 self.redirect = {}
                 k = self.t("k")
                 seti = lambda kk: " ".join(f"{self.var_ref(v)} = {start[v]} + (double)({kk}) * {c_double(st)};" for v, st in ind.items())
-                ok = " && ".join([f"{c} >= 2 * (int64_t)s.rep_n"] + [f"za_coop_int({self.var_ref(v)})" for v in ind])
+                ok = " && ".join([f"{c} >= za_coop_min(s)"] + [f"za_coop_int({self.var_ref(v)})" for v in ind])
                 # REPLICA LANES SHARE THE TRIPS (zab_generic.hip.h): lane r of the instance takes trips k = r, r + R, ...; the
                 # partial sums meet in a fixed-order butterfly; every lane repeats the last trip (partials discarded) so that the
                 # script's temporaries and the loop's value end as they would serially. Differs from the serial sum by rounding.
@@ -793,7 +793,7 @@ class Emitter:
             plan = self._map_plan(items, set(self.scope[-1]) if self.scope else set())
             if plan:
                 pro, okx, shared = self._map_loop(plan, c, n.body, last_value=l)
-                coop = f"if (ZA_COOP_ON(s) && {c} >= 2 * (int64_t)s.rep_n && ({{ {pro} bool z_ = {okx}; if (z_) {{ {shared} }} z_; }})) {{ }} else "
+                coop = f"if (ZA_COOP_ON(s) && {c} >= za_coop_min(s) && ({{ {pro} bool z_ = {okx}; if (z_) {{ {shared} }} z_; }})) {{ }} else "
         body = self.expr(n.body)
         if (inner and hot and self.unroll and self.unrolled < self.UNROLL_MAX_LOOPS
                 and self._nodes(n.body) <= self.UNROLL_MAX_NODES):
