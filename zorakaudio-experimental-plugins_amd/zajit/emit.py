@@ -782,7 +782,9 @@ class Emitter:
                         + " ".join(f"const double {start[v]} = {self.var_ref(v)};" for v in ind)
                         + " " + " ".join(f"double {part[a]} = 0.0;" for a in accs)
                         # (one trip per loop iteration: four per iteration -- the group's loads in flight together, as the map loops
-                        #  do -- was measured and is slower: DOT 147 -> 179 ms, TSEQ 2204 -> 2256 ms at 1024 x 48 000)
+                        #  do -- was measured and is slower: DOT 147 -> 179 ms, TSEQ 2204 -> 2256 ms at 1024 x 48 000; again at one instance
+                        #  per wavefront with the arena load's bounds check branch-free / as a branch, 1 / 4 trips, 12 000 frames: TSEQ 436 /
+                        #  462 (shipped) / 463 / 489 ms, DOT 38.9 / 34.8 (shipped) / 39.2 / 34.9 ms)
                         + f" for (int64_t {k} = s.rep_i; {k} < {c}; {k} += s.rep_n) {{ {seti(k)} (void)({body_r}); }} "
                         + " ".join(f"{part[a]} = za_coop_sum(s, {part[a]});" for a in accs)
                         + " " + " ".join(f"{self.var_ref(a)} = {self.var_ref(a)} + {part[a]};" for a in accs)
