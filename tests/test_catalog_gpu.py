@@ -360,6 +360,19 @@ def test_map_loops_on_replica_lanes(ipw, monkeypatch):
         assert high[i] == p.mem_high, (i, high[i], p.mem_high)
 
 
+@pytest.mark.parametrize("leaf,n,want", [("fx_stft", 1024, 1), ("fx_stft", 2048, 2), ("fx_stft", 8192, 8), ("fx_coopkat", 512, 1),
+                                         ("fx_fftbench_full", 256, 1), ("fx_fftbench_full", 1024, 4)])
+def test_replica_lane_leaves_are_given_a_wavefront_count(leaf, n, want, monkeypatch):
+    """csrc/zabatch.hip: leaves with cooperative transforms / shared loops on their audio path run on ~1024 wavefronts (~256 when
+    each holds a 64 KB transform buffer), from ONE instance per wavefront up."""
+    import zabatch
+    monkeypatch.delenv("ZAB_IPW", raising=False)
+    monkeypatch.delenv("ZAB_FFT_WAVES", raising=False)
+    with zabatch.Engine(leaf, n) as e:
+        e.set_sliders(zabatch.leaf_meta(leaf)["default_sliders"]); e.prepare()
+        assert e.launch_shape()[0] == want
+
+
 def test_modulo_shortcuts_match_the_division():
     """csrc/zart.h za_mod: the device skips the integer division for 0 <= l < r, l == r and power-of-two divisors; the CPU port
     always divides. tests/fixtures/modkat.jsfx walks counters through divisors of every sign (and zero) -- the accumulated sum
