@@ -55,7 +55,13 @@ __device__ __forceinline__ void za_state_bind(SS& s, const ZabBatch& b, int inst
   s.midi_bus = 0.0;
   s.ext_midi_bus = 0.0;
   s.mem = b.mem + (int64_t)inst * b.mem_si;
+#if defined(ZA_MEM_STRIDE1)
+  // (replica-lane leaves are always laid out instance-major -- zajit/build.py sets this for them, zabatch.hip keeps the layout:
+  //  the 64-bit multiply of every arena address by a run-time stride of 1 is four quarter-rate instructions per access)
+  s.mem_stride = 1;
+#else
   s.mem_stride = b.mem_se;
+#endif
   s.mem_cap = b.mem_cap;
   s.mem_high = b.mem_high[inst];
   s.mem_need = b.mem_need[inst];
@@ -75,7 +81,11 @@ __device__ __forceinline__ void za_state_bind(SS& s, const ZabBatch& b, int inst
   s.sink = 0.0;
   s.memtop = ZA_MEMTOP;
   s.fft = b.fft ? b.fft + (int64_t)inst * b.fft_si : nullptr;
+#if defined(ZA_MEM_STRIDE1)
+  s.fft_stride = 1;
+#else
   s.fft_stride = b.fft_se;
+#endif
   s.fft_cap = b.fft ? b.fft_cap : 0;
   s.gmem_attached = b.gmem_att ? b.gmem_att[inst] : 0;
   s.replica = 0;

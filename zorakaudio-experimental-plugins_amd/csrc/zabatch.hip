@@ -324,7 +324,7 @@ int zab_create(const char* module, const zab_config* cfg, zab_engine** out) {
   }
   if (const char* f = getenv("ZAB_FORCE_LAYOUT")) {     // experiments only: "im" / "il" overrides the module's preference
     if (!strcmp(f, "im")) b.instance_major = 1;
-    if (!strcmp(f, "il")) b.instance_major = 0;
+    if (!strcmp(f, "il") && m->prefer_instance_major < 2) b.instance_major = 0;     // (>= 2: compiled for contiguous arenas, ZA_MEM_STRIDE1)
   }
   b.mem_cap = cfg->mem_cap > 0 ? cfg->mem_cap : m->default_mem_cap;
   if (b.mem_cap > 2147483520ll - 1024) {   // device addresses are converted with one 32-bit instruction (zart.h za_addr1)

@@ -127,7 +127,10 @@ def module_source(unit: codegen.Unit) -> str:
     nch = int(unit.defines["ZA_NCH"])
     plan, _why = tpar_plan(unit)
     alias = " ".join(f"X({k}, {p.vars[v]})" for k, v in sorted(p.aliases.items()) if v in p.vars)
-    lines = [f"// generated by zajit.build for leaf {name}; do not edit", unit.preamble(),
+    from .emit import FFT_CALLS
+    fft_hot = bool(_hot_calls(p) & set(FFT_CALLS)) or (unit.defines.get("ZA_USES_COOP") == "1" and "gmem" not in unit.features)   # replica lanes
+    lines = [f"// generated by zajit.build for leaf {name}; do not edit", unit.preamble()
+             + ("#define ZA_MEM_STRIDE1 1\n" if fft_hot else ""),      # arenas contiguous per instance, always (zab_generic.hip.h)
              f"#define ZA_KERNEL(x) zab_{_cid(name)}_##x",
              f"#define ZA_FOR_CH(X) {' '.join(f'X({c})' for c in range(nch))}",
              f"#define ZA_FOR_ALIAS(X) {alias}",
@@ -164,8 +167,6 @@ def module_source(unit: codegen.Unit) -> str:
     lines.append("  ZA_HAS_INIT, ZA_HAS_SLIDER, ZA_HAS_BLOCK, ZA_HAS_SAMPLE,")
     # leaves with FFT builtins on the audio path (@sample / @block): the wave-cooperative transforms stream one instance's
     # buffer with all lanes, so it must be contiguous (a leaf that only transforms in @init/@slider stays interleaved)
-    from .emit import FFT_CALLS
-    fft_hot = bool(_hot_calls(p) & set(FFT_CALLS)) or (unit.defines.get("ZA_USES_COOP") == "1" and "gmem" not in unit.features)   # replica lanes
     # (2 = instance-major AND thin wavefronts with replica lanes while the batch is small, see zabatch.hip / zab_generic)
     # leaves whose time-parallel kernel reads delay lines: 64 consecutive frames of ONE instance per access, so its arena must be
     # contiguous (interleaved, those 64 reads would touch 64 cache lines)
