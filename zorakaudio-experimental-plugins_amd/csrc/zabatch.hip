@@ -595,7 +595,7 @@ static hipError_t launch_span(zab_engine* e, const ZabAudio& a, bool fast) {
       ab.in = a.in ? a.in + pos : nullptr;
       ab.out = a.out ? a.out + pos : nullptr;
       ab.frames = (a.frames - pos < a.block) ? (a.frames - pos) : a.block;
-      he = e->mod->launch_process(&e->b, &ab, e->stream);
+      he = fast ? e->mod->launch_fast(&e->b, &ab, e->stream) : e->mod->launch_process(&e->b, &ab, e->stream);
       if (he == hipSuccess) he = e->mod->launch_msg_flush(&e->b, e->stream);
       e->launches += 2;
     }

@@ -60,6 +60,42 @@ __device__ __forceinline__ double zt_dppz(double v) {
   return __builtin_bit_cast(double, t);
 }
 
+// "This frame left the variable alone" (zajit/tpar.py HOLD): a variable whose incoming value no path of @sample can read has no
+// state-in node; where a frame does not write it, its value is this marker -- a quiet NaN that no arithmetic produces (payload
+// in the low word, which a float -> double conversion leaves zero) and that only ever moves through selects.
+#define ZT_HOLD __builtin_bit_cast(double, (uint64_t)0x7FF800005A5A5A5AULL)
+__device__ __forceinline__ bool zt_is_hold(double v) { return __builtin_bit_cast(uint64_t, v) == 0x7FF800005A5A5A5AULL; }
+
+// wave-wide minimum / maximum of a 64-bit integer (rare paths: conditional writes)
+__device__ __forceinline__ int64_t zt_wave_min_i64(int64_t v) {
+  for (int off = 1; off < 64; off <<= 1) { const int64_t o = __shfl_xor(v, off, 64); v = o < v ? o : v; }
+  return v;
+}
+__device__ __forceinline__ int64_t zt_wave_max_i64(int64_t v) {
+  for (int off = 1; off < 64; off <<= 1) { const int64_t o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
+  return v;
+}
+// A chunk's delay-line write covers [s0, s0 + k) and, after a ring's wrap, [s1, s1 + m). Do two writes touch one cell?
+__device__ __forceinline__ bool zt_range_meet(int64_t a, int64_t na, int64_t b, int64_t nb) {
+  return na > 0 && nb > 0 && a < b + nb && b < a + na;
+}
+__device__ __forceinline__ bool zt_spans_meet(int64_t s0a, int64_t ka, int64_t s1a, int64_t ma, int64_t s0b, int64_t kb, int64_t s1b,
+                                              int64_t mb) {
+  return zt_range_meet(s0a, ka, s0b, kb) || zt_range_meet(s0a, ka, s1b, mb) || zt_range_meet(s1a, ma, s0b, kb) ||
+         zt_range_meet(s1a, ma, s1b, mb);
+}
+__device__ __forceinline__ bool zt_span_hits(int64_t s, int64_t n, int64_t lo, int64_t hi) { return n > 0 && s <= hi && lo < s + n; }
+// Per-trip cells of a uniform loop: address expression 0 visits a0 + k * s0 (range [lo0, hi0]), expression 1 a1 + k * s1. They
+// never name one cell if their ranges are disjoint, or they walk in step through interleaved records (same stride, first
+// addresses that differ by less than a multiple of it). An empty range (no trips) meets nothing.
+__device__ __forceinline__ bool zt_sites_ok(int64_t a0, int64_t s0, int64_t lo0, int64_t hi0, int64_t a1, int64_t s1, int64_t lo1,
+                                            int64_t hi1) {
+  if (hi0 < lo0 || hi1 < lo1) return true;
+  if (hi0 < lo1 || hi1 < lo0) return true;
+  if (s0 != s1 || s0 == 0) return false;
+  return (a1 - a0) % s0 != 0;
+}
+
 // value of the previous lane; lane 0 receives `first` (the value carried in from the previous chunk)
 __device__ __forceinline__ double zt_shift1(double v, double first) { return zt_dpp<ZT_WAVE_SHR1, 0xF>(v, first); }
 

@@ -47,6 +47,8 @@ LEAF_FLAGS = {"fx_dynkat_s1": ["-DZT_SPEC_MAX=1"],       # test variant: switche
               # FFT builtins with the whole 4096-point transform in LDS (zart_fft.h: ZA_FFT_LDS_POINTS; default 1024 + slicing)
               "fx_fftkat_full": ["-DZA_FFT_LDS_POINTS=4096"], "fx_fftbench_full": ["-DZA_FFT_LDS_POINTS=4096"],
               "Roomalizer": ["-DZA_LD_BRANCH"], "TSEQ": ["-DZA_LD_BRANCH"], "DOT": ["-DZA_LD_BRANCH"], "DPT": ["-DZA_LD_BRANCH"]}
+# leaves that could take a time-parallel kernel but keep the generic one, with the reason (measured)
+NO_TPAR: Dict[str, str] = {}
 # leaves whose state the hand-written kernel wants contiguous per instance
 INSTANCE_MAJOR = {"DDT"}
 
@@ -109,15 +111,14 @@ def _hot_calls(prog) -> set:
 
 
 def tpar_plan(unit: codegen.Unit):
-    """Time-parallel plan of the leaf's @sample (zajit/tpar.py), or (None, reason). Leaves with a hand-written kernel keep it;
-    scripts that raise slider masks need the generic kernel's per-block @slider check."""
+    """Time-parallel plan of the leaf's @sample (zajit/tpar.py), or (None, reason). Leaves with a hand-written kernel keep it."""
     from . import tpar
     if os.environ.get("ZA_NO_TPAR"):
         return None, "disabled (ZA_NO_TPAR)"
     if unit.prog.name in FAST_KERNELS:
         return None, "hand-written kernel"
-    if "sliderchange" in unit.features:
-        return None, "script raises slider masks"
+    if unit.prog.name in NO_TPAR:
+        return None, NO_TPAR[unit.prog.name]
     return tpar.try_plan(unit.prog, int(unit.defines["ZA_NCH"]))
 
 
@@ -170,7 +171,7 @@ def module_source(unit: codegen.Unit) -> str:
     # (2 = instance-major AND thin wavefronts with replica lanes while the batch is small, see zabatch.hip / zab_generic)
     # leaves whose time-parallel kernel reads delay lines: 64 consecutive frames of ONE instance per access, so its arena must be
     # contiguous (interleaved, those 64 reads would touch 64 cache lines)
-    tp_mem = plan is not None and bool(plan.loads or plan.stores)
+    tp_mem = plan is not None and bool(plan.loads or plan.stores or any(L.cells for L in plan.loops))
     # (3 = thin wavefronts like 2, but the kernel has no replica lanes: gmem users, zab_generic.hip.h ZA_REPLICAS)
     lines.append(f"  {(3 if 'gmem' in unit.features else 2) if fft_hot else (1 if (name in INSTANCE_MAJOR or tp_mem) else 0)}, 65536, za_var_names, {2 * 32768 if 'fft' in unit.features else 0}, {(2 if p.options.get('gmem') else 1) if 'gmem' in unit.features else 0}, {1 if 'pool' in unit.features else 0}, {1 if 'file' in unit.features else 0}, {(2 if 'msgbuf' in unit.features else 1) if 'msg' in unit.features else 0},")
     lines.append("  za_launch_prepare, za_launch_process, za_launch_slider,")

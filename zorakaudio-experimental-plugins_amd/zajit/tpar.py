@@ -1,32 +1,42 @@
 """Time-parallel lowering of a leaf's @sample section: ONE WAVEFRONT PER INSTANCE, lane = frame.
 
-The generic kernels (csrc/zab_generic.hip.h) run a script the way jsfx_process_block does (dsp_jsfx_aot.py:5814-5899): one
-frame after the other, one lane per instance. Most of a dynamics / filter script is not serial in time at all, though. This
-module proves which parts are, per leaf, and emits a second kernel `zab_<leaf>_tpar` that processes 64 consecutive frames
-of one instance at once:
+The generic kernels (csrc/zab_generic.hip.h) run a script the way jsfx_process_block does (dsp_jsfx_aot.py:5785-5899): host
+block after host block -- @block, the pending-mask @slider check -- and inside a block one frame after the other, one lane
+per instance. Most of a dynamics / filter script is not serial in time at all, though. This module proves which parts are,
+per leaf, and emits a second kernel `zab_<leaf>_tpar` that keeps the block structure (the wavefront runs @block and @slider
+itself between the blocks, with the leaf's ordinary section code) and processes the frames of a block 64 at a time:
 
   1. @sample (user functions inlined, conditionals if-converted) becomes a DAG over the values of ONE frame: inputs
-     spl0.., invariants (variables / sliders that @sample never writes: they change only in @slider / @init), constants,
-     and `state-in` nodes -- the value a variable written by @sample had at the end of the PREVIOUS frame.
+     spl0.., invariants (variables / sliders that @sample never writes: they change only in @block / @slider / @init, i.e.
+     between blocks), constants, and `state-in` nodes -- the value a variable written by @sample had at the end of the
+     PREVIOUS frame. A variable whose incoming value no path of @sample can observe (every read follows a write of the same
+     frame) has no state-in at all: where a frame leaves it alone it carries a HOLD marker, and only its last written value
+     is tracked.
   2. The cross-frame edges out(v)[t-1] -> state-in(v)[t] close cycles. Strongly connected components of that graph are
      the true recurrences; everything else is feed-forward in time and runs one lane per frame.
        * no cycle through state-in(v) ......... v is a delayed signal: a one-lane shift of out(v) (DPP wave_shr),
        * a cycle that is AFFINE in its states .. y[t] = A[t] y[t-1] + b[t] with A, b free of y (one-poles, leaky
          integrators, counters, sample-and-hold `c ? y = x`, biquads as 2x2): a weighted prefix scan over the wavefront
          with DPP row_shr / row_bcast moves (the scheme of the hand-written DDT kernel, csrc/kernels/ddt_fast.hip.h:98-108),
-       * anything else (attack/release smoothers whose coefficient depends on the state, hold counters, ...): the
-         minimal cycle runs as a uniform 64-step loop, inputs broadcast with v_readlane, independent cycles that are ready
-         at the same time share one loop (instruction-level parallelism instead of lanes).
-     In every case the component only has to deliver state-in(v) per lane; all nodes of the frame, the components' own
-     included, are then evaluated one lane per frame with the script's own expressions.
-  3. Values that depend on invariants only are computed once per launch.
+       * affine once its state-dependent conditions are fixed (attack/release smoothers, holds): fixed-point iteration of
+         the condition pattern,
+       * anything else: the minimal cycle runs as a uniform 64-step loop, inputs broadcast with v_readlane.
+  3. loop() / while whose trip count is the same in every frame run as UNIFORM loops: trip k of all 64 frames together, then
+     trip k + 1. Counters are wave-uniform, variables handed from trip to trip are per-lane values, and mem[] at addresses
+     that depend on the counters only are PER-TRIP CELLS -- band k's filter state -- whose recurrence over the frames is
+     classified and solved inside the trip exactly like a top-level one (the band loops of ERBTilt, SpectralStabilizer,
+     EasyExpander, CMD). Reads at moving addresses inside such a loop are gathers (FIR taps into a ring: TSEQ, DOT).
+  4. Values that depend on invariants only are computed once per host block.
 
-The state a launch leaves in vars[] / spl[] is what the serial path leaves: every variable @sample writes holds its value
-at the last frame. Affine components differ from the serial order of operations by re-association only (O(1e-16)
-relative), checked by the same reference-VM fixtures as the generic path (tests/test_tpar.py, tests/test_catalog_gpu.py).
+The state a launch leaves in vars[] / spl[] / mem[] is what the serial path leaves. Affine components differ from the serial
+order of operations by re-association only (O(1e-16) relative), checked by the same reference-VM fixtures as the generic
+path (tests/test_tpar.py, tests/test_catalog_gpu.py). Everything the lowering assumes but cannot prove (distinct address
+expressions address distinct cells, delay lines advance by one cell per frame, rare-event guards stay false) is checked at
+run time; a launch that breaks an assumption is handed, from that point on, to the serial section code
+(`zab_<leaf>_tpar_tail`).
 
 `Plan.simulate` is a numpy restatement of the staged algorithm (one array element per lane) used by the CPU tests to pin
-the analysis itself -- classification, coefficients, carries, partial chunks -- without a GPU.
+the analysis itself -- classification, coefficients, carries, partial chunks, loops -- without a GPU.
 """
 from __future__ import annotations
 
@@ -42,6 +52,8 @@ from .program import Program, is_slider_name, is_spl_name
 
 WAVE = 64
 RNG_INDEX = "rand#index"      # hidden state: MT19937 outputs consumed since the start of the launch
+HOLD_BITS = 0x7FF800005A5A5A5A   # "this frame left the variable alone": a quiet NaN no arithmetic produces (payload in the low
+HOLD = np.array([HOLD_BITS], dtype=np.uint64).view(np.float64)[0]   # word, which a float -> double conversion leaves zero)
 
 
 class Unsupported(Exception):
@@ -49,18 +61,20 @@ class Unsupported(Exception):
 
 
 class N:
-    __slots__ = ("i", "kind", "op", "args", "val", "name", "uniform", "su", "extra")
+    __slots__ = ("i", "kind", "op", "args", "val", "name", "uniform", "su", "extra", "loop")
 
     def __init__(self, i, kind, op=None, args=(), val=None, name=None):
         self.i, self.kind, self.op, self.args, self.val, self.name = i, kind, op, tuple(args), val, name
         self.uniform = False
-        self.su = False          # built from constants and variables @sample never assigns: constant over a launch (known while walking)
+        self.su = False          # wave-uniform, known while walking: built from constants, variables @sample never assigns and
+        #                          uniform loop counters
         self.extra = ()          # ld: nodes this load must wait for besides its address (the stores it may have to forward from)
+        self.loop = None         # innermost uniform loop this node's value changes in (None: once per frame)
 
     def __repr__(self):
         if self.kind == "const":
             return f"#{self.i}:{self.val!r}"
-        if self.kind in ("var", "inv", "st", "in"):
+        if self.kind in ("var", "inv", "st", "in", "hold", "phi", "lout", "lcin"):
             return f"#{self.i}:{self.kind}({self.name})"
         if self.kind == "ld":
             return f"#{self.i}:ld({self.args[0].i})"
@@ -73,11 +87,194 @@ MT_N, MT_M = 624, 397
 CALL2 = set(PURE_MATH2) | {"min", "max"}
 
 
+class LoopInfo:
+    """One uniform loop of the frame: every frame runs the same number of trips, so the wavefront runs trip k of all of its
+    frames together."""
+
+    def __init__(self, lid, parent):
+        self.id = lid
+        self.parent: Optional["LoopInfo"] = parent
+        self.depth = 1 + (parent.depth if parent is not None else 0)
+        self.count: Optional[N] = None           # loop(n): the count node (evaluated once, before the first trip)
+        self.cond: Optional[N] = None            # while: the condition, in terms of this loop's phis
+        self.order: List[str] = []               # loop-carried names, order of first appearance
+        self.phis: Dict[str, N] = {}
+        self.init: Dict[str, N] = {}
+        self.next: Dict[str, N] = {}
+        self.louts: Dict[str, N] = {}
+        self.cells: Dict[str, N] = {}            # "lmem@<id>" -> address node (wave-uniform, changes from trip to trip)
+        self.cin: Dict[str, N] = {}              # -> the cell's value before this frame
+        self.cell_out: Dict[str, N] = {}         # -> the value this frame stores (cells the loop never stores to: absent)
+        self.cell_flag: Dict[str, N] = {}        # -> "a store to this cell ran in this frame" (the arena's high-water mark)
+        self.children: List["LoopInfo"] = []
+
+    def inside(self, other: Optional["LoopInfo"]) -> bool:
+        """self is `other` or nested in it (other None: the frame itself)."""
+        x = self
+        while x is not None:
+            if x is other:
+                return True
+            x = x.parent
+        return other is None
+
+
+def _deeper(a: Optional[LoopInfo], b: Optional[LoopInfo]) -> Optional[LoopInfo]:
+    if a is None:
+        return b
+    if b is None:
+        return a
+    return a if a.depth >= b.depth else b
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# 0. passes over the syntax tree: rare-event guards, variables whose incoming value is observable
+# ----------------------------------------------------------------------------------------------------------------------
+def _reachable_fns(prog: Program, roots) -> List[str]:
+    seen, todo = [], list(roots)
+    while todo:
+        x = todo.pop()
+        if isinstance(x, S.Call) and x.fn in prog.fns and x.fn not in seen:
+            seen.append(x.fn)
+            todo.append(prog.fns[x.fn].body)
+        todo.extend(S.children(x))
+    return seen
+
+
+def _assigned_names(prog: Program, roots, shadow=()) -> set:
+    """Variables assigned by `roots` or a function they can reach (parameters of those functions are their own)."""
+    out = set()
+    seen = set()
+
+    def walk(x, sh):
+        if isinstance(x, S.Assign) and isinstance(x.target, S.Var) and x.target.name not in sh:
+            out.add(x.target.name)
+        if isinstance(x, S.Call) and x.fn in prog.fns and x.fn not in seen:
+            seen.add(x.fn)
+            walk(prog.fns[x.fn].body, frozenset(prog.fns[x.fn].params))
+        for c in S.children(x):
+            walk(c, sh)
+
+    for r in roots:
+        walk(r, frozenset(shadow))
+    return out
+
+
+def _read_names(prog: Program, roots) -> set:
+    out, seen, todo = set(), set(), list(roots)
+    while todo:
+        x = todo.pop()
+        if isinstance(x, S.Var):
+            out.add(x.name)
+        if isinstance(x, S.Call) and x.fn in prog.fns and x.fn not in seen:
+            seen.add(x.fn)
+            todo.append(prog.fns[x.fn].body)
+        todo.extend(S.children(x))
+    return out
+
+
+def _pure_scalar(prog: Program, x) -> bool:
+    """An expression over variables and constants only: no memory, no calls with effects, no assignment."""
+    if isinstance(x, (S.Num, S.Var)):
+        return True
+    if isinstance(x, (S.Unary, S.Binary)):
+        return all(_pure_scalar(prog, c) for c in S.children(x))
+    if isinstance(x, S.Call):
+        fn = "fabs" if x.fn == "abs" else x.fn
+        return fn not in prog.fns and fn in (CALL1 | CALL2) and all(_pure_scalar(prog, a) for a in x.args)
+    return False
+
+
+def split_guards(prog: Program):
+    """Top-level statements of @sample of the form `G ? ( ... )` where G reads only variables that nothing else in @sample
+    writes and the body assigns one of them -- the "rebuild when the sample rate changed / a table is dirty" idiom: running the
+    body clears the condition. The lowering takes G to be false (the statements are dropped, so everything they assign stays
+    an invariant); the kernel evaluates every G at the start of each block and hands a launch whose G holds to the serial code.
+    Returns (remaining statements, guard conditions)."""
+    items = list(prog.sections.get("sample", []))
+    if len(items) == 1 and isinstance(items[0], S.Seq):
+        items = list(items[0].items)
+    cand = {k for k, st in enumerate(items)
+            if isinstance(st, (S.Cond, S.If)) and st.els is None and st.then is not None and _pure_scalar(prog, st.cond)
+            and (_assigned_names(prog, [st.then]) & _read_names(prog, [st.cond]))}
+    while cand:
+        rest = [st for k, st in enumerate(items) if k not in cand]
+        wrest = _assigned_names(prog, rest)
+        bad = {k for k in cand if any(is_spl_name(nm) is not None or nm in wrest for nm in _read_names(prog, [items[k].cond]))}
+        if not bad:
+            break
+        cand -= bad
+    return [st for k, st in enumerate(items) if k not in cand], [items[k].cond for k in sorted(cand)]
+
+
+def exposed_vars(prog: Program, stmts) -> set:
+    """Variables whose value from the previous frame some path of the frame can read (a read not preceded, on that path, by a
+    write of the same frame). Mirrors FrameGraph's order of evaluation; conservative (a loop body may run zero times, the
+    right operand of && / || may not run)."""
+    exposed: set = set()
+    depth = [0]
+
+    def ev(x, d: set, sh: frozenset):
+        if isinstance(x, (S.Num, S.Str)):
+            return
+        if isinstance(x, S.Var):
+            if x.name not in sh and x.name not in d:
+                exposed.add(x.name)
+            return
+        if isinstance(x, S.Assign):
+            ev(x.value, d, sh)
+            t = x.target
+            if isinstance(t, S.Var):
+                if x.op != "=" and t.name not in sh and t.name not in d:
+                    exposed.add(t.name)
+                if t.name not in sh:
+                    d.add(t.name)
+            else:
+                for c in S.children(t):
+                    ev(c, d, sh)
+            return
+        if isinstance(x, S.Binary) and x.op in ("&&", "||"):
+            ev(x.l, d, sh)
+            ev(x.r, set(d), sh)
+            return
+        if isinstance(x, (S.Cond, S.If)):
+            ev(x.cond, d, sh)
+            a, b = set(d), set(d)
+            if x.then is not None:
+                ev(x.then, a, sh)
+            if x.els is not None:
+                ev(x.els, b, sh)
+            d |= (a & b)
+            return
+        if isinstance(x, S.Loop):
+            ev(x.count, d, sh)
+            ev(x.body, set(d), sh)
+            return
+        if isinstance(x, S.While):
+            ev(x.cond, d, sh)
+            ev(x.body, set(d), sh)
+            return
+        if isinstance(x, S.Call):
+            for a in x.args:
+                ev(a, d, sh)
+            if x.fn in prog.fns and depth[0] < 40:
+                depth[0] += 1
+                ev(prog.fns[x.fn].body, d, frozenset(prog.fns[x.fn].params))
+                depth[0] -= 1
+            return
+        for c in S.children(x):
+            ev(c, d, sh)
+
+    d: set = set()
+    for st in stmts:
+        ev(st, d, frozenset())
+    return exposed
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # 1. one frame of @sample as a DAG
 # ----------------------------------------------------------------------------------------------------------------------
 class FrameGraph:
-    def __init__(self, prog: Program, nch: int):
+    def __init__(self, prog: Program, nch: int, stmts=None):
         self.p, self.nch = prog, nch
         self.nodes: List[N] = []
         self.memo: Dict[tuple, N] = {}
@@ -87,20 +284,21 @@ class FrameGraph:
         self.scope: List[Dict[str, str]] = []
         self.depth = 0
         self.rand_sites = 0
-        # variables assigned anywhere in @sample (or a function it can reach): everything else is constant over a launch, which
-        # lets the walk tell launch-constant addresses (mem[] cells used as named state) from moving ones (delay lines)
-        self.wsyn = set()
-        todo = list(prog.sections.get("sample", [])) + [f.body for f in prog.fns.values()]
-        while todo:
-            x = todo.pop()
-            if isinstance(x, S.Assign) and isinstance(x.target, S.Var):
-                self.wsyn.add(x.target.name)
-            todo.extend(S.children(x))
+        self.stmts = list(prog.sections.get("sample", [])) if stmts is None else list(stmts)
+        # variables assigned anywhere in @sample (or a function it can reach): everything else is constant over a block, which
+        # lets the walk tell block-constant addresses (mem[] cells used as named state) from moving ones (delay lines)
+        self.wsyn = _assigned_names(prog, self.stmts)
+        self.exposed = exposed_vars(prog, self.stmts)
         self.pred: Optional[N] = None            # path condition of the statement being walked (None: unconditional)
         self.mem_seq = 0                         # program order of the memory operations of a frame
-        self.cells: Dict[str, N] = {}            # "mem@<id>" -> its (launch-constant) address node
+        self.cells: Dict[str, N] = {}            # "mem@<id>" -> its (block-constant) address node
         self.loads: List[N] = []                 # moving-address loads
         self.stores: List["StoreSite"] = []      # moving-address stores
+        self.loops: List[LoopInfo] = []          # every uniform loop of the frame, outer before inner
+        self.loop_stack: List[LoopInfo] = []
+        self.loop_ids = 0
+        self.lcell_addr: Dict[str, N] = {}       # "lmem@<id>" -> address node (cells of uniform loops)
+        self.holds: Dict[str, N] = {}
         self.ZERO, self.ONE = self.const(0.0), self.const(1.0)
 
     # -- node construction -------------------------------------------------------------------------------------------------
@@ -115,6 +313,8 @@ class FrameGraph:
                 n.su = name not in self.wsyn and name != RNG_INDEX and not name.startswith("mem@") and not name.startswith("memw@")
             elif kind == "op":
                 n.su = op != "mtout" and all(a.su for a in args)
+            for a in args:
+                n.loop = _deeper(n.loop, a.loop)
             self.nodes.append(n)
             self.memo[key] = n
         return n
@@ -134,12 +334,26 @@ class FrameGraph:
             return self.scope[-1][name]
         return name
 
+    def _lcell_owner(self, key: str) -> LoopInfo:
+        return self.lcell_addr["lmem@" + key.split("@", 1)[1]].loop
+
     def read(self, name: str) -> N:
         key = self._canon(name)
         if key in self.env:
             return self.env[key]
         if key.startswith("%"):
             raise Unsupported(f"parameter {name} read before it was bound")
+        if key.startswith("lmemw@"):
+            return self.ZERO                                   # no store to this cell yet in this trip
+        if key.startswith("lmem@"):
+            owner = self._lcell_owner(key)
+            n = owner.cin.get(key)
+            if n is None:
+                n = self.mk("lcin", name=key, val=owner.id)
+                n.loop = owner
+                owner.cin[key] = n
+                owner.cells[key] = self.lcell_addr[key]
+            return n
         if key in self.varnodes:
             return self.varnodes[key]
         k = is_spl_name(key)
@@ -150,17 +364,27 @@ class FrameGraph:
         elif key in ("mem", "gmem"):
             raise Unsupported("mem/gmem used as a value")
         elif key == "samplesblock":
-            raise Unsupported("@sample reads samplesblock (per host block)")
+            n = self.mk("var", name=key)                        # (constant over a block)
         else:
             if (is_slider_name(key) is None and key not in ("srate", "midi_bus", "ext_midi_bus", RNG_INDEX) and key not in self.p.vars
                     and key not in self.cells and not key.startswith("memw@")):
                 raise Unsupported(f"unknown variable {key}")
+            if key in self.wsyn and key not in self.exposed and key in self.p.vars:
+                # no path of the frame can observe this variable's incoming value: where the frame leaves it alone it carries
+                # the HOLD marker instead of a state-in node (which would make every conditional temporary a recurrence)
+                n = self.holds.get(key)
+                if n is None:
+                    n = self.holds[key] = self.mk("hold", name=key)
+                return n
             n = self.mk("var", name=key)
         self.varnodes[key] = n
         return n
 
     def write(self, name: str, node: N):
         key = self._canon(name)
+        if key.startswith("lmem@") or key.startswith("lmemw@"):
+            self.env[key] = node
+            return
         if not key.startswith("%"):
             if is_slider_name(key) is not None:
                 raise Unsupported("@sample writes a slider")
@@ -212,18 +436,22 @@ class FrameGraph:
         return self.op("addr", b, i)              # za_addr(base, index) of csrc/zart.h, as a double
 
     def _region(self, a: N) -> tuple:
-        """Launch-constant terms of base + index: accesses that differ in them are taken to address different buffers (checked
+        """Block-constant terms of base + index: accesses that differ in them are taken to address different buffers (checked
         at run time, chunk by chunk: a load that falls into another buffer's freshly written span aborts the fast path)."""
         terms, todo = [], list(a.args)
         while todo:
             x = todo.pop()
             if x.kind == "op" and x.op == "+":
                 todo.extend(x.args)
-            elif x.su and not (x.kind == "const" and x.val == 0.0):
+            elif x.su and x.loop is None and not (x.kind == "const" and x.val == 0.0):
                 terms.append(x.i)
         return tuple(sorted(terms))
 
     def _cell(self, a: N) -> str:
+        if a.loop is not None:                     # changes from trip to trip of a uniform loop: a cell per trip
+            key = f"lmem@{a.i}"
+            self.lcell_addr[key] = a
+            return key
         key = f"mem@{a.i}"
         self.cells[key] = a
         return key
@@ -242,19 +470,114 @@ class FrameGraph:
             self.write(key, v)
             # "has this cell been stored to in this launch": the write high-water mark of the arena moves only for executed
             # stores, and a store under a condition may never run. (An ordinary state: its updates merge like any variable's.)
-            self.write("memw@" + key[4:], self.ONE)
+            self.write(("lmemw@" if key.startswith("lmem@") else "memw@") + key.split("@", 1)[1], self.ONE)
             return
+        if self.loop_stack:
+            raise Unsupported("store to a moving mem[] address inside a loop")
         self.mem_seq += 1
         self.stores.append(StoreSite(len(self.stores), a, v, self.pred, self.mem_seq, self._region(a)))
 
     def v_Index(self, n):
         return self._load(self._address(n))
 
+    # -- uniform loops ----------------------------------------------------------------------------------------------------------
+    def _snapshot(self):
+        return (dict(self.env), list(self.written), list(self.loads), list(self.stores), dict(self.cells), self.mem_seq,
+                self.rand_sites, dict(self.varnodes), list(self.loops), dict(self.lcell_addr), dict(self.holds))
+
+    def _restore(self, s):
+        (self.env, self.written, self.loads, self.stores, self.cells, self.mem_seq, self.rand_sites, self.varnodes, self.loops,
+         self.lcell_addr, self.holds) = (dict(s[0]), list(s[1]), list(s[2]), list(s[3]), dict(s[4]), s[5], s[6], dict(s[7]), list(s[8]),
+                                        dict(s[9]), dict(s[10]))
+
+    def _loop(self, body_ast, count_ast, cond_ast) -> N:
+        """loop(count, body) / while (cond) body as a UNIFORM loop: the trip count must come out the same in every frame of a
+        block (count / cond built from invariants and uniform counters only); variables the body assigns are handed from trip
+        to trip (phi nodes), wave-uniform where their first value and their update are."""
+        count = self.ev(count_ast) if count_ast is not None else None
+        if count is not None and not count.su:
+            raise Unsupported("loop() count differs from frame to frame")
+        roots = [x for x in (body_ast, cond_ast) if x is not None]
+        # (parameters of the enclosing function are locals of this call: their canonical names)
+        carried = sorted({self._canon(nm) for nm in _assigned_names(self.p, roots)})
+        uniform = set(carried)
+        parent = self.loop_stack[-1] if self.loop_stack else None
+        for _attempt in range(64):
+            snap = self._snapshot()
+            self.loop_ids += 1
+            L = LoopInfo(self.loop_ids, parent)
+            L.count = count
+            env0 = self.env
+            self.env = dict(env0)
+            for v in carried:
+                init = env0[v] if v in env0 else (self.ZERO if v.startswith("%") else self.read(v))
+                phi = self.mk("phi", name=v, val=L.id)
+                phi.su = v in uniform and init.su
+                phi.loop = L
+                L.order.append(v)
+                L.phis[v], L.init[v] = phi, init
+                self.env[v] = phi
+            self.loop_stack.append(L)
+            try:
+                if cond_ast is not None:
+                    before = dict(self.env)
+                    L.cond = self.ev(cond_ast)
+                    if len(self.env) != len(before) or any(self.env.get(k) is not v for k, v in before.items()):
+                        raise Unsupported("while condition with side effects")
+                    if not L.cond.su:
+                        raise Unsupported("while condition differs from frame to frame")
+                self.ev(body_ast)
+            finally:
+                self.loop_stack.pop()
+            # cells of this loop are per trip: they leave the environment here
+            for key in [k for k in self.env if (k.startswith("lmem@") or k.startswith("lmemw@")) and self._lcell_owner(k) is L]:
+                node = self.env.pop(key)
+                if key.startswith("lmemw@"):
+                    L.cell_flag["lmem@" + key[6:]] = node
+                else:
+                    L.cell_out[key] = node
+                    L.cells[key] = self.lcell_addr[key]
+            # names the body wrote that were not known as carried (cells of the frame or of an outer loop, the generator's
+            # position): walk again with them
+            extra = [k for k, v in self.env.items() if k not in carried and env0.get(k) is not v]
+            lost = [v for v in uniform if v in L.phis and not (L.init[v].su and self.env[v].su)]
+            if extra or lost:
+                carried = carried + extra
+                uniform = (uniform | set(extra)) - set(lost)
+                self._restore(snap)
+                continue
+            for v in carried:
+                L.next[v] = self.env[v]
+            env1 = dict(env0)
+            for v in carried:
+                if L.next[v] is L.phis[v]:
+                    continue                           # (assigned on no path that was walked)
+                lo = self.mk("lout", name=v, val=L.id)      # (never `su`: it exists only once the loop has run, and what is built
+                lo.loop = parent                            #  from su values is computed in a block's prologue)
+                L.louts[v] = lo
+                env1[v] = lo
+                if not (v.startswith("%") or v.startswith("lmem")) and v not in self.written:
+                    self.written.append(v)
+            self.env = env1
+            self.loops.append(L)
+            if parent is not None:
+                parent.children.append(L)
+            return self.ZERO
+        raise Unsupported("loop analysis did not settle")
+
     def v_Loop(self, n):
-        raise Unsupported("loop() in @sample")
+        r0 = self.rand_sites
+        v = self._loop(n.body, n.count, None)
+        if self.rand_sites != r0:
+            raise Unsupported("rand() inside a loop")
+        return v
 
     def v_While(self, n):
-        raise Unsupported("while in @sample")
+        r0 = self.rand_sites
+        v = self._loop(n.body, None, n.cond)
+        if self.rand_sites != r0:
+            raise Unsupported("rand() inside a loop")
+        return v
 
     def v_FuncDef(self, n):
         raise Unsupported("nested function definition")
@@ -431,6 +754,11 @@ class StoreSite:
 
     def __init__(self, j, addr, value, pred, seq, region):
         self.j, self.addr, self.value, self.pred, self.seq, self.region = j, addr, value, pred, seq, region
+        # "late":   the chunk's writes land after all of its reads; a read takes the value an earlier frame of the chunk
+        #           writes from that frame's lane (store-to-load forwarding),
+        # "early":  written before the reads (which then come from memory): buffers that loops gather from,
+        # "sparse": under a per-frame condition, into a buffer @sample never reads (decimated histories for the UI).
+        self.mode = "late"
 
 
 class Component:
@@ -451,6 +779,21 @@ class Component:
         self.gdep: List[N] = []                  # nodes of A / b that depend on a placeholder, topological order
         self.slice: List[N] = []                 # nodes needed to evaluate the conditions from the states, topological order
         self.inputs: List[N] = []                # everything outside that the unit reads
+        self.reg: "Region" = None
+
+
+class Region:
+    """The frame itself (loop None) or the body of one uniform loop: its nodes, its recurrences, its schedule."""
+
+    def __init__(self, loop: Optional[LoopInfo]):
+        self.loop = loop
+        self.nodes: List[N] = []
+        self.outs: Dict[str, N] = {}             # state name -> node holding its value at the end of a frame
+        self.st: Dict[str, N] = {}               # state name -> its state-in node
+        self.items: List[tuple] = []
+        self.comps: List[Component] = []
+        self.subs: List["Region"] = []
+        self.ext: List[N] = []                   # loop: everything outside that the body (nested loops included) reads
 
 
 class Plan:
@@ -461,243 +804,1747 @@ class Plan:
         self.spl_out: List[N] = []               # per processed channel
         self.st: Dict[str, N] = {}               # state variable -> its state-in node
         self.items: List[tuple] = []             # schedule of one chunk
-        self.uniform: List[N] = []               # per-launch nodes, topological order
+        self.uniform: List[N] = []               # per-block nodes, topological order
         self.invariants: List[N] = []
         self.inputs: List[N] = []
         self.stats: Dict[str, int] = {}
         self.uses_rand = False
-        self.cells: Dict[str, N] = {}            # "mem@<id>" -> launch-constant address node (mem[] used as named state)
+        self.cells: Dict[str, N] = {}            # "mem@<id>" -> block-constant address node (mem[] used as named state)
         self.stores: List[StoreSite] = []        # delay-line writes (moving addresses), program order
         self.loads: List[N] = []                 # delay-line reads
+        self.top: Region = None
+        self.regions: Dict[int, Region] = {}     # loop id -> region
+        self.guards: List[N] = []                # rare-event conditions taken to be false (split_guards)
+        self.holdvars: List[str] = []            # written variables that may carry the HOLD marker at the end of a frame
+        self.has_block = False                   # the kernel runs @block (and the pending-mask @slider) between the blocks
+        self.has_pending = False                 # the script can raise slider masks: pending ones run @slider before a launch
 
-    # ------------------------------------------------------------------------------------------------------------------
-    # numpy restatement of the staged algorithm (tests)
-    # ------------------------------------------------------------------------------------------------------------------
-    def _sim_serial(self, comp: "Component", val, carry, tn):
-        cur = {nm: carry[nm] for nm in comp.names}
-        caps = {nm: np.zeros(WAVE) for nm in comp.names}
-        for t in range(tn):
-            loc: Dict[int, np.float64] = {}
-            for nm in comp.names:
-                caps[nm][t] = cur[nm]
-                loc[self.st[nm].i] = cur[nm]
-            for m in comp.members:
-                if m.kind == "st":
-                    continue
-                ops = []
-                for a in m.args:
-                    if a.i in loc:
-                        ops.append(loc[a.i])
-                    else:
-                        v = val[a.i]
-                        ops.append(v if np.ndim(v) == 0 else v[t])
-                loc[m.i] = np.float64(_np_op(m.op, ops))
-            for nm in comp.names:
-                cur[nm] = loc[self.outs[nm].i]
-        for nm in comp.names:
-            caps[nm][tn:] = cur[nm]
-            val[self.st[nm].i] = caps[nm]
-
-    def simulate(self, vars0: Dict[str, float], x: np.ndarray, sliders=None, srate=48000.0, spl0=None, mt=None, mem=None):
-        """x: [nch, frames] float32. vars0: name -> value before the launch (missing names are 0). mt: (randMT[624], randIndex)
-        before the launch for scripts that call rand(); self.mt_after holds the pair after it. mem: the arena before the launch
-        (numpy doubles) for scripts that touch mem[]; self.mem_after / self.mem_high_after hold it after.
-        Returns (y float32 [nch, frames], vars after {name: value}, spl after {k: value}). Raises TparAbort when a chunk breaks
-        one of the run-time conditions of the delay-line handling (the kernel hands such a launch to the generic kernel)."""
-        memv = np.zeros(1 << 16) if mem is None else np.array(mem, dtype=np.float64)
-        mem_high = 0
-        stream = MtStream(*(mt if mt is not None else (None, 0))) if self.uses_rand else None
-        _MT_CTX[0] = stream
-        x = np.asarray(x, dtype=np.float32)
-        frames = x.shape[1]
-        sliders = np.zeros(64) if sliders is None else np.asarray(sliders, dtype=np.float64)
-        spl_state = dict(spl0 or {})
-
-        def inv_value(name):
-            k = is_slider_name(name)
-            if k is not None:
-                return float(sliders[k - 1])
-            if name == "srate":
-                return float(srate)
-            if name in ("midi_bus", "ext_midi_bus", RNG_INDEX) or name.startswith("memw@"):
-                return 0.0
-            if name in self.cells:
-                a = int(val[self.cells[name].i])
-                return float(memv[a]) if a < len(memv) else 0.0
-            k = is_spl_name(name)
-            if k is not None:
-                return float(spl_state.get(k, 0.0))
-            return float(vars0.get(name, 0.0))
-
-        val: Dict[int, np.ndarray] = {}
-        self.spec_log = []                     # (states, iterations, converged) per switched recurrence and chunk
-        with np.errstate(all="ignore"):
-            for n in self.uniform:
-                if n.kind == "const":
-                    val[n.i] = np.float64(n.val)
-                elif n.kind == "inv":
-                    val[n.i] = np.float64(inv_value(n.name))
-                else:
-                    val[n.i] = _np_op(n.op, [val[a.i] for a in n.args])
-            cell_addr = {name: int(val[a.i]) for name, a in self.cells.items()}
-            if len(set(cell_addr.values())) != len(cell_addr) or any(a >= len(memv) for a in cell_addr.values()):
-                raise TparAbort(0, "mem[] cells alias each other or lie past the arena")
-            carry = {name: np.float64(inv_value(name)) for name in self.st}
-            sites: Dict[int, dict] = {}
-            y = np.zeros_like(x)
-            final_vals: Dict[int, float] = {}
-            lane = np.arange(WAVE)
-            for f0 in range(0, max(frames, 0), WAVE):
-                tn = min(WAVE, frames - f0)
-                last = tn - 1
-                for n in self.inputs:
-                    col = np.zeros(WAVE)
-                    col[:tn] = x[int(n.val), f0:f0 + tn].astype(np.float64)
-                    val[n.i] = col
-                sites.clear()
-                for it in self.items:
-                    kind = it[0]
-                    if kind == "site":
-                        st_: StoreSite = it[1]
-                        A = np.broadcast_to(val[st_.addr.i], (WAVE,)).astype(np.int64)
-                        d = np.diff(A[:tn])
-                        brk = np.flatnonzero(d != 1)
-                        if len(brk) > 1 or A[:tn].min() < 0 or A[:tn].max() >= len(memv):
-                            raise TparAbort(f0, "a delay-line write does not advance by one cell per frame (or leaves the arena)")
-                        k = int(brk[0]) + 1 if len(brk) else tn
-                        sites[st_.j] = {"A": A, "a0": int(A[0]), "k": k, "ak": int(A[k]) if k < tn else 0}
-                        if any(lo <= a <= hi for a in cell_addr.values() for lo, hi in ((A[:tn].min(), A[:tn].max()),)):
-                            raise TparAbort(f0, "a delay line runs over a mem[] cell")
-                    elif kind == "par" and it[1].kind == "ld":
-                        n = it[1]
-                        B = np.broadcast_to(val[n.args[0].i], (WAVE,)).astype(np.int64)
-                        out = np.where(B < len(memv), memv[np.minimum(B, len(memv) - 1)], 0.0)
-                        best = np.full(WAVE, -1)
-                        for st_ in self.stores:
-                            si = sites[st_.j]
-                            tw = np.full(WAVE, -1)
-                            d0 = B - si["a0"]
-                            tw = np.where((d0 >= 0) & (d0 < si["k"]), d0, tw)
-                            d1 = B - si["ak"]
-                            tw = np.where((d1 >= 0) & (d1 < tn - si["k"]), si["k"] + d1, tw)
-                            if ",".join(map(str, st_.region)) != n.name:
-                                if np.any(tw[:tn] >= 0):
-                                    raise TparAbort(f0, "a delay-line read falls into another buffer's freshly written span")
-                                continue
-                            vis = (tw >= 0) & ((tw < lane) | ((tw == lane) & (st_.seq < n.val))) & (tw >= best)
-                            V = np.broadcast_to(val[st_.value.i], (WAVE,)).astype(np.float64)
-                            out = np.where(vis, V[np.clip(tw, 0, WAVE - 1)], out)
-                            best = np.where(vis, tw, best)
-                        if any(np.any(B[:tn] == a) for a in cell_addr.values()):
-                            raise TparAbort(f0, "a delay-line read hits a mem[] cell")
-                        val[n.i] = out
-                    elif kind == "par":
-                        n = it[1]
-                        val[n.i] = np.broadcast_to(_np_op(n.op, [val[a.i] for a in n.args]), (WAVE,)).astype(np.float64)
-                    elif kind == "shift":
-                        name = it[1]
-                        src = np.broadcast_to(val[self.outs[name].i], (WAVE,))
-                        sh = np.empty(WAVE)
-                        sh[0] = carry[name]
-                        sh[1:] = src[:-1]
-                        val[self.st[name].i] = sh
-                    elif kind == "scan":
-                        comp: Component = it[1]
-                        d = len(comp.names)
-                        A = np.stack([np.stack([np.broadcast_to(val[comp.A[r][c].i], (WAVE,)) for c in range(d)]) for r in range(d)])
-                        b = np.stack([np.broadcast_to(val[comp.b[r].i], (WAVE,)) for r in range(d)])
-                        A, b = A.astype(np.float64).copy(), b.astype(np.float64).copy()          # [d,d,64], [d,64]
-                        states = _scan_exclusive(A, b, np.array([carry[nm] for nm in comp.names]))
-                        for r, nm in enumerate(comp.names):
-                            val[self.st[nm].i] = states[r]
-                    elif kind == "serial":
-                        for comp in it[1]:
-                            self._sim_serial(comp, val, carry, tn)
-                    elif kind == "spec":
-                        for comp in it[1]:
-                            d = len(comp.names)
-
-                            def conds_from(states):
-                                loc = {self.st[nm].i: states[r] for r, nm in enumerate(comp.names)}
-                                for m in comp.slice:
-                                    loc[m.i] = np.broadcast_to(_np_op(m.op, [loc[a.i] if a.i in loc else val[a.i] for a in m.args]), (WAVE,))
-                                return [_truthy(np.broadcast_to(loc[c.i] if c.i in loc else val[c.i], (WAVE,))) for c in comp.conds]
-
-                            prev = [np.full(WAVE, carry[nm]) for nm in comp.names]
-                            gs = conds_from(prev)
-                            converged, iters = False, 0
-                            while iters < SPEC_MAX:
-                                iters += 1
-                                loc = {gn.i: np.where(gs[k], 1.0, 0.0) for k, gn in enumerate(comp.gnodes)}
-                                for n in comp.gdep:
-                                    loc[n.i] = _np_op(n.op, [loc[a.i] if a.i in loc else val[a.i] for a in n.args])
-                                gv = lambda n: np.broadcast_to(loc[n.i] if n.i in loc else val[n.i], (WAVE,)).astype(np.float64)
-                                A = np.stack([np.stack([gv(comp.A[r][c]) for c in range(d)]) for r in range(d)]).copy()
-                                b = np.stack([gv(comp.b[r]) for r in range(d)]).copy()
-                                states = _scan_exclusive(A, b, np.array([carry[nm] for nm in comp.names]))
-                                ng = conds_from(states)
-                                changed = any(bool(np.any(x[:tn] != y[:tn])) for x, y in zip(ng, gs))
-                                # a pattern that only still moves where both of its branches agree (a smoother sitting on its
-                                # target, a value on its clamp) leaves the states where they were: that is converged too
-                                moved = any(bool(np.any(np.abs(a[:tn] - b[:tn]) > SPEC_TOL * np.maximum(np.abs(a[:tn]), np.abs(b[:tn]))))
-                                            for a, b in zip(states, prev))
-                                gs, prev = ng, states
-                                if not (changed and moved):
-                                    converged = True
-                                    break
-                            self.spec_log.append((tuple(comp.names), iters, converged))
-                            if converged:
-                                for r, nm in enumerate(comp.names):
-                                    val[self.st[nm].i] = states[r]
-                            else:
-                                self._sim_serial(comp, val, carry, tn)
-                    else:
-                        raise AssertionError(kind)
-                for st_ in self.stores:                    # the chunk's writes land after all of its reads are resolved
-                    si = sites[st_.j]
-                    memv[si["A"][:tn]] = np.broadcast_to(val[st_.value.i], (WAVE,))[:tn]
-                    mem_high = max(mem_high, int(si["A"][:tn].max()) + 1)
-                for ch in range(self.nch):
-                    v = np.broadcast_to(val[self.spl_out[ch].i], (WAVE,))
-                    y[ch, f0:f0 + tn] = v[:tn].astype(np.float32)
-                for name in self.st:
-                    v = val[self.outs[name].i]
-                    carry[name] = np.float64(v if np.ndim(v) == 0 else v[last])
-                if stream is not None:
-                    stream.end_chunk(int(carry[RNG_INDEX]))
-                if f0 + WAVE >= frames:
-                    for name, o in list(self.outs.items()) + [(f"spl{ch}", self.spl_out[ch]) for ch in range(self.nch)]:
-                        v = val[o.i]
-                        final_vals[name] = float(v if np.ndim(v) == 0 else v[last])
-        vars_after = dict(vars0)
-        spl_after = dict(spl_state)
-        self.mt_after = stream.state(int(final_vals.get(RNG_INDEX, 0))) if stream is not None else mt
-        final_vals.pop(RNG_INDEX, None)
-        for name, v in final_vals.items():
-            k = is_spl_name(name)
-            if name.startswith("memw@"):
-                continue
-            if name in self.cells:
-                if final_vals.get("memw@" + name[4:], 0.0) != 0.0:       # stored to at least once in this launch
-                    memv[cell_addr[name]] = v
-                    mem_high = max(mem_high, cell_addr[name] + 1)
-            elif k is not None:
-                spl_after[k] = v
-            else:
-                vars_after[name] = v
-        self.mem_after, self.mem_high_after = memv, mem_high
-        return y, vars_after, spl_after
+    # (numpy restatement: section 4 below)
 
 
 class TparAbort(Exception):
-    """A chunk broke a run-time condition of the delay-line handling at frame `f0`; the kernel stops there and the generic
-    kernel finishes the launch."""
+    """A chunk broke a run-time condition of the lowering at frame `f0`; the kernel stops there and the serial code finishes
+    the launch."""
 
     def __init__(self, f0, why):
         super().__init__(f"frame {f0}: {why}")
         self.f0, self.why = f0, why
 
 
+ULDS_THRESHOLD = 64   # block-constant values beyond which they live in LDS rather than in (spilled) scalar registers
+SPEC_TOL = 1.0e-13    # relative change of a state between two iterations below which it counts as settled (ZT_SPEC_TOL)
+SPEC_MAX = 8          # iterations of a switched recurrence before the chunk falls back to its serial loop (ZT_SPEC_MAX)
+
+
+def _sccs(n_nodes: int, succ: List[List[int]]) -> List[List[int]]:
+    """Tarjan, iterative. Returns the components in reverse topological order."""
+    index = [-1] * n_nodes
+    low = [0] * n_nodes
+    on = [False] * n_nodes
+    stack: List[int] = []
+    out: List[List[int]] = []
+    counter = 0
+    for root in range(n_nodes):
+        if index[root] != -1:
+            continue
+        work = [(root, 0)]
+        while work:
+            v, pi = work.pop()
+            if pi == 0:
+                index[v] = low[v] = counter
+                counter += 1
+                stack.append(v)
+                on[v] = True
+            recurse = False
+            for k in range(pi, len(succ[v])):
+                w = succ[v][k]
+                if index[w] == -1:
+                    work.append((v, k + 1))
+                    work.append((w, 0))
+                    recurse = True
+                    break
+                if on[w]:
+                    low[v] = min(low[v], index[w])
+            if recurse:
+                continue
+            if low[v] == index[v]:
+                comp = []
+                while True:
+                    w = stack.pop()
+                    on[w] = False
+                    comp.append(w)
+                    if w == v:
+                        break
+                out.append(comp)
+            if work:
+                u = work[-1][0]
+                low[u] = min(low[u], low[v])
+    return out
+
+
+def _in_subtree(n: N, loop: Optional[LoopInfo]) -> bool:
+    """n's value changes inside `loop` (or a loop nested in it); loop None: every node."""
+    if loop is None:
+        return True
+    return n.loop is not None and n.loop.inside(loop)
+
+
+def build_plan(prog: Program, nch: int) -> Plan:
+    """Raises Unsupported when the leaf cannot take the time-parallel kernel."""
+    if not prog.has("sample") or nch <= 0:
+        raise Unsupported("no audio @sample")
+    if os.environ.get("ZA_TPAR_NO_BLOCK") and prog.has("block"):
+        raise Unsupported("@block present")
+    stmts, guard_asts = (list(prog.sections["sample"]), []) if os.environ.get("ZA_TPAR_NO_GUARDS") else split_guards(prog)
+    g = FrameGraph(prog, nch, stmts)
+    guards = [g.ev(c) for c in guard_asts]
+    if any(not x.su for x in guards) or g.env:
+        raise Unsupported("guard condition is not an invariant")
+    for st in stmts:
+        g.ev(st)
+    if g.scope or g.loop_stack:
+        raise AssertionError("scope leak")
+    if g.rand_sites * WAVE > MT_N:
+        raise Unsupported("more rand() calls per chunk than one generation of the generator holds")
+    plan = Plan()
+    plan.g, plan.nch = g, nch
+    plan.has_block = prog.has("block")
+    plan.has_pending = prog.uses("sliderchange", "slider_automate")
+    plan.guards = guards
+    written = list(g.written)
+    # variables @sample leaves as they were (x = x) are not state
+    for name in list(written):
+        vn = g.varnodes.get(name) or g.holds.get(name)
+        if vn is not None and g.env.get(name) is vn:
+            written.remove(name)
+    wset = set(written)
+    for name, vn in g.varnodes.items():
+        if vn.kind == "var":
+            vn.kind = "st" if name in wset else "inv"
+    plan.outs = {name: g.env[name] for name in written}
+    plan.spl_out = [g.env.get(f"spl{ch}", None) or g.read(f"spl{ch}") for ch in range(nch)]
+    plan.st = {name: vn for name, vn in g.varnodes.items() if vn.kind == "st"}
+    plan.cells = dict(g.cells)
+    plan.stores, plan.loads = list(g.stores), list(g.loads)
+
+    hold_memo: Dict[int, bool] = {}
+
+    def may_hold(n: N) -> bool:
+        if n.i in hold_memo:
+            return hold_memo[n.i]
+        hold_memo[n.i] = False
+        r = False
+        if n.kind == "hold":
+            r = True
+        elif n.kind == "op" and n.op == "sel":
+            r = may_hold(n.args[1]) or may_hold(n.args[2])
+        elif n.kind in ("lout", "phi"):
+            L = loop_by_id[n.val]
+            r = may_hold(L.init[n.name]) or may_hold(L.next[n.name])
+        hold_memo[n.i] = r
+        return r
+
+    loop_by_id = {L.id: L for L in g.loops}
+    plan.holdvars = [name for name in written if may_hold(plan.outs[name])]
+    for name in plan.holdvars:
+        if name in plan.st or name.startswith("mem") or name == RNG_INDEX:
+            raise AssertionError(f"{name}: HOLD marker on a state")
+
+    # ---- delay-line writes: how each lands -------------------------------------------------------------------------------------
+    def reaches_load(n: N, memo: Dict[int, bool]) -> bool:
+        if n.i in memo:
+            return memo[n.i]
+        memo[n.i] = False
+        r = n.kind in ("ld", "lout", "lcin") or any(reaches_load(a, memo) for a in n.args)
+        memo[n.i] = r
+        return r
+
+    for ld in plan.loads:
+        ld.name = ",".join(map(str, g._region(ld.args[0])))
+    rl_memo: Dict[int, bool] = {}
+    for st_ in plan.stores:
+        reg = ",".join(map(str, st_.region))
+        same = [ld for ld in plan.loads if ld.name == reg]
+        if sum(1 for o in plan.stores if o.region == st_.region) > 1:
+            raise Unsupported("two writes into one delay line per frame")
+        if st_.pred is not None and not st_.pred.su:
+            if same:
+                raise Unsupported("conditional store to a delay line that @sample reads")
+            st_.mode = "sparse"
+        elif (any(ld.loop is not None for ld in same) and all(ld.val > st_.seq for ld in same)
+              and not reaches_load(st_.addr, rl_memo) and not reaches_load(st_.value, rl_memo)
+              and not os.environ.get("ZA_TPAR_NO_EARLY")):
+            st_.mode = "early"
+    if plan.stores and g.loops and any(L.cell_out for L in g.loops):
+        raise Unsupported("delay lines together with per-trip cells (a hand-back could not undo the cells' stores)")
+    for ld in plan.loads:
+        # a load may have to take its value from a store of this chunk: it waits for every store of its own buffer (address
+        # and value) and, for the aliasing check, for the addresses of all the others
+        ex = []
+        for st_ in plan.stores:
+            ex.append(st_.addr)
+            if st_.pred is not None:
+                ex.append(st_.pred)
+            if st_.mode == "early" or ",".join(map(str, st_.region)) == ld.name:
+                ex.append(st_.value)
+        ld.extra = tuple(ex)
+    if plan.loads and g.loops and any(L.cell_out for L in g.loops):
+        raise Unsupported("gathers together with per-trip cells")
+
+    # ---- live nodes -------------------------------------------------------------------------------------------------------------
+    live: Dict[int, N] = {}
+    live_loops: Dict[int, LoopInfo] = {}
+    todo = list(plan.outs.values()) + list(plan.spl_out) + list(guards)
+    todo += [x for st_ in plan.stores for x in (st_.addr, st_.value) + ((st_.pred,) if st_.pred is not None else ())]
+    todo += [a for a in plan.cells.values()]
+
+    def loop_live(L: LoopInfo):
+        while L is not None and L.id not in live_loops:
+            live_loops[L.id] = L
+            if L.count is not None:
+                todo.append(L.count)
+            if L.cond is not None:
+                todo.append(L.cond)
+            for key, o in L.cell_out.items():
+                todo.extend((o, L.cells[key]))
+                if key in L.cell_flag:
+                    todo.append(L.cell_flag[key])
+            L = L.parent
+
+    for L in g.loops:
+        if L.cell_out:
+            loop_live(L)
+    while todo:
+        n = todo.pop()
+        if n.i in live:
+            continue
+        live[n.i] = n
+        todo.extend(n.args)
+        todo.extend(n.extra)
+        if n.loop is not None:
+            loop_live(n.loop)
+        if n.kind == "st":
+            todo.append(plan.outs[n.name])
+        elif n.kind in ("phi", "lout"):
+            L = loop_by_id[n.val]
+            loop_live(L)
+            todo.extend((L.init[n.name], L.next[n.name]))
+        elif n.kind == "lcin":
+            L = loop_by_id[n.val]
+            loop_live(L)
+            todo.append(L.cells[n.name])
+            if n.name in L.cell_out:
+                todo.append(L.cell_out[n.name])
+    loops = [L for L in g.loops if L.id in live_loops]
+    loops.sort(key=lambda L: (L.depth, L.id))
+    for L in loops:
+        # (a per-trip cell takes its identity from its address EXPRESSION; that two expressions never name one cell is checked
+        #  at run time, zt_sites_ok, for addresses that step evenly through the trips of ONE loop)
+        if L.depth > 1 and L.cells:
+            raise Unsupported("per-trip cells in a nested loop")
+    plan.loops = loops
+    plan.loop_by_id = loop_by_id
+
+    # ---- regions ----------------------------------------------------------------------------------------------------------------
+    top = Region(None)
+    top.outs, top.st = plan.outs, plan.st
+    regions: Dict[int, Region] = {}
+    for L in loops:
+        r = Region(L)
+        r.outs = dict(L.cell_out)
+        r.st = {key: L.cin[key] for key in L.cell_out if key in L.cin and L.cin[key].i in live}
+        regions[L.id] = r
+        (regions[L.parent.id] if L.parent is not None else top).subs.append(r)
+    plan.top, plan.regions = top, regions
+
+    def region_of(n: N) -> Region:
+        return top if n.loop is None else regions[n.loop.id]
+
+    for i in sorted(live):
+        region_of(live[i]).nodes.append(live[i])
+
+    def sched_deps(n: N) -> tuple:
+        if n.kind == "lcin":
+            return (loop_by_id[n.val].cells[n.name],)
+        if n.kind in ("op", "ld"):
+            return n.args + n.extra
+        return ()
+
+    def loop_ext(r: Region):
+        L = r.loop
+        ext: Dict[int, N] = {}
+
+        def want(x: N):
+            if not _in_subtree(x, L) and x.kind != "const":
+                ext[x.i] = x
+
+        def walk(rr: Region):
+            LL = rr.loop
+            for x in (LL.count, LL.cond):
+                if x is not None:
+                    want(x)
+            for v in LL.order:
+                if LL.phis[v].i in live or (v in LL.louts and LL.louts[v].i in live):
+                    want(LL.init[v])
+                    want(LL.next[v])
+            for key, o in LL.cell_out.items():
+                want(o)
+                want(LL.cells[key])
+                if key in LL.cell_flag:
+                    want(LL.cell_flag[key])
+            for n in rr.nodes:
+                for a in sched_deps(n):
+                    want(a)
+            for s in rr.subs:
+                walk(s)
+
+        walk(r)
+        r.ext = [ext[i] for i in sorted(ext)]
+
+    for r in regions.values():
+        loop_ext(r)
+
+    # ---- recurrences of every region ---------------------------------------------------------------------------------------------
+    comp_of: Dict[int, Component] = {}
+    all_regions = [top] + [regions[L.id] for L in loops]
+    for r in all_regions:
+        nodes = list(r.nodes)
+        pos = {n.i: k for k, n in enumerate(nodes)}
+        pseudo = {s.loop.id: len(nodes) + k for k, s in enumerate(r.subs)}
+        succ: List[List[int]] = [[] for _ in range(len(nodes) + len(r.subs))]
+        for n in nodes:
+            for a in sched_deps(n):
+                if a.i in pos:
+                    succ[pos[a.i]].append(pos[n.i])
+            if n.kind == "lout":
+                succ[pseudo[n.val]].append(pos[n.i])
+            if n.kind in ("st", "lcin") and n.name in r.outs and r.outs[n.name].i in pos and n.name in r.st:
+                succ[pos[r.outs[n.name].i]].append(pos[n.i])
+        for s in r.subs:
+            for x in s.ext:
+                if x.i in pos:
+                    succ[pos[x.i]].append(pseudo[s.loop.id])
+        for comp in _sccs(len(succ), succ):
+            cyclic = len(comp) > 1 or comp[0] in succ[comp[0]]
+            if not cyclic:
+                continue
+            if any(k >= len(nodes) for k in comp):
+                raise Unsupported("a recurrence over the frames runs through a loop")
+            members = sorted((nodes[k] for k in comp), key=lambda n: n.i)
+            if any(m.kind == "ld" for m in members):
+                raise Unsupported("feedback through a delay line (a stored value depends on a load of the same buffer)")
+            names = [m.name for m in members if m.kind in ("st", "lcin")]
+            order = written if r.loop is None else list(r.loop.cell_out)
+            names.sort(key=lambda nm: order.index(nm))
+            c = Component(names, members)
+            c.reg = r
+            for m in members:
+                comp_of[m.i] = c
+            r.comps.append(c)
+
+    # uniform nodes: per block (the frame's) or per trip (a loop's)
+    def set_uniform(n: N):
+        if n.kind in ("const", "inv", "hold"):
+            n.uniform = True
+        elif n.kind in ("st", "in", "ld", "lout", "guess"):
+            n.uniform = False
+        elif n.kind == "phi":
+            n.uniform = n.su
+        elif n.kind == "lcin":
+            n.uniform = n.name not in loop_by_id[n.val].cell_out
+        else:
+            n.uniform = all(a.uniform for a in n.args) and n.i not in comp_of
+
+    for i in sorted(live):
+        set_uniform(live[i])
+    # affine forms
+    for ci, c in enumerate(x for r in all_regions for x in r.comps):
+        _classify(g, c.reg, c, ci, live)
+        if c.kind == "spec" and os.environ.get("ZA_TPAR_NO_SPEC"):
+            c.kind = "serial"
+    # nodes created by the affine analysis: liveness / uniformity of the new coefficient nodes. Placeholder-dependent nodes
+    # and the synthetic compares live inside their unit only.
+    comps_all = [c for r in all_regions for c in r.comps]
+    inside = {x.i for c in comps_all if c.kind == "spec" for x in c.gdep + c.gnodes + c.slice}
+    extra: Dict[int, N] = {}
+    todo = [x for c in comps_all if c.kind in ("scan", "spec") for row in c.A for x in row]
+    todo += [x for c in comps_all if c.kind in ("scan", "spec") for x in c.b]
+    todo += [a for c in comps_all if c.kind == "spec" for x in c.gdep + c.slice for a in x.args]
+    while todo:
+        n = todo.pop()
+        if n.i in live or n.i in extra or n.i in inside:
+            continue
+        extra[n.i] = n
+        todo.extend(n.args)
+    for i in sorted(extra):
+        n = extra[i]
+        live[i] = n
+        set_uniform(n)
+        region_of(n).nodes.append(n)
+    for r in all_regions:
+        r.nodes.sort(key=lambda n: n.i)
+    for r in regions.values():
+        loop_ext(r)                           # (coefficient nodes may read further outside values)
+
+    # ---- schedules -------------------------------------------------------------------------------------------------------------------
+    plan.uniform = [n for n in top.nodes if n.uniform]
+    plan.invariants = [n for n in plan.uniform if n.kind == "inv"]
+    plan.inputs = [n for n in top.nodes if n.kind == "in"]
+    for r in all_regions:
+        _schedule(plan, r, comp_of)
+    plan.items = top.items
+    plan.uses_rand = RNG_INDEX in plan.outs
+
+    def count_items(kind, pred=lambda it: True):
+        return sum(1 for r in all_regions for it in r.items if it[0] == kind and pred(it))
+
+    plan.stats = {
+        "nodes": len(live), "uniform": len(plan.uniform), "par": count_items("par"), "shift": count_items("shift"),
+        "scan1": count_items("scan", lambda it: len(it[1].names) == 1), "scan2": count_items("scan", lambda it: len(it[1].names) == 2),
+        "spec_loops": count_items("spec"),
+        "spec_chains": sum(len(it[1]) for r in all_regions for it in r.items if it[0] == "spec"),
+        "spec_switches": sum(len(c.conds) for r in all_regions for it in r.items if it[0] == "spec" for c in it[1]),
+        "serial_loops": count_items("serial"),
+        "serial_chains": sum(len(it[1]) for r in all_regions for it in r.items if it[0] == "serial"),
+        "serial_ops": sum(len([m for m in c.members if m.kind not in ("st", "lcin")]) for r in all_regions for it in r.items
+                          if it[0] == "serial" for c in it[1]),
+        "states": len(plan.st), "written": len(plan.outs), "rand_sites": g.rand_sites,
+        "mem_cells": len(plan.cells), "delay_writes": len(plan.stores), "delay_reads": len(plan.loads),
+        "loops": len(loops), "trip_cells": sum(len(L.cells) for L in loops), "trip_cells_stored": sum(len(L.cell_out) for L in loops),
+        "gathers": sum(1 for ld in plan.loads if ld.loop is not None and ld.i in live),
+        "holds": len(plan.holdvars), "guards": len(guards),
+        "early_writes": sum(1 for s in plan.stores if s.mode == "early"), "sparse_writes": sum(1 for s in plan.stores if s.mode == "sparse"),
+        "block": int(plan.has_block), "pending": int(plan.has_pending),
+    }
+    return plan
+
+
+def _schedule(plan: Plan, r: Region, comp_of: Dict[int, Component]):
+    """Order of one chunk's work in region r: nodes as soon as their operands exist, scans as soon as their coefficients do,
+    switched / serial recurrences that are ready together in one shared loop, nested loops as single items."""
+    L = r.loop
+    comps = r.comps
+    for c in comps:
+        mem = {m.i for m in c.members}
+        ext, seen = [], set()
+        for m in c.members:
+            for a in m.args:
+                if a.i not in mem and a.i not in seen:
+                    seen.add(a.i)
+                    ext.append(a)
+        c.ext = ext
+        if c.kind == "scan":
+            c.inputs = [x for row in c.A for x in row] + list(c.b)
+        elif c.kind == "spec":
+            own = {x.i for x in c.gdep + c.gnodes + c.slice} | mem
+            ins, seen = list(ext), {x.i for x in ext}
+            for x in [y for row in c.A for y in row] + list(c.b) + [a for y in c.gdep + c.slice for a in y.args]:
+                if x.i not in own and x.i not in seen:
+                    seen.add(x.i)
+                    ins.append(x)
+            c.inputs = ins
+        else:
+            c.inputs = ext
+    done = set()
+
+    def is_done(x: N) -> bool:
+        return x.kind == "const" or x.i in done or not _in_subtree(x, L) or (L is None and x.uniform)
+
+    if L is None:
+        done |= {n.i for n in plan.inputs}
+        pending = [n for n in r.nodes if not n.uniform and n.kind != "in"]
+    else:
+        done |= {n.i for n in r.nodes if n.kind == "phi"}
+        pending = [n for n in r.nodes if n.kind != "phi"]
+    comp_done = {id(c): False for c in comps}
+    sub_done = {s.loop.id: False for s in r.subs}
+    items: List[tuple] = []
+    site_done: set = set()
+    loads_in = {s.loop.id: any(ld.loop is not None and ld.loop.inside(s.loop) for ld in plan.loads) for s in r.subs}
+
+    def flush_sites():
+        for st_ in plan.stores:              # every write's span is known before the first read is resolved
+            if st_.j not in site_done:
+                site_done.add(st_.j)
+                items.append(("site", st_))
+
+    remaining = list(pending)
+    guard = 0
+    while remaining or not all(sub_done.values()):
+        guard += 1
+        if guard > 10 * len(r.nodes) + 100:
+            raise AssertionError("scheduler made no progress")
+        progressed = False
+        nxt = []
+        for n in remaining:
+            if n.kind in ("st", "lcin") and n.name in r.st and r.st[n.name] is n:
+                c = comp_of.get(n.i)
+                if c is None:                              # delayed signal
+                    if is_done(r.outs[n.name]):
+                        items.append(("shift", n.name))
+                        done.add(n.i)
+                        progressed = True
+                    else:
+                        nxt.append(n)
+                elif comp_done[id(c)]:
+                    done.add(n.i)
+                    progressed = True
+                else:
+                    nxt.append(n)
+                continue
+            if n.kind == "lout":
+                if sub_done[n.val]:
+                    done.add(n.i)
+                    progressed = True
+                else:
+                    nxt.append(n)
+                continue
+            deps = (plan.loop_by_id[n.val].cells[n.name],) if n.kind == "lcin" else n.args + n.extra
+            if all(is_done(a) for a in deps):
+                if n.kind == "ld" and L is None:
+                    flush_sites()
+                items.append(("par", n))
+                done.add(n.i)
+                progressed = True
+            else:
+                nxt.append(n)
+        remaining = nxt
+        for s in r.subs:
+            if not sub_done[s.loop.id] and all(is_done(x) for x in s.ext):
+                if loads_in[s.loop.id] and L is None:
+                    flush_sites()
+                items.append(("loop", s))
+                sub_done[s.loop.id] = True
+                progressed = True
+        # scans as soon as their coefficients exist (they are lane-parallel work too)
+        for c in comps:
+            if not comp_done[id(c)] and c.kind == "scan" and all(is_done(x) for x in c.inputs):
+                items.append(("scan", c))
+                comp_done[id(c)] = True
+                progressed = True
+        if progressed:
+            continue
+        # only switched / serial recurrences can move now: every one of a kind that is ready shares one loop
+        ready = []
+        for kind in ("spec", "serial"):
+            ready = [c for c in comps if not comp_done[id(c)] and c.kind == kind and all(is_done(x) for x in c.inputs)]
+            if ready:
+                break
+        if not ready:
+            raise AssertionError("dependency cycle outside the recurrences")
+        items.append((kind, ready))
+        for c in ready:
+            comp_done[id(c)] = True
+    if L is None:
+        flush_sites()
+    r.items = items
+
+
+def _classify(g: FrameGraph, reg: Region, c: Component, ci: int = 0, live=None):
+    """Affine in the component's own states, with coefficients that do not depend on them? -> "scan".
+    Affine once the state-dependent conditions (switches) are fixed? -> "spec". Otherwise it stays "serial"."""
+    mem = {m.i for m in c.members}
+    names = c.names
+    d = len(names)
+    if d > 2:
+        return
+
+    def add(a: N, b: N) -> N:
+        if a is g.ZERO:
+            return b
+        if b is g.ZERO:
+            return a
+        return g.op("+", a, b)
+
+    def sub(a: N, b: N) -> N:
+        if b is g.ZERO:
+            return a
+        if a is g.ZERO:
+            return g.op("neg", b)
+        return g.op("-", a, b)
+
+    def mul(a: N, b: N) -> N:
+        if a is g.ZERO or b is g.ZERO:
+            return g.ZERO
+        if a is g.ONE:
+            return b
+        if b is g.ONE:
+            return a
+        return g.op("*", a, b)
+
+    def attempt(allow_guess: bool):
+        memo: Dict[int, Optional[tuple]] = {}
+        conds: List[N] = []
+        gnodes: List[N] = []
+
+        def guess_for(cond: N) -> N:
+            for k, x in enumerate(conds):
+                if x is cond:
+                    return gnodes[k]
+            conds.append(cond)
+            gn = g.mk("guess", name=f"{ci}", val=len(gnodes))
+            gn.loop = reg.loop
+            gnodes.append(gn)
+            return gn
+
+        def pick(cnd: N, a, b):
+            co = {k: g.sel(cnd, a[0].get(k, g.ZERO), b[0].get(k, g.ZERO)) for k in set(a[0]) | set(b[0])}
+            return (co, g.sel(cnd, a[1], b[1]))
+
+        def aff(n: N):
+            if n.i not in mem:
+                return ({}, n)
+            if n.i in memo:
+                return memo[n.i]
+            r = None
+            if n.kind in ("st", "lcin"):
+                r = ({n.name: g.ONE}, g.ZERO)
+            elif n.kind == "op":
+                op = n.op
+                if op in ("+", "-"):
+                    a, b = aff(n.args[0]), aff(n.args[1])
+                    if a and b:
+                        f = add if op == "+" else sub
+                        co = {k: f(a[0].get(k, g.ZERO), b[0].get(k, g.ZERO)) for k in set(a[0]) | set(b[0])}
+                        r = (co, f(a[1], b[1]))
+                elif op == "neg":
+                    a = aff(n.args[0])
+                    if a:
+                        r = ({k: sub(g.ZERO, v) for k, v in a[0].items()}, sub(g.ZERO, a[1]))
+                elif op == "*":
+                    a, b = aff(n.args[0]), aff(n.args[1])
+                    if a and b:
+                        if not a[0]:
+                            r = ({k: mul(a[1], v) for k, v in b[0].items()}, mul(a[1], b[1]))
+                        elif not b[0]:
+                            r = ({k: mul(v, b[1]) for k, v in a[0].items()}, mul(a[1], b[1]))
+                elif op == "/":
+                    a, b = aff(n.args[0]), aff(n.args[1])
+                    if a and b and not b[0]:
+                        r = ({k: g.op("/", v, b[1]) for k, v in a[0].items()}, g.op("/", a[1], b[1]) if a[1] is not g.ZERO else g.ZERO)
+                elif op == "sel":
+                    cnd = n.args[0]
+                    if cnd.i not in mem or allow_guess:
+                        a, b = aff(n.args[1]), aff(n.args[2])
+                        if a and b:
+                            r = pick(cnd if cnd.i not in mem else guess_for(cnd), a, b)
+                elif op in ("min", "max") and allow_guess:      # za_min(a, b) = a < b ? a : b,  za_max(a, b) = a > b ? a : b
+                    a, b = aff(n.args[0]), aff(n.args[1])
+                    if a and b:
+                        r = pick(guess_for(g.op("<" if op == "min" else ">", n.args[0], n.args[1])), a, b)
+                elif op == "fabs" and allow_guess:                # |x| = x < 0 ? -x : x
+                    a = aff(n.args[0])
+                    if a:
+                        neg = ({k: sub(g.ZERO, v) for k, v in a[0].items()}, sub(g.ZERO, a[1]))
+                        r = pick(guess_for(g.op("<", n.args[0], g.ZERO)), neg, a)
+            memo[n.i] = r
+            return r
+
+        rows = []
+        for nm in names:
+            r = aff(reg.outs[nm])
+            if r is None:
+                return None
+            rows.append(r)
+        return rows, conds, gnodes
+
+    if d == 1 and _persistent_rounding(g, reg, c, mem):
+        return                                    # stays "serial": see _persistent_rounding
+    res = attempt(False)
+    if res is not None:
+        c.kind = "scan"
+    else:
+        res = attempt(True)
+        if res is None:
+            return
+        c.kind = "spec"
+    rows, c.conds, c.gnodes = res
+    c.A = [[rows[r][0].get(names[k], g.ZERO) for k in range(d)] for r in range(d)]
+    c.b = [rows[r][1] for r in range(d)]
+    if c.kind == "spec":
+        # coefficient nodes that depend on a placeholder (evaluated inside the iteration), topological = creation order
+        dep: Dict[int, bool] = {}
+
+        def gd(n: N) -> bool:
+            if n.i in dep:
+                return dep[n.i]
+            r = n.kind == "guess" or any(gd(x) for x in n.args)
+            dep[n.i] = r
+            return r
+
+        seen: Dict[int, N] = {}
+        todo = [x for row in c.A for x in row] + list(c.b)
+        while todo:
+            n = todo.pop()
+            if n.i in seen or not gd(n):
+                continue
+            seen[n.i] = n
+            todo.extend(n.args)
+        c.gdep = [seen[i] for i in sorted(seen) if seen[i].kind != "guess"]
+        # nodes needed to evaluate the conditions from the states: members (and the synthetic compares) only
+        sl: Dict[int, N] = {}
+        todo = list(c.conds)
+        synth = {x.i for x in c.conds if x.i not in mem}
+        while todo:
+            n = todo.pop()
+            if n.i in sl or (n.i not in mem and n.i not in synth):
+                continue
+            sl[n.i] = n
+            todo.extend(n.args)
+        c.slice = [sl[i] for i in sorted(sl) if sl[i].kind not in ("st", "lcin")]
+
+
+def _const_value(n: N) -> Optional[float]:
+    """Value of a node built from constants only."""
+    if n.kind == "const":
+        return float(n.val)
+    if n.kind == "op" and n.op in ("+", "-", "*", "neg") and n.args:
+        v = [_const_value(a) for a in n.args]
+        if any(x is None for x in v):
+            return None
+        return {"+": lambda: v[0] + v[1], "-": lambda: v[0] - v[1], "*": lambda: v[0] * v[1], "neg": lambda: -v[0]}[n.op]()
+    return None
+
+
+def _persistent_rounding(g: FrameGraph, reg: Region, c: Component, mem) -> bool:
+    """A recurrence y = y + b with a fractional step keeps every rounding error it ever made (coefficient exactly 1: nothing
+    decays), and scripts put thresholds exactly where such sums are meant to land -- `pos += 1 / N; pos < 1 ? ...` reaches
+    1 after N steps only up to rounding, so the frame at which the test flips depends on the ORDER of the additions. A scan
+    re-associates them. Such components therefore keep their serial loop (exact order); integer-valued steps (counters,
+    hold timers) are exact in any order and stay scans, |a| < 1 forgets its rounding, and a step that is itself a signal
+    (`energy += x * x`) has no value it is meant to land on: thresholds on those are generic.
+    Decided on the branch-wise affine forms of the new state: (coefficient on itself, constant term) per path through ?: /
+    min / max; any path with coefficient 1 and a block-constant term that is not an integer literal marks the component."""
+    nm = c.names[0]
+    limit = 256
+
+    def forms(n: N):
+        if n.i not in mem:
+            return [(g.ZERO, n)]
+        if n.kind in ("st", "lcin"):
+            return [(g.ONE, g.ZERO)]
+        if n.kind != "op":
+            return None
+        if n.op == "sel":
+            a, b = forms(n.args[1]), forms(n.args[2])
+            return None if a is None or b is None or len(a) + len(b) > limit else a + b
+        if n.op in ("min", "max"):
+            a, b = forms(n.args[0]), forms(n.args[1])
+            return None if a is None or b is None or len(a) + len(b) > limit else a + b
+        if n.op == "fabs":
+            a = forms(n.args[0])
+            return None if a is None else a + [(g.op("neg", k), g.op("neg", v)) for k, v in a]
+        if n.op in ("+", "-"):
+            a, b = forms(n.args[0]), forms(n.args[1])
+            if a is None or b is None or len(a) * len(b) > limit:
+                return None
+            return [(g.op(n.op, ka, kb), g.op(n.op, va, vb)) for ka, va in a for kb, vb in b]
+        if n.op == "neg":
+            a = forms(n.args[0])
+            return None if a is None else [(g.op("neg", k), g.op("neg", v)) for k, v in a]
+        if n.op == "*":
+            a, b = forms(n.args[0]), forms(n.args[1])
+            if a is None or b is None or len(a) * len(b) > limit:
+                return None
+            out = []
+            for ka, va in a:
+                for kb, vb in b:
+                    if _const_value(ka) == 0.0:
+                        out.append((g.op("*", va, kb), g.op("*", va, vb)))
+                    elif _const_value(kb) == 0.0:
+                        out.append((g.op("*", ka, vb), g.op("*", va, vb)))
+                    else:
+                        return None
+            return out
+        if n.op == "/":
+            a, b = forms(n.args[0]), forms(n.args[1])
+            if a is None or b is None or any(_const_value(kb) != 0.0 for kb, _ in b) or len(a) * len(b) > limit:
+                return None
+            return [(g.op("/", ka, vb), g.op("/", va, vb)) for ka, va in a for _, vb in b]
+        return None
+
+    fs = forms(reg.outs[nm])
+    if fs is None:
+        return False                              # not affine even branch-wise: the classification below decides
+    for k, v in fs:
+        if _const_value(k) == 1.0:
+            cv = _const_value(v)
+            if cv is not None and cv == math.floor(cv):
+                continue
+            if v.su or os.environ.get("ZA_TPAR_STRICT_SUMS"):
+                return True
+    return False
+
+
+def try_plan(prog: Program, nch: int) -> Tuple[Optional[Plan], str]:
+    try:
+        return build_plan(prog, nch), ""
+    except Unsupported as ex:
+        return None, str(ex)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# 3. HIP emission (csrc/zart_tpar.h holds the wavefront primitives)
+# ----------------------------------------------------------------------------------------------------------------------
+_INFIX = {"+": "+", "-": "-", "*": "*", "/": "/"}
+_CMP = {"<": "<", "<=": "<=", ">": ">", ">=": ">=", "==": "=="}
+_FN2 = {"^": "pow", "|": "za_or", "&": "za_and", "~": "za_xor", "<<": "za_shl", ">>": "za_shr", "%": "za_mod", "!=": "za_ne",
+        "min": "za_min", "max": "za_max", "pow": "pow", "atan2": "atan2"}
+_POW_BASE = {"10.0": "exp10", "2.0": "exp2", c_double(math.e): "exp"}
+_FN1 = {"neg": "za_neg", "not": "za_not", "sqr": "za_sqr", "sign": "za_sign", "invsqrt": "za_invsqrt"}
+
+
+def _expr(op: str, a: List[str]) -> str:
+    """Same C++ spelling as zajit/emit.py gives the construct, so both kernels share zart.h's semantics."""
+    if op in _INFIX:
+        return f"({a[0]} {_INFIX[op]} {a[1]})"
+    if op in _CMP:
+        return f"za_b({a[0]} {_CMP[op]} {a[1]})"
+    if op in ("^", "pow") and a[0] in _POW_BASE and not os.environ.get("ZA_TPAR_PLAIN_POW"):
+        # constant base: the dedicated exponential (68 instructions on gfx950) instead of the general pow (240); both are
+        # accurate to the last bits, so results agree to ~4e-16 relative -- 10^(dB/20) is the commonest libm call in the catalog
+        return f"{_POW_BASE[a[0]]}({a[1]})"
+    if op in _FN2:
+        return f"{_FN2[op]}({a[0]}, {a[1]})"
+    if op in _FN1:
+        return f"{_FN1[op]}({a[0]})"
+    if op == "truth":
+        return f"za_b(za_truthy({a[0]}))"
+    if op == "land":
+        return f"za_b(za_truthy({a[0]}) && za_truthy({a[1]}))"
+    if op == "lor":
+        return f"za_b(za_truthy({a[0]}) || za_truthy({a[1]}))"
+    if op == "sel":
+        return f"(za_truthy({a[0]}) ? {a[1]} : {a[2]})"
+    if op in PURE_MATH1:
+        return f"{PURE_MATH1[op]}({a[0]})"
+    if op == "mtout":
+        return f"zt_mt_word(zt_mt, zt_pos0, {a[0]})"
+    if op == "addr":
+        return f"(double)za_addr({a[0]}, {a[1]})"
+    raise AssertionError(op)
+
+
+class _Emit:
+    """Kernel text of one plan."""
+
+    def __init__(self, plan: Plan, prog: Program, kernel_macro: str):
+        self.plan, self.prog, self.km = plan, prog, kernel_macro
+        self.g = plan.g
+        self.L: List[str] = []
+        p = plan
+        # Block-constant values: a few dozen fit the scalar registers (ZT_UNI); past that the compiler spills them into lanes of
+        # vector registers and every use costs two v_readlane. Large scripts keep them in LDS instead: one broadcast ds_read_b64
+        # per use, the `zo` offset (an opaque 0 set per chunk) keeping the reads inside the iteration.
+        self.n_uni = sum(1 for n in p.uniform if n.kind not in ("const", "hold"))
+        mode = os.environ.get("ZA_TPAR_ULDS", "auto")
+        self.ulds = mode == "1" or (mode == "auto" and self.n_uni > ULDS_THRESHOLD)
+        self.uslot = {n.i: k for k, n in enumerate(x for x in p.uniform if x.kind not in ("const", "hold"))}
+        self.in_loop = False
+        self.cname = {name: f"c{k}" for k, name in enumerate(p.st)}
+        self.hname = {name: f"h{k}" for k, name in enumerate(p.holdvars)}
+        self.cell_addrs: List[N] = []
+        for a in p.cells.values():
+            if a not in self.cell_addrs:
+                self.cell_addrs.append(a)
+        self.lcell_loops = [L for L in p.loops if L.cells]
+        self.has_mem = bool(p.cells or p.stores or p.loads or self.lcell_loops)
+        self.has_streams = bool(p.stores)
+        self.has_serial = p.has_block or p.has_pending
+        self.has_abort = bool(p.cells or p.stores or p.loads or p.guards or self.lcell_loops)
+        self.early = [s for s in p.stores if s.mode == "early"]
+        self.phi_name: Dict[int, str] = {}        # phi / lout node id -> C++ variable
+        for L in p.loops:
+            for k, v in enumerate(L.order):
+                nm = f"p{L.id}_{k}"
+                self.phi_name[L.phis[v].i] = nm
+                if v in L.louts:
+                    self.phi_name[L.louts[v].i] = nm
+
+    # -- names ---------------------------------------------------------------------------------------------------------------
+    def ref(self, n: N) -> str:
+        if n.kind == "const":
+            return c_double(n.val)
+        if n.kind == "hold":
+            return "ZT_HOLD"
+        if n.kind in ("phi", "lout"):
+            return self.phi_name[n.i]
+        if n.uniform and n.loop is None:
+            if self.ulds and self.in_loop:
+                return f"zt_u[{self.uslot[n.i]} + zo]"
+            return f"u{n.i}"
+        return f"n{n.i}"
+
+    def inv_src(self, name: str) -> str:
+        p, prog = self.plan, self.prog
+        k = is_slider_name(name)
+        if k is not None:
+            return f"b.sliders[{k - 1} * b.sl_se + inst * b.sl_si]"
+        if name == "srate":
+            return "b.srate"
+        if name == "samplesblock":
+            return "(double)bn"
+        if name in ("midi_bus", "ext_midi_bus", RNG_INDEX) or name.startswith("memw@"):
+            return "0.0"
+        if name in p.cells:
+            return f"(ca{p.cells[name].i} < mcap ? memp[ca{p.cells[name].i} * mse] : 0.0)"
+        k = is_spl_name(name)
+        if k is not None:
+            return f"b.spl[{k} * b.sl_se + inst * b.sl_si]"
+        return f"b.vars[{prog.vars[name]} * b.var_se + inst * b.var_si]"
+
+    def dst(self, name: str) -> str:
+        p, prog = self.plan, self.prog
+        if name in p.cells:
+            return f"memp[ca{p.cells[name].i} * mse]"
+        k = is_spl_name(name)
+        if k is not None:
+            return f"b.spl[{k} * b.sl_se + inst * b.sl_si]"
+        return f"b.vars[{prog.vars[name]} * b.var_se + inst * b.var_si]"
+
+    def carry(self, reg: Region, nm: str) -> str:
+        """C++ name of the wave-uniform value a recurrence state carries into the chunk."""
+        if reg.loop is None:
+            return self.cname[nm]
+        return f"lc{reg.loop.cin[nm].i}"
+
+    # -- the kernel ----------------------------------------------------------------------------------------------------------
+    def emit(self) -> str:
+        p, L, ref = self.plan, self.L, self.ref
+        km = self.km
+        L.append("// ---- time-parallel kernel: one wavefront per instance, lane = frame (generated by zajit/tpar.py) ----")
+        L.append(f"// schedule: {p.stats}")
+        L.append("#ifndef ZT_SPEC_MAX")
+        L.append(f"#define ZT_SPEC_MAX {SPEC_MAX}")
+        L.append("#endif")
+        L.append(f"#define ZT_SPEC_TOL {SPEC_TOL!r}")
+        L.append("#ifndef ZT_UNI")
+        L.append("#define ZT_UNI(x) zt_uniform(x)")
+        L.append("#endif")
+        L.append(f'extern "C" __global__ void __launch_bounds__(64) {km}(ZabBatch b, ZabAudio a) {{')
+        if self.has_serial:
+            L.append("  ZA_KERNEL_ENTRY();")
+        L.append("  const int lane = threadIdx.x;")
+        L.append("  const int64_t inst = blockIdx.x;")
+        L.append("  const int64_t frames = a.frames;")
+        L.append("  if (frames <= 0 || inst >= b.n_inst) return;")
+        if p.uses_rand:
+            L.append("  __shared__ uint32_t zt_mt[2 * ZT_MT_N];      // rand(): current and next generation of the instance's MT19937")
+            L.append("  uint32_t* const zt_gmt = b.mt + inst * b.mt_si;")
+            L.append("  int zt_pos0 = 0;")
+        if self.ulds:
+            L.append(f"  __shared__ double zt_u[{max(1, self.n_uni)}];")
+        # recurrences whose coefficient is constant over a block: one LDS row of per-lane weights per distinct coefficient
+        self.inv_coefs: List[N] = []
+        for it in p.top.items:
+            if it[0] == "scan" and len(it[1].names) == 1:
+                a = it[1].A[0][0]
+                if a.uniform and a.kind != "const" and a not in self.inv_coefs and not os.environ.get("ZA_TPAR_NO_INVSCAN"):
+                    self.inv_coefs.append(a)
+        # coupled pairs with a block-constant matrix (biquads): one table per distinct matrix, within an LDS budget that still
+        # lets four wavefronts share a CU (one per SIMD, the 1024-instance case)
+        self.inv_mats: List[tuple] = []
+        budget = 36 * 1024 - len(self.inv_coefs) * (64 + 4) * 8 - (2 * 624 * 4 if p.uses_rand else 0)
+        for it in p.top.items:
+            if it[0] == "scan" and len(it[1].names) == 2 and not os.environ.get("ZA_TPAR_NO_INVSCAN"):
+                key = tuple(x for row in it[1].A for x in row)
+                if (all(x.uniform or x.kind == "const" for x in key) and key not in self.inv_mats
+                        and (len(self.inv_mats) + 1) * (12 + 8 * 64) * 8 <= budget):
+                    self.inv_mats.append(key)
+        if self.inv_mats:
+            L.append(f"  __shared__ double zt_m[{len(self.inv_mats)} * ZT_MAT_TABLE_DOUBLES];      // per block-constant 2 x 2 matrix: powers and per-lane weights")
+        if self.inv_coefs:
+            L.append(f"  __shared__ double zt_w[{len(self.inv_coefs)} * 64];      // a^((lane & 15) + 1) per block-constant coefficient")
+            L.append(f"  __shared__ double zt_q[{len(self.inv_coefs)} * 4];       // a^2, a^4, a^8, a^16")
+        if self.has_abort:
+            L.append(f"  __shared__ double zt_snap[{max(1, len(self.cname))}];")
+        if self.has_mem:
+            L.append("  // mem[]: block-constant addresses are cells (named state kept in registers), addresses that follow a uniform loop's")
+            L.append("  // counters are per-trip cells, moving ones are delay lines")
+            L.append("  double* const memp = b.mem + inst * b.mem_si;")
+            L.append("  const int64_t mse = b.mem_se, mcap = b.mem_cap;")
+        L.append(f"  const float* const in_ = a.in + inst * {p.nch} * a.frame_stride;")
+        L.append(f"  float* const out_ = a.out + inst * {p.nch} * a.frame_stride;")
+        if self.has_serial:
+            L.append("  uint64_t zt_pend_seen = 0;     // slider masks the script raised in any block of this launch (host: consumeDspSliderChanges)")
+        L.append("  // the audio of a chunk is read one iteration ahead, so that its HBM latency is hidden behind the previous chunk's work")
+        for n in p.inputs:
+            L.append(f"  float x{n.i} = lane < frames ? in_[{int(n.val)} * a.frame_stride + lane] : 0.0f;")
+        # ZT_PIN: an empty asm that takes the prefetched registers, i.e. the point where the compiler waits for their loads. It
+        # sits before the loop and, in the loop, before the chunk's stores: the loads have had the whole chunk to land, and no
+        # path reaches the top of the loop with them pending -- there the wait would be a full vmcnt(0), taken right after the
+        # NEXT chunk's loads were issued (every chunk would pay an HBM round trip).
+        self.pin = ", ".join(f'"+v"(x{n.i})' for n in p.inputs)
+        if self.pin:
+            L.append(f"  asm volatile(\"\" : {self.pin});")
+        L.append(f"  const int64_t blk = {'a.block > 0 ? (int64_t)a.block : frames' if p.has_block else 'frames'};   // a script without @block sees one block per launch")
+        L.append("  for (int64_t pos = 0; pos < frames; pos += blk) {")
+        L.append("    const int64_t bn = frames - pos < blk ? frames - pos : blk;")
+        L.append("    const int64_t bend = pos + bn;")
+        if self.has_serial:
+            self.emit_serial_phase()
+        self.emit_block_prologue()
+        self.emit_chunk_loop()
+        L.append("  }")
+        if self.has_serial:
+            L.append("  if (lane == 0 && zt_pend_seen) b.pend[3 * (int64_t)b.n_pad + inst] |= zt_pend_seen;")
+        if self.has_abort:
+            L.append("  if (lane == 0) b.resume[inst] = frames;")
+        L.append("}")
+        if self.has_abort:
+            self.emit_tail()
+        L.append("static int32_t za_fast_applies(const ZabBatch* b, const ZabAudio* a) { (void)b; return a->frames > 0 ? 1 : 0; }")
+        L.append("static hipError_t za_launch_fast(const ZabBatch* b, const ZabAudio* a, hipStream_t st) {")
+        L.append(f"  hipLaunchKernelGGL({km}, dim3(b->n_inst), dim3(64), 0, st, *b, *a);")
+        if self.has_abort:
+            L.append(f"  hipLaunchKernelGGL({km[:-1]}_tail), dim3((b->n_inst + 63) / 64), dim3(64), 0, st, *b, *a);")
+        L.append("  return hipGetLastError();")
+        L.append("}")
+        return "\n".join(L) + "\n"
+
+    # -- between the blocks: @block and the pending-mask @slider, run by the wavefront with the leaf's section code -----------------
+    def emit_serial_phase(self):
+        p, L = self.plan, self.L
+        L.append("    // jsfx_process_block's block prologue (dsp_jsfx_aot.py:5766-5804): samplesblock, @block, @slider if a mask is pending.")
+        L.append("    // The state is in vars[] / mem[] here (every block ends with its values stored), so the section code runs on it as in")
+        L.append("    // the generic kernel: on lane 0, or -- leaves with cooperative builtins -- on all 64 lanes as replicas of the instance.")
+        if p.has_block:
+            L.append("    {")
+        else:
+            L.append("    if (pos == 0 && (b.pend[inst] | b.pend[b.n_pad + inst] | b.pend[2 * (int64_t)b.n_pad + inst]) != 0ull) {")
+        L.append("#ifdef ZA_REPLICAS")
+        L.append("      const bool zt_run = true;")
+        L.append("#else")
+        L.append("      const bool zt_run = lane == 0;")
+        L.append("#endif")
+        L.append("      if (zt_run) {")
+        L.append("        ZaS s;")
+        L.append("        za_state_load(s, b, (int)inst);")
+        L.append("#ifdef ZA_REPLICAS")
+        L.append("        s.replica = lane != 0 ? 1u : 0u; s.rep_i = (uint32_t)lane; s.rep_n = 64u; s.rep_stride = 1u;")
+        L.append("#endif")
+        L.append("        s.samplesblock = (double)bn;")
+        L.append("        s.block_size = (int)bn;")
+        if p.has_block:
+            L.append("#if ZA_USES_MSG")
+            L.append("        za_msg_begin_block(s);")
+            L.append("#endif")
+            L.append("        za_section_block(s);")
+        L.append("        if (s.pend_change | s.pend_automate | s.pend_automate_end) za_section_slider(s);")
+        L.append("        zt_pend_seen |= s.pend_change | s.pend_automate | s.pend_automate_end;")
+        L.append("        s.pend_change = s.pend_automate = s.pend_automate_end = 0;")
+        L.append("        if (lane == 0) za_state_store(s, b, (int)inst);")
+        L.append("      }")
+        L.append("      __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"workgroup\");")
+        L.append("      __builtin_amdgcn_wave_barrier();")
+        L.append("      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"workgroup\");")
+        L.append("    }")
+
+    def emit_leave(self, ind: str, frame: str):
+        """Hand the rest of the launch, from `frame` on, to the serial code (state already in vars[] / mem[])."""
+        L = self.L
+        L.append(f"{ind}if (lane == 0) b.resume[inst] = {frame};")
+        if self.has_serial:
+            L.append(f"{ind}if (lane == 0 && zt_pend_seen) b.pend[3 * (int64_t)b.n_pad + inst] |= zt_pend_seen;")
+        L.append(f"{ind}return;")
+
+    def emit_block_prologue(self):
+        p, L, ref = self.plan, self.L, self.ref
+        if p.uses_rand:
+            L.append("    __syncthreads();")
+            L.append("    zt_pos0 = zt_mt_begin(zt_mt, zt_gmt, b.mt_se, b.mti[inst], lane);     // (a block ends with the generator's state stored)")
+        L.append("    // per block: invariants and everything that depends on them only")
+        ca_done = set()
+        for n in p.uniform:
+            if n.kind in ("const", "hold"):
+                continue
+            if n.kind == "inv":
+                if n.name in p.cells and p.cells[n.name].i not in ca_done:      # a cell @sample only reads
+                    ca_done.add(p.cells[n.name].i)
+                    L.append(f"    const int64_t ca{p.cells[n.name].i} = (int64_t){ref(p.cells[n.name])};")
+                L.append(f"    const double u{n.i} = {self.inv_src(n.name)};   // {n.name}")
+            else:
+                L.append(f"    const double u{n.i} = ZT_UNI({_expr(n.op, [ref(x) for x in n.args])});")
+        if self.ulds:
+            L.append("    __syncthreads();")
+            L.append("    if (lane == 0) {")
+            for n in p.uniform:
+                if n.kind not in ("const", "hold"):
+                    L.append(f"      zt_u[{self.uslot[n.i]}] = u{n.i};")
+            L.append("    }")
+            L.append("    __syncthreads();")
+        for gn in p.guards:
+            L.append(f"    if (za_truthy({ref(gn)})) {{   // a rare-event branch the lowering left out (tpar.split_guards) is due: the serial code runs it")
+            self.emit_leave("      ", "pos")
+            L.append("    }")
+        if self.has_mem:
+            L.append("    int64_t zt_high = b.mem_high[inst], zt_hc = 0;")
+            for a in self.cell_addrs:
+                if a.i not in ca_done:
+                    L.append(f"    const int64_t ca{a.i} = (int64_t){ref(a)};")
+            if self.cell_addrs:
+                ca = self.cell_addrs
+                clash = " || ".join([f"ca{a.i} >= mcap" for a in ca] + [f"ca{a.i} == ca{b_.i}" for i_, a in enumerate(ca) for b_ in ca[i_ + 1:]])
+                L.append(f"    int64_t cmin = ca{ca[0].i}, cmax = ca{ca[0].i};")
+                for a in ca[1:]:
+                    L.append(f"    cmin = ca{a.i} < cmin ? ca{a.i} : cmin; cmax = ca{a.i} > cmax ? ca{a.i} : cmax;")
+                L.append(f"    if ({clash}) {{   // cells that alias each other (or lie past the arena): not a case for this kernel")
+                self.emit_leave("      ", "pos")
+                L.append("    }")
+        for Lp in self.lcell_loops:
+            self.emit_address_pass(Lp)
+        if self.inv_mats:
+            L.append("    __syncthreads();")
+            for k, key in enumerate(self.inv_mats):
+                L.append(f"    {{ const ZtMat2 am = {{{ref(key[0])}, {ref(key[1])}, {ref(key[2])}, {ref(key[3])}}}; zt_mat_table(zt_m + {k} * ZT_MAT_TABLE_DOUBLES, am, lane); }}")
+            if not self.inv_coefs:
+                L.append("    __syncthreads();")
+        if self.inv_coefs:
+            if not self.inv_mats:
+                L.append("    __syncthreads();")
+            for k, a in enumerate(self.inv_coefs):
+                L.append(f"    zt_w[{k} * 64 + lane] = zt_pow_row({ref(a)}, lane);")
+                L.append(f"    if (lane == 0) {{ const double p2 = {ref(a)} * {ref(a)}, p4 = p2 * p2, p8 = p4 * p4; zt_q[{k} * 4] = p2; zt_q[{k} * 4 + 1] = p4; zt_q[{k} * 4 + 2] = p8; zt_q[{k} * 4 + 3] = p8 * p8; }}")
+            L.append("    __syncthreads();")
+        L.append("    // state carried from frame to frame (wave-uniform)")
+        for name, c in self.cname.items():
+            L.append(f"    double {c} = {self.inv_src(name)};   // {name}")
+        for name, h in self.hname.items():
+            L.append(f"    double {h} = {self.inv_src(name)};   // {name}: its last written value (frames may leave it alone)")
+
+    def emit_address_pass(self, Lp: LoopInfo):
+        """Before a block's first chunk: walk the trips of a loop with per-trip cells once, addresses only. Every address expression
+        must step evenly through the trips (a[k] = a[0] + k * stride) inside the arena, and two expressions may never name one cell
+        (zt_sites_ok: disjoint ranges, or interleaved records -- same stride, offsets that differ by less than a multiple of it)."""
+        p, L, ref = self.plan, self.L, self.ref
+        reg = p.regions[Lp.id]
+        keys = [k for k in Lp.cells if (k in Lp.cin and Lp.cin[k].i in self.live_ids()) or k in Lp.cell_out]
+        need: Dict[int, N] = {}
+        todo = [Lp.cells[k] for k in keys] + ([Lp.cond] if Lp.cond is not None else [])
+        uphis = []
+        while todo:
+            n = todo.pop()
+            if n.i in need or not _in_subtree(n, Lp):
+                continue
+            need[n.i] = n
+            if n.kind == "phi":
+                if n.name not in uphis:
+                    uphis.append(n.name)
+                todo.append(Lp.next[n.name])
+            todo.extend(n.args)
+        L.append(f"    {{   // per-trip cells of loop {Lp.id}: addresses step evenly through the trips and never meet")
+        L.append("      bool zt_abad = false;")
+        for v in uphis:
+            L.append(f"      double {self.phi_name[Lp.phis[v].i]} = {ref(Lp.init[v])};")
+        for j, k in enumerate(keys):
+            L.append(f"      int64_t za0_{j} = 0, zas_{j} = 1, zap_{j} = 0, zalo_{j} = 0, zahi_{j} = -1;")
+        if Lp.count is not None:
+            L.append(f"      const int64_t zt_cnt = za_loopcount(ZT_UNI({ref(Lp.count)}));")
+            L.append("      for (int64_t zk = 0; zk < zt_cnt; ++zk) {")
+        else:
+            L.append("      for (int64_t zk = 0; zk < ZA_LOOP_CAP; ++zk) {")
+        for i in sorted(need):
+            n = need[i]
+            if n.kind == "phi":
+                continue
+            L.append(f"        const double n{n.i} = ZT_UNI({_expr(n.op, [ref(x) for x in n.args])});")
+            if n is Lp.cond:
+                L.append(f"        if (!za_truthy(n{n.i})) break;")
+        if Lp.cond is not None and Lp.cond.i not in need:
+            L.append(f"        if (!za_truthy({ref(Lp.cond)})) break;")
+        for j, k in enumerate(keys):
+            an = ref(Lp.cells[k])
+            L.append(f"        {{ const int64_t A = (int64_t){an}; zt_abad |= A >= mcap;")
+            L.append(f"          if (zk == 0) {{ za0_{j} = zalo_{j} = zahi_{j} = A; }} else {{ if (zk == 1) zas_{j} = A - zap_{j}; else zt_abad |= (A - zap_{j}) != zas_{j};")
+            L.append(f"            zalo_{j} = A < zalo_{j} ? A : zalo_{j}; zahi_{j} = A > zahi_{j} ? A : zahi_{j}; }}")
+            L.append(f"          zap_{j} = A; }}")
+        for v in uphis:
+            L.append(f"        const double q{self.phi_name[Lp.phis[v].i]} = {ref(Lp.next[v])};")
+        for v in uphis:
+            L.append(f"        {self.phi_name[Lp.phis[v].i]} = q{self.phi_name[Lp.phis[v].i]};")
+        L.append("      }")
+        for j, k in enumerate(keys):
+            for j2 in range(j + 1, len(keys)):
+                if k in Lp.cell_out or keys[j2] in Lp.cell_out:
+                    L.append(f"      zt_abad |= !zt_sites_ok(za0_{j}, zas_{j}, zalo_{j}, zahi_{j}, za0_{j2}, zas_{j2}, zalo_{j2}, zahi_{j2});")
+            for a in self.cell_addrs:
+                L.append(f"      zt_abad |= ca{a.i} >= zalo_{j} && ca{a.i} <= zahi_{j};")
+            if k in Lp.cell_out and not (k in Lp.cell_flag and Lp.cell_flag[k].kind != "const"):
+                L.append(f"      if (zahi_{j} >= 0) zt_high = zahi_{j} + 1 > zt_high ? zahi_{j} + 1 : zt_high;     // (stored to in every frame)")
+        L.append("      if (zt_abad) {")
+        self.emit_leave("        ", "pos")
+        L.append("      }")
+        L.append("    }")
+
+    def live_ids(self):
+        if not hasattr(self, "_live"):
+            self._live = {n.i for r in [self.plan.top] + list(self.plan.regions.values()) for n in r.nodes}
+        return self._live
+
+    # -- one block's chunks ----------------------------------------------------------------------------------------------------
+    def emit_chunk_loop(self):
+        p, L, ref = self.plan, self.L, self.ref
+        cname = self.cname
+        L.append("    for (int64_t f0 = pos; f0 < bend; f0 += 64) {")
+        L.append("    const int tn = (int)(bend - f0 < 64 ? bend - f0 : 64);")
+        L.append("    const int last = tn - 1;")
+        L.append("    const bool valid = lane < tn;")
+        for n in p.inputs:
+            L.append(f"    const double n{n.i} = (double)x{n.i};")
+        L.append("    {   // the next chunk's audio (of the next block, at a block's end)")
+        L.append("      const int64_t nf = f0 + 64 < bend ? f0 + 64 : bend;")
+        L.append("      if (nf + lane < frames) {")
+        for n in p.inputs:
+            L.append(f"        x{n.i} = in_[{int(n.val)} * a.frame_stride + nf + lane];")
+        L.append("      } else {")
+        for n in p.inputs:
+            L.append(f"        x{n.i} = 0.0f;")
+        L.append("      }")
+        L.append("    }")
+        # Values leave the registers as early as possible: a state's carry is taken (v_readlane at the chunk's last frame) as soon
+        # as both its recurrence and its new value exist, and the values a block must leave in vars[] -- needed in the block's
+        # last chunk only -- are stored in small conditional batches right after they are computed, instead of all living to the
+        # end of the chunk body (144 written variables would be 288 registers per lane there).
+        self.in_loop = True
+        if self.inv_coefs or self.inv_mats or self.ulds:
+            L.append("    int zo; asm volatile(\"s_mov_b32 %0, 0\" : \"=s\"(zo));   // opaque 0: keeps the table reads inside the iteration")
+        if self.has_abort:
+            L.append("    if (lane == 0) {   // the states as they stand before this chunk, in case it has to be handed to the serial code")
+            for k, (name, c) in enumerate(cname.items()):
+                L.append(f"      zt_snap[{k}] = {c};")
+            L.append("    }")
+            L.append("    bool zt_bad = false, zt_badl = false;")
+        L.append("    const bool fin = f0 + 64 >= bend;   // the block's last chunk: its last frame leaves every written variable as the script would")
+        self.avail = {n.i for n in p.inputs}
+        self.raw_issued: set = set()
+        self.unit_done: set = set()
+        self.carried: set = set()
+        self.stored: set = set()
+        self.finals = [(name, o) for name, o in p.outs.items() if name != RNG_INDEX and name not in self.hname]
+        self.finals += [(f"spl{ch}", p.spl_out[ch]) for ch in range(p.nch) if f"spl{ch}" not in p.outs]
+        self.pending: List[tuple] = []
+        self.emit_region(p.top, "    ")
+        if self.has_abort:
+            self.emit_abort_block()
+        if self.has_streams:
+            L.append("    // the chunk's writes land after all of its reads are resolved")
+            for st_ in p.stores:
+                j = st_.j
+                if st_.mode == "late":
+                    gate = f"valid && zsu{j}" if st_.pred is not None else "valid"
+                    L.append(f"    if ({gate}) memp[(int64_t){ref(st_.addr)} * mse] = {ref(st_.value)};")
+                if st_.mode in ("late", "early"):
+                    upd = (f"{{ const int64_t h0 = s0{j} + sk{j}, h1 = sk{j} < tn ? s1{j} + (tn - sk{j}) : 0; zt_high = h0 > zt_high ? h0 : zt_high; "
+                           f"zt_high = h1 > zt_high ? h1 : zt_high; }}")
+                    L.append(f"    if (zsu{j}) {upd}" if st_.pred is not None else f"    {upd}")
+                else:
+                    L.append(f"    for (uint64_t m = zsm{j}; m; m &= m - 1) {{   // in frame order: a later frame's store to the same cell wins")
+                    L.append(f"      const int l = (int)__ffsll((long long)m) - 1;")
+                    L.append(f"      if (lane == l) memp[(int64_t){ref(st_.addr)} * mse] = {ref(st_.value)};")
+                    L.append(f"      const int64_t h = (int64_t)zt_readlane({ref(st_.addr)}, l) + 1; zt_high = h > zt_high ? h : zt_high;")
+                    L.append("    }")
+        # variables that frames may leave alone: the last value written in this chunk, if any
+        for name, h in self.hname.items():
+            o = p.outs[name]
+            L.append(f"    {{ const double v = {ref(o)}; const uint64_t m = __ballot(valid && !zt_is_hold(v)); if (m) {h} = zt_readlane(v, 63 - __clzll((long long)m)); }}")
+        self.retire(final=True)
+        if self.hname:
+            L.append("    if (fin && lane == last) {")
+            for name, h in self.hname.items():
+                L.append(f"      {self.dst(name)} = {h};")
+            L.append("    }")
+        if self.has_mem:
+            L.append("    if (fin && lane == last) b.mem_high[inst] = zt_high > zt_hc ? zt_high : zt_hc;")
+        if self.pin:
+            L.append(f"    asm volatile(\"\" : {self.pin});   // the next chunk's audio has landed; its wait comes before this chunk's stores")
+        L.append("    if (valid) {")
+        for ch in range(p.nch):
+            L.append(f"      out_[{ch} * a.frame_stride + f0 + lane] = (float){ref(p.spl_out[ch])};")
+        L.append("    }")
+        if p.uses_rand:
+            L.append(f"    zt_mt_retire(zt_mt, zt_pos0, (int){cname[RNG_INDEX]}, lane);")
+        L.append("    }")
+        self.in_loop = False
+        if p.uses_rand:
+            L.append(f"    zt_mt_end(zt_mt, zt_pos0, (int){cname[RNG_INDEX]}, zt_gmt, b.mt_se, b.mti + inst, lane);")
+        if p.has_block and (self.has_mem or True):
+            L.append("    __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"workgroup\");     // the block's values are in vars[] / mem[] before @block reads them")
+            L.append("    __builtin_amdgcn_wave_barrier();")
+            L.append("    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"workgroup\");")
+
+    def ready(self, o: N) -> bool:
+        return (o.uniform and o.loop is None) or o.kind in ("const", "hold") or o.i in self.avail
+
+    def retire(self, final: bool = False):
+        p, L, ref = self.plan, self.L, self.ref
+        for name, c in self.cname.items():
+            o = p.outs[name]
+            if name not in self.carried and name in self.unit_done and self.ready(o):
+                self.carried.add(name)
+                L.append(f"    {c} = {ref(o) if (o.uniform or o.kind == 'const') else f'zt_readlane({ref(o)}, last)'};")
+        for name, o in self.finals:
+            if (name in p.cells or name.startswith("memw@")) and not final:
+                continue                                   # (a cell needs its "stored to" flag beside it: both go out at the end)
+            if name not in self.stored and self.ready(o) and (final or not (o.uniform or o.kind == "const")):
+                self.stored.add(name)
+                self.pending.append((name, o))
+        if self.pending and (final or len(self.pending) >= 12):
+            L.append("    if (fin && lane == last) {")
+            for name, o in self.pending:
+                if name.startswith("memw@"):
+                    continue
+                if name in p.cells:                     # a cell is written back only if the launch stored to it at all
+                    flag = p.outs.get("memw@" + name[4:])
+                    if flag is not None:
+                        L.append(f"      if ({ref(flag)} != 0.0) {{ {self.dst(name)} = {ref(o)}; zt_hc = zt_hc > ca{p.cells[name].i} + 1 ? zt_hc : ca{p.cells[name].i} + 1; }}")
+                    continue
+                L.append(f"      {self.dst(name)} = {ref(o)};")
+            L.append("    }")
+            self.pending.clear()
+
+    def emit_abort_block(self):
+        p, L = self.plan, self.L
+        cname = self.cname
+        L.append("    if (zt_bad || __ballot(valid && zt_badl)) {")
+        L.append("      // a condition of the lowering does not hold in this chunk: put the states back as they were before it and leave")
+        L.append("      // the rest of the launch to the serial code (za_launch_fast runs it right behind this kernel)")
+        for st_ in reversed(self.early):
+            L.append(f"      if (valid && zse{st_.j}) memp[(int64_t){self.ref(st_.addr)} * mse] = zso{st_.j};      // (what this chunk's early stores replaced)")
+        L.append("      if (lane == 0) {")
+        for k, name in enumerate(cname):
+            if name.startswith("memw@") or name == RNG_INDEX:
+                continue
+            if name in p.cells:
+                flag = "memw@" + name[4:]
+                if flag in cname:
+                    fk = list(cname).index(flag)
+                    L.append(f"        if (zt_snap[{fk}] != 0.0) {{ {self.dst(name)} = zt_snap[{k}]; zt_high = zt_high > ca{p.cells[name].i} + 1 ? zt_high : ca{p.cells[name].i} + 1; }}")
+                continue
+            L.append(f"        {self.dst(name)} = zt_snap[{k}];")
+        for name, h in self.hname.items():
+            L.append(f"        {self.dst(name)} = {h};")
+        if self.has_mem:
+            L.append("        b.mem_high[inst] = zt_high;")
+        L.append("      }")
+        if p.uses_rand:
+            k = list(cname).index(RNG_INDEX)
+            L.append(f"      zt_mt_end(zt_mt, zt_pos0, (int)zt_snap[{k}], zt_gmt, b.mt_se, b.mti + inst, lane);")
+        self.emit_leave("      ", "f0")
+        L.append("    }")
+
+    # -- one region's schedule ----------------------------------------------------------------------------------------------------
+    def serial_loop(self, reg: Region, comps: List[Component], ind: str):
+        """64 uniform steps; leaves the state before each frame in k<st> of that frame's lane."""
+        L, ref = self.L, self.ref
+        for c in comps:
+            for nm in c.names:
+                s = reg.st[nm].i
+                L.append(f"{ind}double y{s} = {self.carry(reg, nm)}, k{s} = {self.carry(reg, nm)};")
+        L.append(f"{ind}for (int t = 0; t < tn; ++t) {{")
+        L.append(f"{ind}  const bool me = lane == t;")
+        seen_ext = set()
+        for c in comps:
+            mem = {m.i for m in c.members}
+            for nm in c.names:
+                s = reg.st[nm].i
+                L.append(f"{ind}  k{s} = me ? y{s} : k{s};")
+            for x in c.ext:
+                if not x.uniform and x.kind not in ("const", "hold") and x.i not in seen_ext:
+                    seen_ext.add(x.i)
+                    L.append(f"{ind}  const double e{x.i} = zt_readlane({ref(x)}, t);")
+
+            def sref(x: N, mem=mem) -> str:
+                if x.kind in ("st", "lcin") and x.i in mem:
+                    return f"y{x.i}"
+                if x.i in mem:
+                    return f"m{x.i}"
+                if x.kind in ("const", "hold") or x.uniform:
+                    return ref(x)
+                return f"e{x.i}"
+
+            for m in c.members:
+                if m.kind in ("st", "lcin"):
+                    continue
+                L.append(f"{ind}  const double m{m.i} = {_expr(m.op, [sref(x) for x in m.args])};")
+            for nm in c.names:            # all new states are computed from the old ones before any is replaced
+                L.append(f"{ind}  const double q{reg.st[nm].i} = {sref(reg.outs[nm])};")
+            for nm in c.names:
+                L.append(f"{ind}  y{reg.st[nm].i} = q{reg.st[nm].i};")
+        L.append(f"{ind}}}")
+
+    def emit_site(self, st_: StoreSite, ind: str):
+        p, L, ref = self.plan, self.L, self.ref
+        j, an = st_.j, ref(st_.addr)
+        if st_.mode == "sparse":
+            L.append(f"{ind}// conditional write {j} into a buffer @sample never reads: the frames whose condition holds, inside the arena, away")
+            L.append(f"{ind}// from every cell and from this chunk's other writes")
+            L.append(f"{ind}const uint64_t zsm{j} = __ballot(valid && za_truthy({ref(st_.pred)}));")
+            L.append(f"{ind}int64_t zlo{j} = 0, zhi{j} = -1;")
+            L.append(f"{ind}if (zsm{j}) {{")
+            L.append(f"{ind}  const bool on = (zsm{j} >> lane) & 1ull;")
+            L.append(f"{ind}  const int64_t A = (int64_t){an};")
+            L.append(f"{ind}  zlo{j} = zt_wave_min_i64(on ? A : INT64_MAX); zhi{j} = zt_wave_max_i64(on ? A : INT64_MIN);")
+            L.append(f"{ind}  zt_bad |= zhi{j} >= mcap;")
+            if self.cell_addrs:
+                L.append(f"{ind}  zt_bad |= zlo{j} <= cmax && zhi{j} >= cmin;")
+            L.append(f"{ind}}}")
+            return
+        L.append(f"{ind}// delay-line write {j}: must advance by one cell per frame (at most one wrap inside the chunk)")
+        if st_.pred is not None:
+            L.append(f"{ind}const bool zsu{j} = za_truthy({ref(st_.pred)});      // (block-constant condition)")
+        L.append(f"{ind}const double sp{j} = zt_shift1({an}, {an} - 1.0);")
+        L.append(f"{ind}const uint64_t sm{j} = __ballot(valid && lane > 0 && ({an} - sp{j} != 1.0));")
+        L.append(f"{ind}const int sk{j} = sm{j} ? (int)__ffsll((long long)sm{j}) - 1 : tn;")
+        L.append(f"{ind}const int64_t s0{j} = (int64_t)zt_readlane({an}, 0), s1{j} = sk{j} < tn ? (int64_t)zt_readlane({an}, sk{j}) : 0;")
+        cond = f"__popcll(sm{j}) > 1 || s0{j} + sk{j} > mcap || (sk{j} < tn && s1{j} + (tn - sk{j}) > mcap)"
+        if self.cell_addrs:
+            cond += f" || (s0{j} <= cmax && s0{j} + sk{j} > cmin) || (sk{j} < tn && s1{j} <= cmax && s1{j} + (tn - sk{j}) > cmin)"
+        L.append(f"{ind}const bool zsb{j} = {cond};")
+        L.append(f"{ind}zt_bad |= {'zsu%d && ' % j if st_.pred is not None else ''}zsb{j};")
+
+    def emit_site_pairs(self, ind: str):
+        """No two writes of a chunk may touch one cell (different buffers are an assumption: checked here)."""
+        p, L = self.plan, self.L
+        dense = [s for s in p.stores if s.mode != "sparse"]
+        for x, sa in enumerate(dense):
+            for sb in dense[x + 1:]:
+                a, b = sa.j, sb.j
+                L.append(f"{ind}zt_bad |= zt_spans_meet(s0{a}, sk{a}, s1{a}, tn - sk{a}, s0{b}, sk{b}, s1{b}, tn - sk{b});")
+            for sp_ in (s for s in p.stores if s.mode == "sparse"):
+                a, b = sa.j, sp_.j
+                L.append(f"{ind}zt_bad |= zhi{b} >= zlo{b} && (zt_span_hits(s0{a}, sk{a}, zlo{b}, zhi{b}) || zt_span_hits(s1{a}, tn - sk{a}, zlo{b}, zhi{b}));")
+        sparse = [s for s in p.stores if s.mode == "sparse"]
+        for x, sa in enumerate(sparse):
+            for sb in sparse[x + 1:]:
+                L.append(f"{ind}zt_bad |= zhi{sa.j} >= zlo{sa.j} && zhi{sb.j} >= zlo{sb.j} && zlo{sa.j} <= zhi{sb.j} && zlo{sb.j} <= zhi{sa.j};")
+        for st_ in self.early:
+            j = st_.j
+            gate = f"zsu{j} && !zsb{j}" if st_.pred is not None else f"!zsb{j}"
+            L.append(f"{ind}// write {j} goes out now: the loops that gather from its buffer read memory (what it replaces is kept for a hand-back)")
+            L.append(f"{ind}const bool zse{j} = {gate} && !zt_bad;")
+            L.append(f"{ind}double zso{j} = 0.0;")
+            L.append(f"{ind}if (valid && zse{j}) {{ zso{j} = memp[(int64_t){self.ref(st_.addr)} * mse]; memp[(int64_t){self.ref(st_.addr)} * mse] = {self.ref(st_.value)}; }}")
+
+    def emit_load(self, n: N, ind: str):
+        p, L, ref = self.plan, self.L, self.ref
+        L.append(f"{ind}double n{n.i};   // delay-line read: memory as it was before this chunk, or the value an earlier frame of the chunk writes")
+        L.append(f"{ind}{{")
+        if n.i in self.raw_issued:
+            L.append(f"{ind}  const int64_t B = B{n.i};")
+            L.append(f"{ind}  double v = raw{n.i};")
+        else:
+            L.append(f"{ind}  const int64_t B = (int64_t){ref(n.args[0])};")
+            L.append(f"{ind}  double v = B < mcap ? memp[B * mse] : 0.0;")
+        need_best = any(s.mode == "late" and ",".join(map(str, s.region)) == n.name for s in p.stores)
+        if need_best:
+            L.append(f"{ind}  int best = -1;")
+        for st_ in p.stores:
+            j = st_.j
+            if st_.mode == "sparse":
+                L.append(f"{ind}  zt_badl |= B >= zlo{j} && B <= zhi{j};")
+                continue
+            on = f"zsu{j} && " if st_.pred is not None else ""
+            L.append(f"{ind}  {{ int tw = -1; const int64_t d0 = B - s0{j}, d1 = B - s1{j};")
+            L.append(f"{ind}    if ((uint64_t)d0 < (uint64_t)sk{j}) tw = (int)d0;")
+            L.append(f"{ind}    if ((uint64_t)d1 < (uint64_t)(tn - sk{j})) tw = sk{j} + (int)d1;")
+            if ",".join(map(str, st_.region)) != n.name:
+                L.append(f"{ind}    zt_badl |= {on}tw >= 0; }}")
+            elif st_.mode == "early":
+                # memory already holds this chunk's values: right for frames at or before this one, wrong for later ones
+                before = "false" if st_.seq < n.val else "true"
+                L.append(f"{ind}    zt_badl |= {on}(tw > lane || (tw == lane && {before})); }}")
+            else:
+                before = "true" if st_.seq < n.val else "false"
+                L.append(f"{ind}    const bool vis = {on}valid && tw >= 0 && (tw < lane || (tw == lane && {before})) && tw >= best;")
+                L.append(f"{ind}    if (__ballot(vis)) {{ const double fw = zt_bperm({ref(st_.value)}, tw); v = vis ? fw : v; best = vis ? tw : best; }} }}")
+        if self.cell_addrs:
+            L.append(f"{ind}  zt_badl |= B >= cmin && B <= cmax;")
+        L.append(f"{ind}  n{n.i} = v;")
+        L.append(f"{ind}}}")
+
+    def emit_region(self, reg: Region, ind: str):
+        p, L, ref = self.plan, self.L, self.ref
+        top = reg.loop is None
+        sites_open = False
+        for gid, it in enumerate(reg.items):
+            kind = it[0]
+            if kind != "site" and sites_open:
+                self.emit_site_pairs(ind)
+                sites_open = False
+            if top:
+                if kind == "par":
+                    self.avail.add(it[1].i)
+                elif kind == "shift":
+                    self.avail.add(reg.st[it[1]].i)
+                    self.unit_done.add(it[1])
+                elif kind == "scan":
+                    for nm in it[1].names:
+                        self.avail.add(reg.st[nm].i)
+                        self.unit_done.add(nm)
+                elif kind in ("spec", "serial"):
+                    for c in it[1]:
+                        for nm in c.names:
+                            self.avail.add(reg.st[nm].i)
+                            self.unit_done.add(nm)
+                elif kind == "loop":
+                    for lo in it[1].loop.louts.values():
+                        self.avail.add(lo.i)
+            if kind == "site":
+                self.emit_site(it[1], ind)
+                sites_open = True
+                continue
+            if kind == "loop":
+                self.emit_loop(it[1], ind)
+            elif kind == "par" and it[1].kind == "ld":
+                self.emit_load(it[1], ind)
+            elif kind == "par" and it[1].kind == "lcin":
+                n = it[1]
+                A = f"la{reg.loop.cells[n.name].i}"
+                L.append(f"{ind}const double n{n.i} = ZT_UNI({A} < mcap ? memp[{A} * mse] : 0.0);     // a cell this loop only reads")
+            elif kind == "par":
+                n = it[1]
+                e = _expr(n.op, [ref(x) for x in n.args])
+                L.append(f"{ind}const double n{n.i} = {('ZT_UNI(' + e + ')') if (n.uniform and not top) else e};")
+                if not top and n is reg.loop.cond:
+                    L.append(f"{ind}if (!za_truthy(n{n.i})) break;")
+                for ld in p.loads:            # the reads of this address go out now: their latency overlaps everything up to their use
+                    if ld.args[0] is n and ld.i not in self.raw_issued and not any(s.mode == "early" for s in p.stores):
+                        self.raw_issued.add(ld.i)
+                        L.append(f"{ind}const int64_t B{ld.i} = (int64_t)n{n.i};")
+                        L.append(f"{ind}const double raw{ld.i} = B{ld.i} < mcap ? memp[B{ld.i} * mse] : 0.0;")
+                if not top:                   # a per-trip cell's address: its value before the chunk
+                    for key, a in reg.loop.cells.items():
+                        if a is n:
+                            L.append(f"{ind}const int64_t la{n.i} = (int64_t)n{n.i};")
+                            if key in reg.st:
+                                L.append(f"{ind}const double lc{reg.loop.cin[key].i} = ZT_UNI(memp[la{n.i} * mse]);")
+                            break
+            elif kind == "shift":
+                name = it[1]
+                L.append(f"{ind}const double n{reg.st[name].i} = zt_shift1({ref(reg.outs[name])}, {self.carry(reg, name)});   // {name}[t-1]")
+            elif kind == "scan":
+                self.emit_scan(reg, it[1], ind)
+            elif kind == "serial":
+                names = [nm for c in it[1] for nm in c.names]
+                L.append(f"{ind}// serial recurrences sharing one loop: {', '.join(names)}")
+                self.serial_loop(reg, it[1], ind)
+                for nm in names:
+                    s = reg.st[nm].i
+                    L.append(f"{ind}const double n{s} = k{s};")
+            elif kind == "spec":
+                self.emit_spec(reg, it[1], gid, ind)
+            else:
+                raise AssertionError(kind)
+            if top:
+                self.retire()
+        if sites_open:
+            self.emit_site_pairs(ind)
+
+    def emit_scan(self, reg: Region, c: Component, ind: str):
+        L, ref = self.L, self.ref
+        cn = lambda nm: self.carry(reg, nm)
+        top = reg.loop is None
+        if len(c.names) == 1 and c.A[0][0].kind == "const" and c.A[0][0].val == 1.0:
+            nm = c.names[0]
+            s = reg.st[nm].i
+            L.append(f"{ind}const double n{s} = zt_shift1(zt_scan1_sum({ref(c.b[0])}, {cn(nm)}, lane), {cn(nm)});   // {nm}: running sum")
+        elif len(c.names) == 1 and top and c.A[0][0] in self.inv_coefs:
+            nm = c.names[0]
+            s = reg.st[nm].i
+            k = self.inv_coefs.index(c.A[0][0])
+            L.append(f"{ind}const ZtPow sq{s} = {{zt_q[{k} * 4 + zo], zt_q[{k} * 4 + 1 + zo], zt_q[{k} * 4 + 2 + zo], zt_q[{k} * 4 + 3 + zo]}};   // {nm}: constant-coefficient recurrence")
+            L.append(f"{ind}const double n{s} = zt_shift1(zt_scan1_inv({ref(c.b[0])}, {ref(c.A[0][0])}, sq{s}, zt_w[{k} * 64 + lane + zo], {cn(nm)}, lane), {cn(nm)});")
+        elif len(c.names) == 1:
+            nm = c.names[0]
+            s = reg.st[nm].i
+            L.append(f"{ind}double sa{s} = {ref(c.A[0][0])}, sb{s} = {ref(c.b[0])};   // {nm}: affine recurrence")
+            L.append(f"{ind}zt_scan1(sa{s}, sb{s});")
+            L.append(f"{ind}const double n{s} = zt_shift1(__builtin_fma(sa{s}, {cn(nm)}, sb{s}), {cn(nm)});")
+        elif len(c.names) == 2 and top and tuple(x for row in c.A for x in row) in self.inv_mats:
+            n0, n1 = c.names
+            s0, s1 = reg.st[n0].i, reg.st[n1].i
+            k = self.inv_mats.index(tuple(x for row in c.A for x in row))
+            L.append(f"{ind}double sb{s0} = {ref(c.b[0])}, sb{s1} = {ref(c.b[1])};   // {n0}, {n1}: coupled pair, block-constant matrix")
+            L.append(f"{ind}{{ const ZtMat2 am = {{{ref(c.A[0][0])}, {ref(c.A[0][1])}, {ref(c.A[1][0])}, {ref(c.A[1][1])}}};")
+            L.append(f"{ind}  zt_scan2_inv(sb{s0}, sb{s1}, am, zt_m + {k} * ZT_MAT_TABLE_DOUBLES, zo, {cn(n0)}, {cn(n1)}, lane); }}")
+            L.append(f"{ind}const double n{s0} = zt_shift1(sb{s0}, {cn(n0)});")
+            L.append(f"{ind}const double n{s1} = zt_shift1(sb{s1}, {cn(n1)});")
+        else:
+            n0, n1 = c.names
+            s0, s1 = reg.st[n0].i, reg.st[n1].i
+            L.append(f"{ind}ZtMap2 sm{s0} = {{{ref(c.A[0][0])}, {ref(c.A[0][1])}, {ref(c.A[1][0])}, {ref(c.A[1][1])}, {ref(c.b[0])}, {ref(c.b[1])}}};   // {n0}, {n1}: coupled affine pair")
+            L.append(f"{ind}zt_scan2(sm{s0});")
+            L.append(f"{ind}const double n{s0} = zt_shift1(__builtin_fma(sm{s0}.a00, {cn(n0)}, __builtin_fma(sm{s0}.a01, {cn(n1)}, sm{s0}.b0)), {cn(n0)});")
+            L.append(f"{ind}const double n{s1} = zt_shift1(__builtin_fma(sm{s0}.a10, {cn(n0)}, __builtin_fma(sm{s0}.a11, {cn(n1)}, sm{s0}.b1)), {cn(n1)});")
+
+    def emit_spec(self, reg: Region, comps: List[Component], gid: int, ind: str):
+        L, ref = self.L, self.ref
+        cn = lambda nm: self.carry(reg, nm)
+        tag = f"{reg.loop.id if reg.loop is not None else 0}_{gid}"
+        names = [nm for c in comps for nm in c.names]
+        L.append(f"{ind}// switched recurrences (affine once their state-dependent conditions are fixed), solved by iterating the")
+        L.append(f"{ind}// condition pattern to its fixed point: {', '.join(names)}")
+        for nm in names:
+            L.append(f"{ind}double s{reg.st[nm].i} = {cn(nm)}, p{reg.st[nm].i} = {cn(nm)};")
+        gname = {}
+        for c in comps:
+            for k, gn in enumerate(c.gnodes):
+                gname[gn.i] = f"g{gn.name}_{k}"
+                L.append(f"{ind}bool {gname[gn.i]};")
+
+        def xref(x: N, loc: Dict[int, str]) -> str:
+            if x.i in loc:
+                return loc[x.i]
+            if x.kind == "guess":
+                return f"({gname[x.i]} ? 1.0 : 0.0)"
+            return ref(x)
+
+        def slice_eval(c: Component, ind2: str, out_prefix: str):
+            loc = {reg.st[nm].i: f"s{reg.st[nm].i}" for nm in c.names}
+            for m in c.slice:
+                loc[m.i] = f"v{m.i}"
+                L.append(f"{ind2}const double v{m.i} = {_expr(m.op, [xref(x, loc) for x in m.args])};")
+            for k, (cnd, gn) in enumerate(zip(c.conds, c.gnodes)):
+                L.append(f"{ind2}{out_prefix}{gname[gn.i]} = za_truthy({xref(cnd, loc)});")
+
+        L.append(f"{ind}{{   // first pattern: the states taken to stay at their carried values")
+        for c in comps:
+            slice_eval(c, ind + "  ", "")
+        L.append(f"{ind}}}")
+        L.append(f"{ind}bool sch{tag}; int sit{tag} = 0, sst{tag} = 0;")
+        L.append(f"{ind}do {{")
+        for c in comps:
+            loc: Dict[int, str] = {}
+            for n in c.gdep:
+                loc[n.i] = f"d{n.i}"
+                L.append(f"{ind}  const double d{n.i} = {_expr(n.op, [xref(x, loc) for x in n.args])};")
+            if len(c.names) == 1:
+                nm = c.names[0]
+                s = reg.st[nm].i
+                L.append(f"{ind}  double sa{s} = {xref(c.A[0][0], loc)}, sb{s} = {xref(c.b[0], loc)};")
+                L.append(f"{ind}  zt_scan1(sa{s}, sb{s});")
+                L.append(f"{ind}  s{s} = zt_shift1(__builtin_fma(sa{s}, {cn(nm)}, sb{s}), {cn(nm)});")
+            else:
+                n0, n1 = c.names
+                s0, s1 = reg.st[n0].i, reg.st[n1].i
+                L.append(f"{ind}  ZtMap2 sm{s0} = {{{xref(c.A[0][0], loc)}, {xref(c.A[0][1], loc)}, {xref(c.A[1][0], loc)}, {xref(c.A[1][1], loc)}, {xref(c.b[0], loc)}, {xref(c.b[1], loc)}}};")
+                L.append(f"{ind}  zt_scan2(sm{s0});")
+                L.append(f"{ind}  s{s0} = zt_shift1(__builtin_fma(sm{s0}.a00, {cn(n0)}, __builtin_fma(sm{s0}.a01, {cn(n1)}, sm{s0}.b0)), {cn(n0)});")
+                L.append(f"{ind}  s{s1} = zt_shift1(__builtin_fma(sm{s0}.a10, {cn(n0)}, __builtin_fma(sm{s0}.a11, {cn(n1)}, sm{s0}.b1)), {cn(n1)});")
+        L.append(f"{ind}  // the pattern these states imply")
+        for c in comps:
+            slice_eval(c, ind + "  ", "const bool h")
+        diffs = " || ".join(f"(h{gname[gn.i]} != {gname[gn.i]})" for c in comps for gn in c.gnodes)
+        moved = " || ".join(f"(fabs(s{reg.st[nm].i} - p{reg.st[nm].i}) > ZT_SPEC_TOL * fmax(fabs(s{reg.st[nm].i}), fabs(p{reg.st[nm].i})))" for nm in names)
+        L.append(f"{ind}  // settled = the pattern reproduced itself -- or it still flips, but only where its branches agree: the states have not")
+        L.append(f"{ind}  // moved over two passes in a row, i.e. also under the pattern they themselves imply")
+        L.append(f"{ind}  sst{tag} = (__ballot(valid && ({moved})) != 0ull) ? 0 : sst{tag} + 1;")
+        L.append(f"{ind}  sch{tag} = (__ballot(valid && ({diffs})) != 0ull) && sst{tag} < 2;")
+        for c in comps:
+            for gn in c.gnodes:
+                L.append(f"{ind}  {gname[gn.i]} = h{gname[gn.i]};")
+        for nm in names:
+            L.append(f"{ind}  p{reg.st[nm].i} = s{reg.st[nm].i};")
+        L.append(f"{ind}}} while (sch{tag} && ++sit{tag} < ZT_SPEC_MAX);")
+        L.append(f"{ind}if (sch{tag}) {{   // no fixed point within the budget (a pattern that keeps moving along the chunk): the serial loop")
+        self.serial_loop(reg, comps, ind + "  ")
+        for nm in names:
+            s = reg.st[nm].i
+            L.append(f"{ind}  s{s} = k{s};")
+        L.append(f"{ind}}}")
+        for nm in names:
+            s = reg.st[nm].i
+            L.append(f"{ind}const double n{s} = s{s};")
+
+    def emit_loop(self, reg: Region, ind: str):
+        """A uniform loop: trip k of all the chunk's frames, then trip k + 1."""
+        p, L, ref = self.plan, self.L, self.ref
+        Lp = reg.loop
+        live = self.live_ids()
+        carried = [v for v in Lp.order if Lp.phis[v].i in live or (v in Lp.louts and Lp.louts[v].i in live)]
+        L.append(f"{ind}// uniform loop {Lp.id}: every frame runs the same trips; {len(carried)} values handed from trip to trip, {len(Lp.cell_out)} per-trip cells")
+        for v in carried:
+            L.append(f"{ind}double {self.phi_name[Lp.phis[v].i]} = {ref(Lp.init[v])};   // {v}")
+        if Lp.count is not None:
+            L.append(f"{ind}const int64_t zc{Lp.id} = za_loopcount(ZT_UNI({ref(Lp.count)}));")
+            L.append(f"{ind}for (int64_t zk{Lp.id} = 0; zk{Lp.id} < zc{Lp.id}; ++zk{Lp.id}) {{")
+        else:
+            L.append(f"{ind}for (int64_t zk{Lp.id} = 0; zk{Lp.id} < ZA_LOOP_CAP; ++zk{Lp.id}) {{")
+            if Lp.cond is not None and not _in_subtree(Lp.cond, Lp):
+                L.append(f"{ind}  if (!za_truthy({ref(Lp.cond)})) break;")
+        self.emit_region(reg, ind + "  ")
+        for key, o in Lp.cell_out.items():
+            A = f"la{Lp.cells[key].i}"
+            L.append(f"{ind}  if (lane == last) memp[{A} * mse] = {ref(o)};     // {key}: the cell after the chunk's last frame")
+            fl = Lp.cell_flag.get(key)
+            if fl is not None and fl.kind != "const":
+                test = f"za_truthy({ref(fl)})" if fl.uniform else f"__ballot(valid && za_truthy({ref(fl)}))"
+                L.append(f"{ind}  if ({test}) zt_high = {A} + 1 > zt_high ? {A} + 1 : zt_high;")
+        tmp = [v for v in carried if Lp.next[v].kind == "phi" and Lp.next[v].val == Lp.id and Lp.next[v] is not Lp.phis[v]]
+        for v in tmp:
+            L.append(f"{ind}  const double q{self.phi_name[Lp.phis[v].i]} = {ref(Lp.next[v])};")
+        for v in carried:
+            if Lp.next[v] is Lp.phis[v]:
+                continue
+            src = f"q{self.phi_name[Lp.phis[v].i]}" if v in tmp else ref(Lp.next[v])
+            L.append(f"{ind}  {self.phi_name[Lp.phis[v].i]} = {src};")
+        L.append(f"{ind}}}")
+
+    # -- the serial finish ---------------------------------------------------------------------------------------------------------
+    def emit_tail(self):
+        p, L = self.plan, self.L
+        km = self.km
+        # the generic code of the leaf, one lane per instance, from wherever the kernel above stopped (normally: nowhere)
+        L.append("// instances the time-parallel kernel handed back (b.resume[i] < frames) finish the launch here, frame by frame, with the")
+        L.append("// generic section code -- the exact serial semantics; every other lane leaves at once. The block the hand-back happened in")
+        L.append("// has had its @block already.")
+        L.append(f'extern "C" __global__ void __launch_bounds__(64) {km[:-1]}_tail)(ZabBatch b, ZabAudio a) {{')
+        L.append("  ZA_KERNEL_ENTRY();")
+        L.append("  const int inst = blockIdx.x * 64 + threadIdx.x;")
+        L.append("  if (inst >= b.n_inst) return;")
+        L.append("  const int64_t from = b.resume[inst];")
+        L.append("  if (from >= a.frames) return;")
+        L.append("  ZaS s;")
+        L.append("  za_state_load(s, b, inst);")
+        L.append("  uint64_t pend_seen = 0;")
+        L.append(f"  const float* in = a.in + (int64_t)inst * {p.nch} * a.frame_stride;")
+        L.append(f"  float* out = a.out + (int64_t)inst * {p.nch} * a.frame_stride;")
+        L.append(f"  const int64_t blk = {'a.block > 0 ? (int64_t)a.block : a.frames' if p.has_block else 'a.frames'};")
+        L.append("  { const int64_t b0 = (from / blk) * blk, n0 = a.frames - b0 < blk ? a.frames - b0 : blk; s.samplesblock = (double)n0; s.block_size = (int)n0; }")
+        L.append("  for (int64_t t = from; t < a.frames; ++t) {")
+        if p.has_block:
+            L.append("    if (t != from && t % blk == 0) {")
+            L.append("      const int64_t n = a.frames - t < blk ? a.frames - t : blk;")
+            L.append("      s.samplesblock = (double)n;")
+            L.append("      s.block_size = (int)n;")
+            L.append("#if ZA_USES_MSG")
+            L.append("      za_msg_begin_block(s);")
+            L.append("#endif")
+            L.append("      za_section_block(s);")
+            L.append("      if (s.pend_change | s.pend_automate | s.pend_automate_end) za_section_slider(s);")
+            L.append("      pend_seen |= s.pend_change | s.pend_automate | s.pend_automate_end;")
+            L.append("      s.pend_change = s.pend_automate = s.pend_automate_end = 0;")
+            L.append("    }")
+        for ch in range(p.nch):
+            L.append(f"    s.spl[{ch}] = (double)in[{ch} * a.frame_stride + t];")
+        L.append("    za_section_sample(s);")
+        for ch in range(p.nch):
+            L.append(f"    out[{ch} * a.frame_stride + t] = (float)s.spl[{ch}];")
+        L.append("  }")
+        L.append("  za_state_store(s, b, inst);")
+        L.append("  if (pend_seen) b.pend[3 * (int64_t)b.n_pad + inst] |= pend_seen;")
+        L.append("  b.resume[inst] = a.frames;")
+        L.append("}")
+
+
+def emit_hip(plan: Plan, prog: Program, kernel_macro: str = "ZA_KERNEL(tpar)") -> str:
+    """Kernel + launcher text, appended to a leaf module after zab_generic.hip.h (which defines ZabBatch / ZabAudio)."""
+    return _Emit(plan, prog, kernel_macro).emit()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# 4. numpy restatement of the staged algorithm (tests)
+# ----------------------------------------------------------------------------------------------------------------------
 class MtStream:
     """MT19937 as za_mt_next (csrc/zart.h) runs it, in the form the kernels use: two generations side by side, the next one
     produced from the current one in three lane-parallel phases (element k of a new generation needs new[k - 227] from
@@ -760,10 +2607,6 @@ class MtStream:
 
 _MT_CTX: List[Optional[MtStream]] = [None]
 
-ULDS_THRESHOLD = 64   # launch-constant values beyond which they live in LDS rather than in (spilled) scalar registers
-SPEC_TOL = 1.0e-13    # relative change of a state between two iterations below which it counts as settled (ZT_SPEC_TOL)
-SPEC_MAX = 8          # iterations of a switched recurrence before the chunk falls back to its serial loop (ZT_SPEC_MAX)
-
 
 def _scan_exclusive(A, b, c0):
     """Kogge-Stone over the lanes, element = the map y -> A y + b, combined as (current o earlier); returns the state BEFORE
@@ -786,6 +2629,10 @@ def _scan_exclusive(A, b, c0):
 
 def _truthy(a):
     return (a < 0.0) | (a > 0.0)
+
+
+def _is_hold(a):
+    return np.asarray(a, dtype=np.float64).view(np.uint64) == np.uint64(HOLD_BITS)
 
 
 def _i32(a):
@@ -874,1070 +2721,429 @@ def _np_op(op, a):
     raise AssertionError(op)
 
 
-def _sccs(n_nodes: int, succ: List[List[int]]) -> List[List[int]]:
-    """Tarjan, iterative. Returns the components in reverse topological order."""
-    index = [-1] * n_nodes
-    low = [0] * n_nodes
-    on = [False] * n_nodes
-    stack: List[int] = []
-    out: List[List[int]] = []
-    counter = 0
-    for root in range(n_nodes):
-        if index[root] != -1:
-            continue
-        work = [(root, 0)]
-        while work:
-            v, pi = work.pop()
-            if pi == 0:
-                index[v] = low[v] = counter
-                counter += 1
-                stack.append(v)
-                on[v] = True
-            recurse = False
-            for k in range(pi, len(succ[v])):
-                w = succ[v][k]
-                if index[w] == -1:
-                    work.append((v, k + 1))
-                    work.append((w, 0))
-                    recurse = True
-                    break
-                if on[w]:
-                    low[v] = min(low[v], index[w])
-            if recurse:
-                continue
-            if low[v] == index[v]:
-                comp = []
-                while True:
-                    w = stack.pop()
-                    on[w] = False
-                    comp.append(w)
-                    if w == v:
-                        break
-                out.append(comp)
-            if work:
-                u = work[-1][0]
-                low[u] = min(low[u], low[v])
-    return out
+def _sites_ok(a0, s0, lo0, hi0, a1, s1, lo1, hi1) -> bool:
+    """zt_sites_ok of csrc/zart_tpar.h: two address sequences a0 + k * s0 and a1 + k * s1 never name one cell."""
+    if hi0 < lo0 or hi1 < lo1:
+        return True                         # (no trips)
+    if hi0 < lo1 or hi1 < lo0:
+        return True
+    if s0 != s1 or s0 == 0:
+        return False
+    return (a1 - a0) % s0 != 0
 
 
-def build_plan(prog: Program, nch: int) -> Plan:
-    """Raises Unsupported when the leaf cannot take the time-parallel kernel."""
-    if not prog.has("sample") or nch <= 0:
-        raise Unsupported("no audio @sample")
-    if prog.has("block"):
-        raise Unsupported("@block present")
-    g = FrameGraph(prog, nch)
-    for st in prog.sections["sample"]:
-        g.ev(st)
-    if g.scope:
-        raise AssertionError("scope leak")
-    if g.rand_sites * WAVE > MT_N:
-        raise Unsupported("more rand() calls per chunk than one generation of the generator holds")
-    plan = Plan()
-    plan.g, plan.nch = g, nch
-    written = list(g.written)
-    # variables @sample leaves as they were (x = x) are not state
-    for name in list(written):
-        vn = g.varnodes.get(name)
-        if vn is not None and g.env.get(name) is vn:
-            written.remove(name)
-    wset = set(written)
-    for name, vn in g.varnodes.items():
-        if vn.kind == "var":
-            vn.kind = "st" if name in wset else "inv"
-    plan.outs = {name: g.env[name] for name in written}
-    plan.spl_out = [g.env.get(f"spl{ch}", None) or g.read(f"spl{ch}") for ch in range(nch)]
-    plan.st = {name: vn for name, vn in g.varnodes.items() if vn.kind == "st"}
-    plan.cells = dict(g.cells)
-    plan.stores, plan.loads = list(g.stores), list(g.loads)
-    for st_ in plan.stores:
-        if st_.pred is not None:
-            raise Unsupported("conditional store to a moving mem[] address")
-    if plan.stores and g.rand_sites:
-        raise Unsupported("rand() together with delay lines")
-    for ld in plan.loads:
-        # a load may have to take its value from a store of this chunk: it waits for every store of its own buffer (address
-        # and value) and, for the aliasing check, for the addresses of all the others
-        reg = g._region(ld.args[0])
-        ld.name = ",".join(map(str, reg))
-        ld.extra = tuple(x for st_ in plan.stores for x in ((st_.addr, st_.value) if st_.region == reg else (st_.addr,)))
+class _Sim:
+    """State of one Plan.simulate call."""
 
-    # live nodes
-    live: Dict[int, N] = {}
-    todo = list(plan.outs.values()) + list(plan.spl_out) + [x for st_ in plan.stores for x in (st_.addr, st_.value)]
-    todo += [a for a in plan.cells.values()]
-    while todo:
-        n = todo.pop()
-        if n.i in live:
-            continue
-        live[n.i] = n
-        todo.extend(n.args)
-        todo.extend(n.extra)
-        if n.kind == "st":
-            todo.append(plan.outs[n.name])
-    order = sorted(live)                     # creation order is a topological order of the in-frame edges
-    pos = {i: k for k, i in enumerate(order)}
-    succ: List[List[int]] = [[] for _ in order]
-    for i in order:
-        n = live[i]
-        for a in n.args + n.extra:
-            succ[pos[a.i]].append(pos[i])
-        if n.kind == "st":
-            succ[pos[plan.outs[n.name].i]].append(pos[i])
-    comps_raw = _sccs(len(order), succ)
-    comp_of: Dict[int, int] = {}
-    components: List[Component] = []
-    for comp in comps_raw:
-        ids = [order[k] for k in comp]
-        cyclic = len(ids) > 1 or any(pos[ids[0]] in succ[pos[ids[0]]] for _ in (0,))
-        if not cyclic:
-            continue
-        members = [live[i] for i in sorted(ids)]
-        if any(m.kind == "ld" for m in members):
-            raise Unsupported("feedback through a delay line (a stored value depends on a load of the same buffer)")
-        names = [m.name for m in members if m.kind == "st"]
-        names.sort(key=lambda nm: written.index(nm))
-        c = Component(names, members)
-        for m in members:
-            comp_of[m.i] = len(components)
-        components.append(c)
-
-    # uniform (per launch) nodes
-    for i in order:
-        n = live[i]
-        if n.kind in ("const", "inv"):
-            n.uniform = True
-        elif n.kind in ("st", "in", "ld"):
-            n.uniform = False
-        else:
-            n.uniform = all(a.uniform for a in n.args) and n.i not in comp_of
-    # affine forms
-    import os
-    for ci, c in enumerate(components):
-        _classify(g, plan, c, comp_of, ci)
-        if c.kind == "spec" and os.environ.get("ZA_TPAR_NO_SPEC"):
-            c.kind = "serial"
-    # nodes created by the affine analysis: liveness / uniformity of the new coefficient nodes. Placeholder-dependent nodes
-    # and the synthetic compares live inside their unit only.
-    inside = {x.i for c in components if c.kind == "spec" for x in c.gdep + c.gnodes + c.slice}
-    extra: Dict[int, N] = {}
-    todo = [x for c in components if c.kind in ("scan", "spec") for row in c.A for x in row]
-    todo += [x for c in components if c.kind in ("scan", "spec") for x in c.b]
-    todo += [a for c in components if c.kind == "spec" for x in c.gdep + c.slice for a in x.args]
-    while todo:
-        n = todo.pop()
-        if n.i in live or n.i in extra or n.i in inside:
-            continue
-        extra[n.i] = n
-        todo.extend(n.args)
-    for i in sorted(extra):
-        n = extra[i]
-        live[i] = n
-        n.uniform = n.kind in ("const", "inv") or (n.kind == "op" and all(a.uniform for a in n.args))
-    order = sorted(live)
-
-    # ---- schedule of one chunk --------------------------------------------------------------------------------------------
-    plan.uniform = [live[i] for i in order if live[i].uniform]
-    plan.invariants = [n for n in plan.uniform if n.kind == "inv"]
-    plan.inputs = [live[i] for i in order if live[i].kind == "in"]
-    done = {n.i for n in plan.uniform} | {n.i for n in plan.inputs}
-    pending_nodes = [live[i] for i in order if i not in done]
-    comp_done = [False] * len(components)
-    items: List[tuple] = []
-
-    def comp_inputs(c: Component) -> List[N]:
-        return c.inputs
-
-    for c in components:
-        mem = {m.i for m in c.members}
-        ext, seen = [], set()
-        for m in c.members:
-            for a in m.args:
-                if a.i not in mem and a.i not in seen:
-                    seen.add(a.i)
-                    ext.append(a)
-        c.ext = ext
-        if c.kind == "scan":
-            c.inputs = [x for row in c.A for x in row] + list(c.b)
-        elif c.kind == "spec":
-            own = {x.i for x in c.gdep + c.gnodes + c.slice} | mem
-            ins, seen = list(ext), {x.i for x in ext}
-            for x in [y for row in c.A for y in row] + list(c.b) + [a for y in c.gdep + c.slice for a in y.args]:
-                if x.i not in own and x.i not in seen:
-                    seen.add(x.i)
-                    ins.append(x)
-            c.inputs = ins
-        else:
-            c.inputs = ext
-
-    site_done: set = set()
-    remaining = list(pending_nodes)
-    guard = 0
-    while remaining:
-        guard += 1
-        if guard > 10 * len(order) + 100:
-            raise AssertionError("scheduler made no progress")
-        progressed = False
-        nxt = []
-        for n in remaining:
-            if n.kind == "st":
-                ci = comp_of.get(n.i)
-                if ci is None:                              # delayed signal
-                    if plan.outs[n.name].i in done:
-                        items.append(("shift", n.name))
-                        done.add(n.i)
-                        progressed = True
-                    else:
-                        nxt.append(n)
-                elif comp_done[ci]:
-                    done.add(n.i)
-                    progressed = True
-                else:
-                    nxt.append(n)
-                continue
-            if all(a.i in done for a in n.args + n.extra):
-                if n.kind == "ld":
-                    for st_ in plan.stores:              # every write's span is known before the first read is resolved
-                        if st_.j not in site_done:
-                            site_done.add(st_.j)
-                            items.append(("site", st_))
-                items.append(("par", n))
-                done.add(n.i)
-                progressed = True
-            else:
-                nxt.append(n)
-        remaining = nxt
-        # scans as soon as their coefficients exist (they are lane-parallel work too)
-        for ci, c in enumerate(components):
-            if not comp_done[ci] and c.kind == "scan" and all(x.i in done for x in comp_inputs(c)):
-                items.append(("scan", c))
-                comp_done[ci] = True
-                progressed = True
-        if progressed:
-            continue
-        # only switched / serial recurrences can move now: every one of a kind that is ready shares one loop
-        for kind in ("spec", "serial"):
-            ready = [ci for ci, c in enumerate(components) if not comp_done[ci] and c.kind == kind and all(x.i in done for x in c.inputs)]
-            if ready:
-                break
-        if not ready:
-            raise AssertionError("dependency cycle outside the recurrences")
-        items.append((kind, [components[ci] for ci in ready]))
-        for ci in ready:
-            comp_done[ci] = True
-    for st_ in plan.stores:
-        if st_.j not in site_done:
-            items.append(("site", st_))
-    plan.items = items
-    plan.uses_rand = RNG_INDEX in plan.outs
-    plan.stats = {
-        "nodes": len(order), "uniform": len(plan.uniform), "par": sum(1 for it in items if it[0] == "par"),
-        "shift": sum(1 for it in items if it[0] == "shift"),
-        "scan1": sum(1 for it in items if it[0] == "scan" and len(it[1].names) == 1),
-        "scan2": sum(1 for it in items if it[0] == "scan" and len(it[1].names) == 2),
-        "spec_loops": sum(1 for it in items if it[0] == "spec"),
-        "spec_chains": sum(len(it[1]) for it in items if it[0] == "spec"),
-        "spec_switches": sum(len(c.conds) for it in items if it[0] == "spec" for c in it[1]),
-        "serial_loops": sum(1 for it in items if it[0] == "serial"),
-        "serial_chains": sum(len(it[1]) for it in items if it[0] == "serial"),
-        "serial_ops": sum(len([m for m in c.members if m.kind != "st"]) for it in items if it[0] == "serial" for c in it[1]),
-        "states": len(plan.st), "written": len(plan.outs), "rand_sites": g.rand_sites,
-        "mem_cells": len(plan.cells), "delay_writes": len(plan.stores), "delay_reads": len(plan.loads),
-    }
-    return plan
+    def __init__(self, plan: Plan, memv, tn):
+        self.plan, self.memv, self.tn = plan, memv, tn
 
 
-def _classify(g: FrameGraph, plan: Plan, c: Component, comp_of: Dict[int, int], ci: int = 0):
-    """Affine in the component's own states, with coefficients that do not depend on them? -> "scan".
-    Affine once the state-dependent conditions (switches) are fixed? -> "spec". Otherwise it stays "serial"."""
-    mem = {m.i for m in c.members}
-    names = c.names
-    d = len(names)
-    if d > 2:
-        return
+def _simulate(self: Plan, vars0: Dict[str, float], x: np.ndarray, sliders=None, srate=48000.0, spl0=None, mt=None, mem=None):
+    """x: [nch, frames] float32. vars0: name -> value before the launch (missing names are 0). mt: (randMT[624], randIndex)
+    before the launch for scripts that call rand(); self.mt_after holds the pair after it. mem: the arena before the launch
+    (numpy doubles) for scripts that touch mem[]; self.mem_after / self.mem_high_after hold it after. The launch is taken as
+    one block (@block, if the script has one, is not run here).
+    Returns (y float32 [nch, frames], vars after {name: value}, spl after {k: value}). Raises TparAbort when a chunk breaks
+    one of the run-time conditions of the lowering (the kernel hands such a launch to the serial code)."""
+    memv = np.zeros(1 << 16) if mem is None else np.array(mem, dtype=np.float64)
+    mcap = len(memv)
+    mem_high = [0]
+    stream = MtStream(*(mt if mt is not None else (None, 0))) if self.uses_rand else None
+    _MT_CTX[0] = stream
+    x = np.asarray(x, dtype=np.float32)
+    frames = x.shape[1]
+    sliders = np.zeros(64) if sliders is None else np.asarray(sliders, dtype=np.float64)
+    spl_state = dict(spl0 or {})
+    top = self.top
+    lane = np.arange(WAVE)
 
-    def add(a: N, b: N) -> N:
-        if a is g.ZERO:
-            return b
-        if b is g.ZERO:
-            return a
-        return g.op("+", a, b)
-
-    def sub(a: N, b: N) -> N:
-        if b is g.ZERO:
-            return a
-        if a is g.ZERO:
-            return g.op("neg", b)
-        return g.op("-", a, b)
-
-    def mul(a: N, b: N) -> N:
-        if a is g.ZERO or b is g.ZERO:
-            return g.ZERO
-        if a is g.ONE:
-            return b
-        if b is g.ONE:
-            return a
-        return g.op("*", a, b)
-
-    def attempt(allow_guess: bool):
-        memo: Dict[int, Optional[tuple]] = {}
-        conds: List[N] = []
-        gnodes: List[N] = []
-
-        def guess_for(cond: N) -> N:
-            for k, x in enumerate(conds):
-                if x is cond:
-                    return gnodes[k]
-            conds.append(cond)
-            gn = g.mk("guess", name=f"{ci}", val=len(gnodes))
-            gnodes.append(gn)
-            return gn
-
-        def pick(cnd: N, a, b):
-            co = {k: g.sel(cnd, a[0].get(k, g.ZERO), b[0].get(k, g.ZERO)) for k in set(a[0]) | set(b[0])}
-            return (co, g.sel(cnd, a[1], b[1]))
-
-        def aff(n: N):
-            if n.i not in mem:
-                return ({}, n)
-            if n.i in memo:
-                return memo[n.i]
-            r = None
-            if n.kind == "st":
-                r = ({n.name: g.ONE}, g.ZERO)
-            elif n.kind == "op":
-                op = n.op
-                if op in ("+", "-"):
-                    a, b = aff(n.args[0]), aff(n.args[1])
-                    if a and b:
-                        f = add if op == "+" else sub
-                        co = {k: f(a[0].get(k, g.ZERO), b[0].get(k, g.ZERO)) for k in set(a[0]) | set(b[0])}
-                        r = (co, f(a[1], b[1]))
-                elif op == "neg":
-                    a = aff(n.args[0])
-                    if a:
-                        r = ({k: sub(g.ZERO, v) for k, v in a[0].items()}, sub(g.ZERO, a[1]))
-                elif op == "*":
-                    a, b = aff(n.args[0]), aff(n.args[1])
-                    if a and b:
-                        if not a[0]:
-                            r = ({k: mul(a[1], v) for k, v in b[0].items()}, mul(a[1], b[1]))
-                        elif not b[0]:
-                            r = ({k: mul(v, b[1]) for k, v in a[0].items()}, mul(a[1], b[1]))
-                elif op == "/":
-                    a, b = aff(n.args[0]), aff(n.args[1])
-                    if a and b and not b[0]:
-                        r = ({k: g.op("/", v, b[1]) for k, v in a[0].items()}, g.op("/", a[1], b[1]) if a[1] is not g.ZERO else g.ZERO)
-                elif op == "sel":
-                    cnd = n.args[0]
-                    if cnd.i not in mem or allow_guess:
-                        a, b = aff(n.args[1]), aff(n.args[2])
-                        if a and b:
-                            r = pick(cnd if cnd.i not in mem else guess_for(cnd), a, b)
-                elif op in ("min", "max") and allow_guess:      # za_min(a, b) = a < b ? a : b,  za_max(a, b) = a > b ? a : b
-                    a, b = aff(n.args[0]), aff(n.args[1])
-                    if a and b:
-                        r = pick(guess_for(g.op("<" if op == "min" else ">", n.args[0], n.args[1])), a, b)
-                elif op == "fabs" and allow_guess:                # |x| = x < 0 ? -x : x
-                    a = aff(n.args[0])
-                    if a:
-                        neg = ({k: sub(g.ZERO, v) for k, v in a[0].items()}, sub(g.ZERO, a[1]))
-                        r = pick(guess_for(g.op("<", n.args[0], g.ZERO)), neg, a)
-            memo[n.i] = r
-            return r
-
-        rows = []
-        for nm in names:
-            r = aff(plan.outs[nm])
-            if r is None:
-                return None
-            rows.append(r)
-        return rows, conds, gnodes
-
-    if d == 1 and _persistent_rounding(g, plan, c, mem):
-        return                                    # stays "serial": see _persistent_rounding
-    res = attempt(False)
-    if res is not None:
-        c.kind = "scan"
-    else:
-        res = attempt(True)
-        if res is None:
-            return
-        c.kind = "spec"
-    rows, c.conds, c.gnodes = res
-    c.A = [[rows[r][0].get(names[k], g.ZERO) for k in range(d)] for r in range(d)]
-    c.b = [rows[r][1] for r in range(d)]
-    if c.kind == "spec":
-        # coefficient nodes that depend on a placeholder (evaluated inside the iteration), topological = creation order
-        dep: Dict[int, bool] = {}
-
-        def gd(n: N) -> bool:
-            if n.i in dep:
-                return dep[n.i]
-            r = n.kind == "guess" or any(gd(x) for x in n.args)
-            dep[n.i] = r
-            return r
-
-        seen: Dict[int, N] = {}
-        todo = [x for row in c.A for x in row] + list(c.b)
-        while todo:
-            n = todo.pop()
-            if n.i in seen or not gd(n):
-                continue
-            seen[n.i] = n
-            todo.extend(n.args)
-        c.gdep = [seen[i] for i in sorted(seen) if seen[i].kind != "guess"]
-        # nodes needed to evaluate the conditions from the states: members (and the synthetic compares) only
-        sl: Dict[int, N] = {}
-        todo = list(c.conds)
-        synth = {x.i for x in c.conds if x.i not in mem}
-        while todo:
-            n = todo.pop()
-            if n.i in sl or (n.i not in mem and n.i not in synth):
-                continue
-            sl[n.i] = n
-            todo.extend(n.args)
-        c.slice = [sl[i] for i in sorted(sl) if sl[i].kind != "st"]
-
-
-def _const_value(n: N) -> Optional[float]:
-    """Value of a node built from constants only."""
-    if n.kind == "const":
-        return float(n.val)
-    if n.kind == "op" and n.op in ("+", "-", "*", "neg") and n.args:
-        v = [_const_value(a) for a in n.args]
-        if any(x is None for x in v):
-            return None
-        return {"+": lambda: v[0] + v[1], "-": lambda: v[0] - v[1], "*": lambda: v[0] * v[1], "neg": lambda: -v[0]}[n.op]()
-    return None
-
-
-def _persistent_rounding(g: FrameGraph, plan: Plan, c: Component, mem) -> bool:
-    """A recurrence y = y + b with a fractional step keeps every rounding error it ever made (coefficient exactly 1: nothing
-    decays), and scripts put thresholds exactly where such sums are meant to land -- `pos += 1 / N; pos < 1 ? ...` reaches
-    1 after N steps only up to rounding, so the frame at which the test flips depends on the ORDER of the additions. A scan
-    re-associates them. Such components therefore keep their serial loop (exact order); integer-valued steps (counters,
-    hold timers) are exact in any order and stay scans, and |a| < 1 forgets its rounding, so thresholds on it are generic.
-    Decided on the branch-wise affine forms of the new state: (coefficient on itself, constant term) per path through ?: /
-    min / max; any path with coefficient 1 and a constant term that is not an integer literal marks the component."""
-    nm = c.names[0]
-    limit = 256
-
-    def forms(n: N):
-        if n.i not in mem:
-            return [(g.ZERO, n)]
-        if n.kind == "st":
-            return [(g.ONE, g.ZERO)]
-        if n.kind != "op":
-            return None
-        if n.op == "sel":
-            a, b = forms(n.args[1]), forms(n.args[2])
-            return None if a is None or b is None or len(a) + len(b) > limit else a + b
-        if n.op in ("min", "max"):
-            a, b = forms(n.args[0]), forms(n.args[1])
-            return None if a is None or b is None or len(a) + len(b) > limit else a + b
-        if n.op == "fabs":
-            a = forms(n.args[0])
-            return None if a is None else a + [(g.op("neg", k), g.op("neg", v)) for k, v in a]
-        if n.op in ("+", "-"):
-            a, b = forms(n.args[0]), forms(n.args[1])
-            if a is None or b is None or len(a) * len(b) > limit:
-                return None
-            return [(g.op(n.op, ka, kb), g.op(n.op, va, vb)) for ka, va in a for kb, vb in b]
-        if n.op == "neg":
-            a = forms(n.args[0])
-            return None if a is None else [(g.op("neg", k), g.op("neg", v)) for k, v in a]
-        if n.op == "*":
-            a, b = forms(n.args[0]), forms(n.args[1])
-            if a is None or b is None or len(a) * len(b) > limit:
-                return None
-            out = []
-            for ka, va in a:
-                for kb, vb in b:
-                    if _const_value(ka) == 0.0:
-                        out.append((g.op("*", va, kb), g.op("*", va, vb)))
-                    elif _const_value(kb) == 0.0:
-                        out.append((g.op("*", ka, vb), g.op("*", va, vb)))
-                    else:
-                        return None
-            return out
-        if n.op == "/":
-            a, b = forms(n.args[0]), forms(n.args[1])
-            if a is None or b is None or any(_const_value(kb) != 0.0 for kb, _ in b) or len(a) * len(b) > limit:
-                return None
-            return [(g.op("/", ka, vb), g.op("/", va, vb)) for ka, va in a for _, vb in b]
-        return None
-
-    fs = forms(plan.outs[nm])
-    if fs is None:
-        return False                              # not affine even branch-wise: the classification below decides
-    for k, v in fs:
-        if _const_value(k) == 1.0:
-            cv = _const_value(v)
-            if cv is None or cv != math.floor(cv):
-                return True
-    return False
-
-
-def try_plan(prog: Program, nch: int) -> Tuple[Optional[Plan], str]:
-    try:
-        return build_plan(prog, nch), ""
-    except Unsupported as ex:
-        return None, str(ex)
-
-
-# ----------------------------------------------------------------------------------------------------------------------
-# 3. HIP emission (csrc/zart_tpar.h holds the wavefront primitives)
-# ----------------------------------------------------------------------------------------------------------------------
-_INFIX = {"+": "+", "-": "-", "*": "*", "/": "/"}
-_CMP = {"<": "<", "<=": "<=", ">": ">", ">=": ">=", "==": "=="}
-_FN2 = {"^": "pow", "|": "za_or", "&": "za_and", "~": "za_xor", "<<": "za_shl", ">>": "za_shr", "%": "za_mod", "!=": "za_ne",
-        "min": "za_min", "max": "za_max", "pow": "pow", "atan2": "atan2"}
-_POW_BASE = {"10.0": "exp10", "2.0": "exp2", c_double(math.e): "exp"}
-_FN1 = {"neg": "za_neg", "not": "za_not", "sqr": "za_sqr", "sign": "za_sign", "invsqrt": "za_invsqrt"}
-
-
-def _expr(op: str, a: List[str]) -> str:
-    """Same C++ spelling as zajit/emit.py gives the construct, so both kernels share zart.h's semantics."""
-    if op in _INFIX:
-        return f"({a[0]} {_INFIX[op]} {a[1]})"
-    if op in _CMP:
-        return f"za_b({a[0]} {_CMP[op]} {a[1]})"
-    if op in ("^", "pow") and a[0] in _POW_BASE and not os.environ.get("ZA_TPAR_PLAIN_POW"):
-        # constant base: the dedicated exponential (68 instructions on gfx950) instead of the general pow (240); both are
-        # accurate to the last bits, so results agree to ~4e-16 relative -- 10^(dB/20) is the commonest libm call in the catalog
-        return f"{_POW_BASE[a[0]]}({a[1]})"
-    if op in _FN2:
-        return f"{_FN2[op]}({a[0]}, {a[1]})"
-    if op in _FN1:
-        return f"{_FN1[op]}({a[0]})"
-    if op == "truth":
-        return f"za_b(za_truthy({a[0]}))"
-    if op == "land":
-        return f"za_b(za_truthy({a[0]}) && za_truthy({a[1]}))"
-    if op == "lor":
-        return f"za_b(za_truthy({a[0]}) || za_truthy({a[1]}))"
-    if op == "sel":
-        return f"(za_truthy({a[0]}) ? {a[1]} : {a[2]})"
-    if op in PURE_MATH1:
-        return f"{PURE_MATH1[op]}({a[0]})"
-    if op == "mtout":
-        return f"zt_mt_word(zt_mt, zt_pos0, {a[0]})"
-    if op == "addr":
-        return f"(double)za_addr({a[0]}, {a[1]})"
-    raise AssertionError(op)
-
-
-def emit_hip(plan: Plan, prog: Program, kernel_macro: str = "ZA_KERNEL(tpar)") -> str:
-    """Kernel + launcher text, appended to a leaf module after zab_generic.hip.h (which defines ZabBatch / ZabAudio)."""
-    g = plan.g
-    L: List[str] = []
-
-    # Launch-constant values: a few dozen fit the scalar registers (ZT_UNI); past that the compiler spills them into lanes of
-    # vector registers and every use costs two v_readlane. Large scripts keep them in LDS instead: one broadcast ds_read_b64 per
-    # use, the `zo` offset (an opaque 0 set per chunk) keeping the reads inside the iteration.
-    n_uni = sum(1 for n in plan.uniform if n.kind != "const")
-    mode = os.environ.get("ZA_TPAR_ULDS", "auto")
-    ulds = mode == "1" or (mode == "auto" and n_uni > ULDS_THRESHOLD)
-    uslot = {n.i: k for k, n in enumerate(x for x in plan.uniform if x.kind != "const")}
-    in_loop = [False]
-
-    def ref(n: N) -> str:
-        if n.kind == "const":
-            return c_double(n.val)
-        if n.uniform and ulds and in_loop[0]:
-            return f"zt_u[{uslot[n.i]} + zo]"
-        return (f"u{n.i}" if n.uniform else f"n{n.i}")
-
-    def inv_src(name: str) -> str:
+    def inv_value(name):
         k = is_slider_name(name)
         if k is not None:
-            return f"b.sliders[{k - 1} * b.sl_se + inst * b.sl_si]"
+            return float(sliders[k - 1])
         if name == "srate":
-            return "b.srate"
+            return float(srate)
+        if name == "samplesblock":
+            return float(frames)
         if name in ("midi_bus", "ext_midi_bus", RNG_INDEX) or name.startswith("memw@"):
-            return "0.0"
-        if name in plan.cells:
-            return f"(ca{plan.cells[name].i} < mcap ? memp[ca{plan.cells[name].i} * mse] : 0.0)"
+            return 0.0
+        if name in self.cells:
+            a = int(val[self.cells[name].i])
+            return float(memv[a]) if a < len(memv) else 0.0
         k = is_spl_name(name)
         if k is not None:
-            return f"b.spl[{k} * b.sl_se + inst * b.sl_si]"
-        return f"b.vars[{prog.vars[name]} * b.var_se + inst * b.var_si]"
+            return float(spl_state.get(k, 0.0))
+        return float(vars0.get(name, 0.0))
 
-    def dst(name: str) -> str:
-        if name in plan.cells:
-            return f"memp[ca{plan.cells[name].i} * mse]"
-        k = is_spl_name(name)
-        if k is not None:
-            return f"b.spl[{k} * b.sl_se + inst * b.sl_si]"
-        return f"b.vars[{prog.vars[name]} * b.var_se + inst * b.var_si]"
+    val: Dict[int, np.ndarray] = {}
+    self.spec_log = []                     # (states, iterations, converged) per switched recurrence and chunk
 
-    cname = {name: f"c{k}" for k, name in enumerate(plan.st)}
-    L.append("// ---- time-parallel kernel: one wavefront per instance, lane = frame (generated by zajit/tpar.py) ----")
-    L.append(f"// schedule: {plan.stats}")
-    L.append("#ifndef ZT_SPEC_MAX")
-    L.append(f"#define ZT_SPEC_MAX {SPEC_MAX}")
-    L.append("#endif")
-    L.append(f"#define ZT_SPEC_TOL {SPEC_TOL!r}")
-    L.append("#ifndef ZT_UNI")
-    L.append("#define ZT_UNI(x) zt_uniform(x)")
-    L.append("#endif")
-    L.append(f'extern "C" __global__ void __launch_bounds__(64) {kernel_macro}(ZabBatch b, ZabAudio a) {{')
-    L.append("  const int lane = threadIdx.x;")
-    L.append("  const int64_t inst = blockIdx.x;")
-    L.append("  const int64_t frames = a.frames;")
-    L.append("  if (frames <= 0 || inst >= b.n_inst) return;")
-    if plan.uses_rand:
-        L.append("  __shared__ uint32_t zt_mt[2 * ZT_MT_N];      // rand(): current and next generation of the instance's MT19937")
-        L.append("  uint32_t* const zt_gmt = b.mt + inst * b.mt_si;")
-        L.append("  int zt_pos0 = zt_mt_begin(zt_mt, zt_gmt, b.mt_se, b.mti[inst], lane);")
-    L.append("  // per launch: invariants and everything that depends on them only")
-    for n in plan.uniform:
+    def V(n: N):
         if n.kind == "const":
-            continue
-        if n.kind == "inv":
-            L.append(f"  const double u{n.i} = {inv_src(n.name)};   // {n.name}")
-        else:
-            L.append(f"  const double u{n.i} = ZT_UNI({_expr(n.op, [ref(x) for x in n.args])});")
-    if ulds:
-        L.append(f"  __shared__ double zt_u[{max(1, n_uni)}];")
-        L.append("  if (lane == 0) {")
-        for n in plan.uniform:
-            if n.kind != "const":
-                L.append(f"    zt_u[{uslot[n.i]}] = u{n.i};")
-        L.append("  }")
-        L.append("  __syncthreads();")
-    has_mem = bool(plan.cells or plan.stores or plan.loads)
-    has_streams = bool(plan.stores)
-    cell_addrs: List[N] = []
-    for a in plan.cells.values():
-        if a not in cell_addrs:
-            cell_addrs.append(a)
-    if has_mem:
-        L.append("  // mem[]: launch-constant addresses are cells (named state kept in registers), moving ones are delay lines")
-        L.append("  double* const memp = b.mem + inst * b.mem_si;")
-        L.append("  const int64_t mse = b.mem_se, mcap = b.mem_cap;")
-        L.append("  int64_t zt_high = b.mem_high[inst], zt_hc = 0;")
-        for a in cell_addrs:
-            L.append(f"  const int64_t ca{a.i} = (int64_t){ref(a)};")
-        if cell_addrs:
-            clash = " || ".join([f"ca{a.i} >= mcap" for a in cell_addrs] +
-                                [f"ca{a.i} == ca{b_.i}" for i_, a in enumerate(cell_addrs) for b_ in cell_addrs[i_ + 1:]])
-            lo = cell_addrs[0]
-            L.append(f"  int64_t cmin = ca{lo.i}, cmax = ca{lo.i};")
-            for a in cell_addrs[1:]:
-                L.append(f"  cmin = ca{a.i} < cmin ? ca{a.i} : cmin; cmax = ca{a.i} > cmax ? ca{a.i} : cmax;")
-            L.append(f"  if ({clash}) {{   // cells that alias each other (or lie past the arena): not a case for this kernel")
-            L.append("    if (lane == 0) b.resume[inst] = 0;")
-            L.append("    return;")
-            L.append("  }")
-    # recurrences whose coefficient is constant over the launch: one LDS row of per-lane weights per distinct coefficient
-    inv_coefs: List[N] = []
-    for it in plan.items:
-        if it[0] == "scan" and len(it[1].names) == 1:
-            a = it[1].A[0][0]
-            if a.uniform and a.kind != "const" and a not in inv_coefs and not os.environ.get("ZA_TPAR_NO_INVSCAN"):
-                inv_coefs.append(a)
-    # coupled pairs with a launch-constant matrix (biquads): one table per distinct matrix, within an LDS budget that still
-    # lets four wavefronts share a CU (one per SIMD, the 1024-instance case)
-    inv_mats: List[tuple] = []
-    budget = 36 * 1024 - len(inv_coefs) * (64 + 4) * 8 - (2 * 624 * 4 if plan.uses_rand else 0)
-    for it in plan.items:
-        if it[0] == "scan" and len(it[1].names) == 2 and not os.environ.get("ZA_TPAR_NO_INVSCAN"):
-            key = tuple(x for row in it[1].A for x in row)
-            if all(x.uniform or x.kind == "const" for x in key) and key not in inv_mats and (len(inv_mats) + 1) * (12 + 8 * 64) * 8 <= budget:
-                inv_mats.append(key)
-    if inv_mats:
-        L.append(f"  __shared__ double zt_m[{len(inv_mats)} * ZT_MAT_TABLE_DOUBLES];      // per launch-constant 2 x 2 matrix: powers and per-lane weights")
-        for k, key in enumerate(inv_mats):
-            L.append(f"  {{ const ZtMat2 am = {{{ref(key[0])}, {ref(key[1])}, {ref(key[2])}, {ref(key[3])}}}; zt_mat_table(zt_m + {k} * ZT_MAT_TABLE_DOUBLES, am, lane); }}")
-        if not inv_coefs:
-            L.append("  __syncthreads();")
-    if inv_coefs:
-        L.append(f"  __shared__ double zt_w[{len(inv_coefs)} * 64];      // a^((lane & 15) + 1) per launch-constant coefficient")
-        L.append(f"  __shared__ double zt_q[{len(inv_coefs)} * 4];       // a^2, a^4, a^8, a^16")
-        for k, a in enumerate(inv_coefs):
-            L.append(f"  zt_w[{k} * 64 + lane] = zt_pow_row({ref(a)}, lane);")
-            L.append(f"  if (lane == 0) {{ const double p2 = {ref(a)} * {ref(a)}, p4 = p2 * p2, p8 = p4 * p4; zt_q[{k} * 4] = p2; zt_q[{k} * 4 + 1] = p4; zt_q[{k} * 4 + 2] = p8; zt_q[{k} * 4 + 3] = p8 * p8; }}")
-        L.append("  __syncthreads();")
-    if has_streams:
-        L.append(f"  __shared__ double zt_snap[{max(1, len(cname))}];")
-    L.append("  // state carried from frame to frame (wave-uniform)")
-    for name, c in cname.items():
-        L.append(f"  double {c} = {inv_src(name)};   // {name}")
-    L.append(f"  const float* const in_ = a.in + inst * {plan.nch} * a.frame_stride;")
-    L.append(f"  float* const out_ = a.out + inst * {plan.nch} * a.frame_stride;")
-    L.append("  // the audio of a chunk is read one iteration ahead, so that its HBM latency is hidden behind the previous chunk's work")
-    for n in plan.inputs:
-        L.append(f"  float x{n.i} = lane < frames ? in_[{int(n.val)} * a.frame_stride + lane] : 0.0f;")
-    # ZT_PIN: an empty asm that takes the prefetched registers, i.e. the point where the compiler waits for their loads. It
-    # sits before the loop and, in the loop, before the chunk's stores: the loads have had the whole chunk to land, and no
-    # path reaches the top of the loop with them pending -- there the wait would be a full vmcnt(0), taken right after the
-    # NEXT chunk's loads were issued (every chunk would pay an HBM round trip).
-    pin = ", ".join(f'"+v"(x{n.i})' for n in plan.inputs)
-    if pin:
-        L.append(f"  asm volatile(\"\" : {pin});")
-    L.append("  for (int64_t f0 = 0; f0 < frames; f0 += 64) {")
-    L.append("    const int tn = (int)(frames - f0 < 64 ? frames - f0 : 64);")
-    L.append("    const int last = tn - 1;")
-    L.append("    const bool valid = lane < tn;")
-    for n in plan.inputs:
-        L.append(f"    const double n{n.i} = (double)x{n.i};")
-    L.append("    if (f0 + 64 + lane < frames) {")
-    for n in plan.inputs:
-        L.append(f"      x{n.i} = in_[{int(n.val)} * a.frame_stride + f0 + 64 + lane];")
-    L.append("    } else {")
-    for n in plan.inputs:
-        L.append(f"      x{n.i} = 0.0f;")
-    L.append("    }")
+            return np.float64(n.val)
+        if n.kind == "hold":
+            return HOLD
+        return val[n.i]
 
-    def serial_loop(comps: List[Component], ind: str):
-        """64 uniform steps; leaves the state before each frame in k<st> of that frame's lane."""
-        for c in comps:
-            for nm in c.names:
-                s = plan.st[nm].i
-                L.append(f"{ind}double y{s} = {cname[nm]}, k{s} = {cname[nm]};")
-        L.append(f"{ind}for (int t = 0; t < tn; ++t) {{")
-        L.append(f"{ind}  const bool me = lane == t;")
-        seen_ext = set()
-        for c in comps:
-            mem = {m.i for m in c.members}
-            for nm in c.names:
-                s = plan.st[nm].i
-                L.append(f"{ind}  k{s} = me ? y{s} : k{s};")
-            for x in c.ext:
-                if not x.uniform and x.kind != "const" and x.i not in seen_ext:
-                    seen_ext.add(x.i)
-                    L.append(f"{ind}  const double e{x.i} = zt_readlane(n{x.i}, t);")
+    def vec(n: N):
+        return np.broadcast_to(V(n), (WAVE,)).astype(np.float64)
 
-            def sref(x: N, mem=mem) -> str:
-                if x.kind == "st" and x.i in mem:
-                    return f"y{x.i}"
-                if x.i in mem:
-                    return f"m{x.i}"
-                if x.kind == "const" or x.uniform:
-                    return ref(x)
-                return f"e{x.i}"
+    def uni(n: N, what):
+        v = V(n)
+        if np.ndim(v):
+            if not np.all(v.view(np.uint64) == v.view(np.uint64)[0]):
+                raise AssertionError(f"{what}: not wave-uniform")
+            v = v[0]
+        return float(v)
 
-            for m in c.members:
-                if m.kind == "st":
+    def sim_serial(reg: Region, comp: Component, carry, tn):
+        cur = {nm: carry[nm] for nm in comp.names}
+        caps = {nm: np.zeros(WAVE) for nm in comp.names}
+        for t in range(tn):
+            loc: Dict[int, np.float64] = {}
+            for nm in comp.names:
+                caps[nm][t] = cur[nm]
+                loc[reg.st[nm].i] = cur[nm]
+            for m in comp.members:
+                if m.kind in ("st", "lcin"):
                     continue
-                L.append(f"{ind}  const double m{m.i} = {_expr(m.op, [sref(x) for x in m.args])};")
-            for nm in c.names:            # all new states are computed from the old ones before any is replaced
-                L.append(f"{ind}  const double q{plan.st[nm].i} = {sref(plan.outs[nm])};")
-            for nm in c.names:
-                L.append(f"{ind}  y{plan.st[nm].i} = q{plan.st[nm].i};")
-        L.append(f"{ind}}}")
+                ops = []
+                for a in m.args:
+                    if a.i in loc:
+                        ops.append(loc[a.i])
+                    else:
+                        v = V(a)
+                        ops.append(v if np.ndim(v) == 0 else v[t])
+                loc[m.i] = np.float64(_np_op(m.op, ops))
+            for nm in comp.names:
+                cur[nm] = loc[reg.outs[nm].i] if reg.outs[nm].i in loc else np.float64(vec(reg.outs[nm])[t])
+        for nm in comp.names:
+            caps[nm][tn:] = cur[nm]
+            val[reg.st[nm].i] = caps[nm]
 
-    # Values leave the registers as early as possible: a state's carry is taken (v_readlane at the chunk's last frame) as soon
-    # as both its recurrence and its new value exist, and the values a launch must leave in vars[] -- needed in the launch's
-    # last chunk only -- are stored in small conditional batches right after they are computed, instead of all living to the
-    # end of the chunk body (144 written variables would be 288 registers per lane there).
-    in_loop[0] = True
-    if inv_coefs or inv_mats or ulds:
-        L.append("    int zo; asm volatile(\"s_mov_b32 %0, 0\" : \"=s\"(zo));   // opaque 0: keeps the table reads inside the iteration")
-    if has_streams:
-        L.append(f"    if (lane == 0) {{   // the states as they stand before this chunk, in case it has to be handed to the generic kernel")
-        for k, (name, c) in enumerate(cname.items()):
-            L.append(f"      zt_snap[{k}] = {c};")
-        L.append("    }")
-        L.append("    bool zt_bad = false, zt_badl = false;")
-    L.append("    const bool fin = f0 + 64 >= frames;   // the launch's last chunk: its last frame leaves every written variable as the script would")
-    avail = {n.i for n in plan.inputs}
-    raw_issued: set = set()
-    unit_done: set = set()
-    carried: set = set()
-    stored: set = set()
-    finals = [(name, o) for name, o in plan.outs.items() if name != RNG_INDEX]
-    finals += [(f"spl{ch}", plan.spl_out[ch]) for ch in range(plan.nch) if f"spl{ch}" not in plan.outs]
-    pending: List[tuple] = []
-
-    def ready(o: N) -> bool:
-        return o.uniform or o.kind == "const" or o.i in avail
-
-    def retire(final: bool = False):
-        for name, c in cname.items():
-            o = plan.outs[name]
-            if name not in carried and name in unit_done and ready(o):
-                carried.add(name)
-                L.append(f"    {c} = {ref(o) if (o.uniform or o.kind == 'const') else f'zt_readlane(n{o.i}, last)'};")
-        for name, o in finals:
-            if (name in plan.cells or name.startswith("memw@")) and not final:
-                continue                                   # (a cell needs its "stored to" flag beside it: both go out at the end)
-            if name not in stored and ready(o) and (final or not (o.uniform or o.kind == "const")):
-                stored.add(name)
-                pending.append((name, o))
-        if pending and (final or len(pending) >= 12):
-            L.append("    if (fin && lane == last) {")
-            for name, o in pending:
-                if name.startswith("memw@"):
+    def run_items(reg: Region, carry, f0, tn, sites):
+        """One chunk's (or one trip's) schedule. carry: state name -> value before the chunk."""
+        for it in reg.items:
+            kind = it[0]
+            if kind == "site":
+                st_: StoreSite = it[1]
+                A = vec(st_.addr).astype(np.int64)
+                if st_.mode == "sparse":
+                    on = _truthy(vec(st_.pred)) & (lane < tn)
+                    si = {"A": A, "on": on, "lo": int(A[on].min()) if on.any() else 0, "hi": int(A[on].max()) if on.any() else -1}
+                    if si["hi"] >= mcap or any(si["lo"] <= a <= si["hi"] for a in cell_addr.values()):
+                        raise TparAbort(f0, "a conditional write leaves the arena or runs over a mem[] cell")
+                    sites[st_.j] = si
                     continue
-                if name in plan.cells:                     # a cell is written back only if the launch stored to it at all
-                    flag = plan.outs.get("memw@" + name[4:])
-                    if flag is not None:
-                        L.append(f"      if ({ref(flag)} != 0.0) {{ {dst(name)} = {ref(o)}; zt_hc = zt_hc > ca{plan.cells[name].i} + 1 ? zt_hc : ca{plan.cells[name].i} + 1; }}")
-                    continue
-                L.append(f"      {dst(name)} = {ref(o)};")
-            L.append("    }")
-            pending.clear()
+                live_site = st_.pred is None or bool(_truthy(np.float64(uni(st_.pred, "store condition"))))
+                d = np.diff(A[:tn])
+                brk = np.flatnonzero(d != 1)
+                k = int(brk[0]) + 1 if len(brk) else tn
+                si = {"A": A, "a0": int(A[0]), "k": k, "ak": int(A[k]) if k < tn else 0, "live": live_site}
+                sites[st_.j] = si
+                if live_site:
+                    if len(brk) > 1 or A[:tn].min() < 0 or A[:tn].max() >= len(memv):
+                        raise TparAbort(f0, "a delay-line write does not advance by one cell per frame (or leaves the arena)")
+                    if any(lo <= a <= hi for a in cell_addr.values() for lo, hi in ((A[:tn].min(), A[:tn].max()),)):
+                        raise TparAbort(f0, "a delay line runs over a mem[] cell")
+                if len(sites) == len(self.stores):         # every span known: no two writes may touch one cell
+                    spans = {}
+                    for s2 in self.stores:
+                        q = sites[s2.j]
+                        if s2.mode == "sparse":
+                            spans[s2.j] = set(int(a) for a in q["A"][q["on"]])
+                        else:
+                            spans[s2.j] = set(int(a) for a in q["A"][:tn]) if q["live"] else set()
+                    js = list(spans)
+                    for i1 in range(len(js)):
+                        for i2 in range(i1 + 1, len(js)):
+                            lo1, hi1 = (min(spans[js[i1]]), max(spans[js[i1]])) if spans[js[i1]] else (0, -1)
+                            lo2, hi2 = (min(spans[js[i2]]), max(spans[js[i2]])) if spans[js[i2]] else (0, -1)
+                            both_sparse = self.stores[js[i1]].mode == "sparse" and self.stores[js[i2]].mode == "sparse"
+                            if (hi1 >= lo1 and hi2 >= lo2 and lo1 <= hi2 and lo2 <= hi1) if both_sparse else (spans[js[i1]] & spans[js[i2]]):
+                                raise TparAbort(f0, "two writes of a chunk touch one cell")
+                    for s2 in self.stores:                  # early writes go out now
+                        if s2.mode == "early" and sites[s2.j]["live"]:
+                            q = sites[s2.j]
+                            q["old"] = memv[q["A"][:tn]].copy()
+                            memv[q["A"][:tn]] = vec(s2.value)[:tn]
+            elif kind == "par" and it[1].kind == "ld":
+                n = it[1]
+                B = vec(n.args[0]).astype(np.int64)
+                out = np.where(B < len(memv), memv[np.minimum(B, len(memv) - 1)], 0.0)
+                best = np.full(WAVE, -1)
+                for st_ in self.stores:
+                    si = sites[st_.j]
+                    if st_.mode == "sparse":
+                        if np.any((B[:tn] >= si["lo"]) & (B[:tn] <= si["hi"])):
+                            raise TparAbort(f0, "a delay-line read falls into a conditional write's span")
+                        continue
+                    if not si["live"]:
+                        continue
+                    tw = np.full(WAVE, -1)
+                    d0 = B - si["a0"]
+                    tw = np.where((d0 >= 0) & (d0 < si["k"]), d0, tw)
+                    d1 = B - si["ak"]
+                    tw = np.where((d1 >= 0) & (d1 < tn - si["k"]), si["k"] + d1, tw)
+                    if ",".join(map(str, st_.region)) != n.name:
+                        if np.any(tw[:tn] >= 0):
+                            raise TparAbort(f0, "a delay-line read falls into another buffer's freshly written span")
+                        continue
+                    if st_.mode == "early":
+                        late = (tw > lane) | ((tw == lane) & (not st_.seq < n.val))
+                        if np.any(late[:tn]):
+                            raise TparAbort(f0, "a gather reads a cell that a later frame of the chunk has already overwritten")
+                        continue
+                    vis = (tw >= 0) & ((tw < lane) | ((tw == lane) & (st_.seq < n.val))) & (tw >= best)
+                    Vv = vec(st_.value)
+                    out = np.where(vis, Vv[np.clip(tw, 0, WAVE - 1)], out)
+                    best = np.where(vis, tw, best)
+                if any(np.any(B[:tn] == a) for a in cell_addr.values()):
+                    raise TparAbort(f0, "a delay-line read hits a mem[] cell")
+                val[n.i] = out
+            elif kind == "par" and it[1].kind == "lcin":
+                n = it[1]
+                a = int(uni(reg.loop.cells[n.name], "cell address"))
+                val[n.i] = np.float64(memv[a] if a < mcap else 0.0)
+            elif kind == "par":
+                n = it[1]
+                val[n.i] = _np_op(n.op, [V(a) for a in n.args])
+                if reg.loop is None or not n.uniform:
+                    val[n.i] = np.broadcast_to(val[n.i], (WAVE,)).astype(np.float64)
+                if reg.loop is not None and n is reg.loop.cond and not _truthy(np.float64(uni(n, "while condition"))):
+                    return False
+            elif kind == "loop":
+                run_loop(it[1], f0, tn, sites)
+            elif kind == "shift":
+                name = it[1]
+                src = vec(reg.outs[name])
+                sh = np.empty(WAVE)
+                sh[0] = carry[name]
+                sh[1:] = src[:-1]
+                val[reg.st[name].i] = sh
+            elif kind == "scan":
+                comp: Component = it[1]
+                d = len(comp.names)
+                A = np.stack([np.stack([vec(comp.A[r][c]) for c in range(d)]) for r in range(d)]).copy()
+                b = np.stack([vec(comp.b[r]) for r in range(d)]).copy()          # [d,d,64], [d,64]
+                states = _scan_exclusive(A, b, np.array([carry[nm] for nm in comp.names]))
+                for r, nm in enumerate(comp.names):
+                    val[reg.st[nm].i] = states[r]
+            elif kind == "serial":
+                for comp in it[1]:
+                    sim_serial(reg, comp, carry, tn)
+            elif kind == "spec":
+                for comp in it[1]:
+                    d = len(comp.names)
 
-    for gid, it in enumerate(plan.items):
-        kind = it[0]
-        if kind == "par":
-            avail.add(it[1].i)
-        elif kind == "site":
-            pass
-        elif kind == "shift":
-            avail.add(plan.st[it[1]].i)
-            unit_done.add(it[1])
-        elif kind == "scan":
-            for nm in it[1].names:
-                avail.add(plan.st[nm].i)
-                unit_done.add(nm)
-        else:
-            for c in it[1]:
-                for nm in c.names:
-                    avail.add(plan.st[nm].i)
-                    unit_done.add(nm)
-        if gid:
-            pass
-        if kind == "site":
-            st_: StoreSite = it[1]
-            j, an = st_.j, ref(st_.addr)
-            L.append(f"    // delay-line write {j}: must advance by one cell per frame (at most one wrap inside the chunk)")
-            L.append(f"    const double sp{j} = zt_shift1({an}, {an} - 1.0);")
-            L.append(f"    const uint64_t sm{j} = __ballot(valid && lane > 0 && ({an} - sp{j} != 1.0));")
-            L.append(f"    const int sk{j} = sm{j} ? (int)__ffsll((long long)sm{j}) - 1 : tn;")
-            L.append(f"    const int64_t s0{j} = (int64_t)zt_readlane({an}, 0), s1{j} = sk{j} < tn ? (int64_t)zt_readlane({an}, sk{j}) : 0;")
-            L.append(f"    zt_bad |= __popcll(sm{j}) > 1 || s0{j} + sk{j} > mcap || (sk{j} < tn && s1{j} + (tn - sk{j}) > mcap);")
-            if cell_addrs:
-                L.append(f"    zt_bad |= (s0{j} <= cmax && s0{j} + sk{j} > cmin) || (sk{j} < tn && s1{j} <= cmax && s1{j} + (tn - sk{j}) > cmin);")
-            continue
-        if kind == "par" and it[1].kind == "ld":
-            n = it[1]
-            L.append(f"    double n{n.i};   // delay-line read: memory as it was before this chunk, or the value an earlier frame of the chunk writes")
-            L.append("    {")
-            if n.i in raw_issued:
-                L.append(f"      const int64_t B = B{n.i};")
-                L.append(f"      double v = raw{n.i};")
+                    def conds_from(states):
+                        loc = {reg.st[nm].i: states[r] for r, nm in enumerate(comp.names)}
+                        for m in comp.slice:
+                            loc[m.i] = np.broadcast_to(_np_op(m.op, [loc[a.i] if a.i in loc else V(a) for a in m.args]), (WAVE,))
+                        return [_truthy(np.broadcast_to(loc[c.i] if c.i in loc else V(c), (WAVE,))) for c in comp.conds]
+
+                    prev = [np.full(WAVE, carry[nm]) for nm in comp.names]
+                    gs = conds_from(prev)
+                    converged, iters, still = False, 0, 0
+                    while iters < SPEC_MAX:
+                        iters += 1
+                        loc = {gn.i: np.where(gs[k], 1.0, 0.0) for k, gn in enumerate(comp.gnodes)}
+                        for n in comp.gdep:
+                            loc[n.i] = _np_op(n.op, [loc[a.i] if a.i in loc else V(a) for a in n.args])
+                        gv = lambda n: np.broadcast_to(loc[n.i] if n.i in loc else V(n), (WAVE,)).astype(np.float64)
+                        A = np.stack([np.stack([gv(comp.A[r][c]) for c in range(d)]) for r in range(d)]).copy()
+                        b = np.stack([gv(comp.b[r]) for r in range(d)]).copy()
+                        states = _scan_exclusive(A, b, np.array([carry[nm] for nm in comp.names]))
+                        ng = conds_from(states)
+                        changed = any(bool(np.any(x_[:tn] != y_[:tn])) for x_, y_ in zip(ng, gs))
+                        # a pattern that only still flips where both of its branches agree (a smoother sitting on its target,
+                        # a value on its clamp) leaves the states where they were, also under the pattern they themselves imply
+                        moved = any(bool(np.any(np.abs(a_[:tn] - b_[:tn]) > SPEC_TOL * np.maximum(np.abs(a_[:tn]), np.abs(b_[:tn]))))
+                                    for a_, b_ in zip(states, prev))
+                        still = 0 if moved else still + 1
+                        gs, prev = ng, states
+                        if not changed or still >= 2:
+                            converged = True
+                            break
+                    self.spec_log.append((tuple(comp.names), iters, converged))
+                    if converged:
+                        for r, nm in enumerate(comp.names):
+                            val[reg.st[nm].i] = states[r]
+                    else:
+                        sim_serial(reg, comp, carry, tn)
             else:
-                L.append(f"      const int64_t B = (int64_t){ref(n.args[0])};")
-                L.append("      double v = B < mcap ? memp[B * mse] : 0.0;")
-            L.append("      int best = -1;")
-            for st_ in plan.stores:
-                j = st_.j
-                L.append(f"      {{ int tw = -1; const int64_t d0 = B - s0{j}, d1 = B - s1{j};")
-                L.append(f"        if ((uint64_t)d0 < (uint64_t)sk{j}) tw = (int)d0;")
-                L.append(f"        if ((uint64_t)d1 < (uint64_t)(tn - sk{j})) tw = sk{j} + (int)d1;")
-                if ",".join(map(str, st_.region)) != n.name:
-                    L.append("        zt_badl |= tw >= 0; }")
-                else:
-                    before = "true" if st_.seq < n.val else "false"
-                    L.append(f"        const bool vis = valid && tw >= 0 && (tw < lane || (tw == lane && {before})) && tw >= best;")
-                    L.append(f"        if (__ballot(vis)) {{ const double fw = zt_bperm({ref(st_.value)}, tw); v = vis ? fw : v; best = vis ? tw : best; }} }}")
-            if cell_addrs:
-                L.append("      zt_badl |= B >= cmin && B <= cmax;")
-            L.append(f"      n{n.i} = v;")
-            L.append("    }")
-            retire()
-            continue
-        if kind == "par":
-            n = it[1]
-            L.append(f"    const double n{n.i} = {_expr(n.op, [ref(x) for x in n.args])};")
-            for ld in plan.loads:            # the reads of this address go out now: their latency overlaps everything up to their use
-                if ld.args[0] is n and ld.i not in raw_issued:
-                    raw_issued.add(ld.i)
-                    L.append(f"    const int64_t B{ld.i} = (int64_t)n{n.i};")
-                    L.append(f"    const double raw{ld.i} = B{ld.i} < mcap ? memp[B{ld.i} * mse] : 0.0;")
-        elif kind == "shift":
-            name = it[1]
-            L.append(f"    const double n{plan.st[name].i} = zt_shift1({ref(plan.outs[name])}, {cname[name]});   // {name}[t-1]")
-        elif kind == "scan":
-            c: Component = it[1]
-            if len(c.names) == 1 and c.A[0][0].kind == "const" and c.A[0][0].val == 1.0:
-                nm = c.names[0]
-                s = plan.st[nm].i
-                L.append(f"    const double n{s} = zt_shift1(zt_scan1_sum({ref(c.b[0])}, {cname[nm]}, lane), {cname[nm]});   // {nm}: running sum")
-            elif len(c.names) == 1 and c.A[0][0] in inv_coefs:
-                nm = c.names[0]
-                s = plan.st[nm].i
-                k = inv_coefs.index(c.A[0][0])
-                L.append(f"    const ZtPow sq{s} = {{zt_q[{k} * 4 + zo], zt_q[{k} * 4 + 1 + zo], zt_q[{k} * 4 + 2 + zo], zt_q[{k} * 4 + 3 + zo]}};   // {nm}: constant-coefficient recurrence")
-                L.append(f"    const double n{s} = zt_shift1(zt_scan1_inv({ref(c.b[0])}, {ref(c.A[0][0])}, sq{s}, zt_w[{k} * 64 + lane + zo], {cname[nm]}, lane), {cname[nm]});")
-            elif len(c.names) == 1:
-                nm = c.names[0]
-                s = plan.st[nm].i
-                L.append(f"    double sa{s} = {ref(c.A[0][0])}, sb{s} = {ref(c.b[0])};   // {nm}: affine recurrence")
-                L.append(f"    zt_scan1(sa{s}, sb{s});")
-                L.append(f"    const double n{s} = zt_shift1(__builtin_fma(sa{s}, {cname[nm]}, sb{s}), {cname[nm]});")
-            elif len(c.names) == 2 and tuple(x for row in c.A for x in row) in inv_mats:
-                n0, n1 = c.names
-                s0, s1 = plan.st[n0].i, plan.st[n1].i
-                k = inv_mats.index(tuple(x for row in c.A for x in row))
-                L.append(f"    double sb{s0} = {ref(c.b[0])}, sb{s1} = {ref(c.b[1])};   // {n0}, {n1}: coupled pair, launch-constant matrix")
-                L.append(f"    {{ const ZtMat2 am = {{{ref(c.A[0][0])}, {ref(c.A[0][1])}, {ref(c.A[1][0])}, {ref(c.A[1][1])}}};")
-                L.append(f"      zt_scan2_inv(sb{s0}, sb{s1}, am, zt_m + {k} * ZT_MAT_TABLE_DOUBLES, zo, {cname[n0]}, {cname[n1]}, lane); }}")
-                L.append(f"    const double n{s0} = zt_shift1(sb{s0}, {cname[n0]});")
-                L.append(f"    const double n{s1} = zt_shift1(sb{s1}, {cname[n1]});")
+                raise AssertionError(kind)
+        return True
+
+    class _CellCarry:
+        """A per-trip cell's value before the chunk: read when its recurrence runs (its address is a node of the trip)."""
+
+        def __init__(self, Lp):
+            self.Lp = Lp
+
+        def __getitem__(self, key):
+            return np.float64(memv[int(uni(self.Lp.cells[key], "cell address"))])
+
+    def run_loop(reg: Region, f0, tn, sites):
+        Lp = reg.loop
+        for v in Lp.order:
+            val[Lp.phis[v].i] = V(Lp.init[v]) if Lp.phis[v].su else vec(Lp.init[v])
+        cnt = None
+        if Lp.count is not None:
+            c = uni(Lp.count, "loop count")
+            cnt = 0 if not c > 0 else int(min(c, 134217728.0))
+        k = 0
+        while cnt is None or k < cnt:
+            if Lp.cond is not None and not _in_subtree(Lp.cond, Lp) and not _truthy(np.float64(uni(Lp.cond, "while condition"))):
+                break
+            if Lp.cond is not None and k >= (1 << 26):
+                raise AssertionError("loop cap")
+            if not run_items(reg, _CellCarry(Lp), f0, tn, sites):
+                break
+            for key, o in Lp.cell_out.items():
+                a = int(uni(Lp.cells[key], "cell address"))
+                memv[a] = vec(o)[tn - 1]
+                fl = Lp.cell_flag.get(key)
+                if fl is None or np.any(_truthy(vec(fl))[:tn]):
+                    mem_high[0] = max(mem_high[0], a + 1)
+            nxt = {v: V(Lp.next[v]) for v in Lp.order}
+            for v in Lp.order:
+                val[Lp.phis[v].i] = nxt[v]
+            k += 1
+        for v, lo in Lp.louts.items():
+            val[lo.i] = vec(Lp.phis[v])
+
+    def address_pass(Lp: LoopInfo):
+        """The kernel's check before a block: every per-trip cell address steps evenly and no two ever meet."""
+        reg = self.regions[Lp.id]
+        need = sorted({n.i: n for n in reg.nodes if n.uniform and n.kind == "op"}.values(), key=lambda n: n.i)
+        for v in Lp.order:
+            if Lp.phis[v].su:
+                val[Lp.phis[v].i] = V(Lp.init[v])
+        seqs: Dict[str, List[int]] = {key: [] for key in Lp.cells}
+        cnt = None
+        if Lp.count is not None:
+            c = uni(Lp.count, "loop count")
+            cnt = 0 if not c > 0 else int(min(c, 134217728.0))
+        k = 0
+        while cnt is None or k < cnt:
+            stop = False
+            for n in need:
+                try:
+                    val[n.i] = _np_op(n.op, [V(a) for a in n.args])
+                except KeyError:
+                    continue                  # (depends on a cell's value: not an address)
+                if n is Lp.cond and not _truthy(np.float64(val[n.i])):
+                    stop = True
+                    break
+            if stop or (Lp.cond is not None and not _in_subtree(Lp.cond, Lp) and not _truthy(np.float64(uni(Lp.cond, "cond")))):
+                break
+            for key, a in Lp.cells.items():
+                seqs[key].append(int(uni(a, "cell address")))
+            nxt = {v: V(Lp.next[v]) for v in Lp.order if Lp.phis[v].su}
+            for v, x_ in nxt.items():
+                val[Lp.phis[v].i] = x_
+            k += 1
+        desc = {}
+        for key, s in seqs.items():
+            if not s:
+                desc[key] = (0, 1, 0, -1)
+                continue
+            st = s[1] - s[0] if len(s) > 1 else 1
+            if any(b_ - a_ != st for a_, b_ in zip(s, s[1:])) or max(s) >= mcap:
+                raise TparAbort(0, "a per-trip cell address does not step evenly through the trips (or leaves the arena)")
+            desc[key] = (s[0], st, min(s), max(s))
+        keys = list(desc)
+        for i1 in range(len(keys)):
+            for i2 in range(i1 + 1, len(keys)):
+                if (keys[i1] in Lp.cell_out or keys[i2] in Lp.cell_out) and not _sites_ok(*desc[keys[i1]], *desc[keys[i2]]):
+                    raise TparAbort(0, "two per-trip cell addresses may name one cell")
+            if any(desc[keys[i1]][2] <= a <= desc[keys[i1]][3] for a in cell_addr.values()):
+                raise TparAbort(0, "a per-trip cell runs over a mem[] cell")
+
+    with np.errstate(all="ignore"):
+        for n in self.uniform:
+            if n.kind in ("const", "hold"):
+                continue
+            if n.kind == "inv":
+                val[n.i] = np.float64(inv_value(n.name))
             else:
-                n0, n1 = c.names
-                s0, s1 = plan.st[n0].i, plan.st[n1].i
-                L.append(f"    ZtMap2 sm{s0} = {{{ref(c.A[0][0])}, {ref(c.A[0][1])}, {ref(c.A[1][0])}, {ref(c.A[1][1])}, {ref(c.b[0])}, {ref(c.b[1])}}};   // {n0}, {n1}: coupled affine pair")
-                L.append(f"    zt_scan2(sm{s0});")
-                L.append(f"    const double n{s0} = zt_shift1(__builtin_fma(sm{s0}.a00, {cname[n0]}, __builtin_fma(sm{s0}.a01, {cname[n1]}, sm{s0}.b0)), {cname[n0]});")
-                L.append(f"    const double n{s1} = zt_shift1(__builtin_fma(sm{s0}.a10, {cname[n0]}, __builtin_fma(sm{s0}.a11, {cname[n1]}, sm{s0}.b1)), {cname[n1]});")
-        elif kind == "serial":
-            names = [nm for c in it[1] for nm in c.names]
-            L.append(f"    // serial recurrences sharing one loop: {', '.join(names)}")
-            serial_loop(it[1], "    ")
-            for nm in names:
-                s = plan.st[nm].i
-                L.append(f"    const double n{s} = k{s};")
-        elif kind == "spec":
-            comps: List[Component] = it[1]
-            names = [nm for c in comps for nm in c.names]
-            L.append(f"    // switched recurrences (affine once their state-dependent conditions are fixed), solved by iterating the")
-            L.append(f"    // condition pattern to its fixed point: {', '.join(names)}")
-            for nm in names:
-                L.append(f"    double s{plan.st[nm].i} = {cname[nm]}, p{plan.st[nm].i} = {cname[nm]};")
-            gname = {}
-            for c in comps:
-                for k, gn in enumerate(c.gnodes):
-                    gname[gn.i] = f"g{gn.name}_{k}"
-                    L.append(f"    bool {gname[gn.i]};")
-
-            def xref(x: N, loc: Dict[int, str]) -> str:
-                if x.i in loc:
-                    return loc[x.i]
-                if x.kind == "guess":
-                    return f"({gname[x.i]} ? 1.0 : 0.0)"
-                return ref(x)
-
-            def slice_eval(c: Component, ind: str, out_prefix: str):
-                loc = {plan.st[nm].i: f"s{plan.st[nm].i}" for nm in c.names}
-                for m in c.slice:
-                    loc[m.i] = f"v{m.i}"
-                    L.append(f"{ind}const double v{m.i} = {_expr(m.op, [xref(x, loc) for x in m.args])};")
-                for k, (cn, gn) in enumerate(zip(c.conds, c.gnodes)):
-                    L.append(f"{ind}{out_prefix}{gname[gn.i]} = za_truthy({xref(cn, loc)});")
-
-            L.append("    {   // first pattern: the states taken to stay at their carried values")
-            for c in comps:
-                slice_eval(c, "      ", "")
-            L.append("    }")
-            L.append(f"    bool sch{gid}; int sit{gid} = 0;")
-            L.append("    do {")
-            for c in comps:
-                loc: Dict[int, str] = {}
-                for n in c.gdep:
-                    loc[n.i] = f"d{n.i}"
-                    L.append(f"      const double d{n.i} = {_expr(n.op, [xref(x, loc) for x in n.args])};")
-                if len(c.names) == 1:
-                    nm = c.names[0]
-                    s = plan.st[nm].i
-                    L.append(f"      double sa{s} = {xref(c.A[0][0], loc)}, sb{s} = {xref(c.b[0], loc)};")
-                    L.append(f"      zt_scan1(sa{s}, sb{s});")
-                    L.append(f"      s{s} = zt_shift1(__builtin_fma(sa{s}, {cname[nm]}, sb{s}), {cname[nm]});")
-                else:
-                    n0, n1 = c.names
-                    s0, s1 = plan.st[n0].i, plan.st[n1].i
-                    L.append(f"      ZtMap2 sm{s0} = {{{xref(c.A[0][0], loc)}, {xref(c.A[0][1], loc)}, {xref(c.A[1][0], loc)}, {xref(c.A[1][1], loc)}, {xref(c.b[0], loc)}, {xref(c.b[1], loc)}}};")
-                    L.append(f"      zt_scan2(sm{s0});")
-                    L.append(f"      s{s0} = zt_shift1(__builtin_fma(sm{s0}.a00, {cname[n0]}, __builtin_fma(sm{s0}.a01, {cname[n1]}, sm{s0}.b0)), {cname[n0]});")
-                    L.append(f"      s{s1} = zt_shift1(__builtin_fma(sm{s0}.a10, {cname[n0]}, __builtin_fma(sm{s0}.a11, {cname[n1]}, sm{s0}.b1)), {cname[n1]});")
-            L.append("      // the pattern these states imply")
-            for c in comps:
-                slice_eval(c, "      ", "const bool h")
-            diffs = " || ".join(f"(h{gname[gn.i]} != {gname[gn.i]})" for c in comps for gn in c.gnodes)
-            moved = " || ".join(f"(fabs(s{plan.st[nm].i} - p{plan.st[nm].i}) > ZT_SPEC_TOL * fmax(fabs(s{plan.st[nm].i}), fabs(p{plan.st[nm].i})))" for nm in names)
-            L.append("      // settled = the pattern reproduced itself, or it only still moves where its branches agree (states unchanged)")
-            L.append(f"      sch{gid} = (__ballot(valid && ({diffs})) != 0ull) && (__ballot(valid && ({moved})) != 0ull);")
-            for c in comps:
-                for gn in c.gnodes:
-                    L.append(f"      {gname[gn.i]} = h{gname[gn.i]};")
-            for nm in names:
-                L.append(f"      p{plan.st[nm].i} = s{plan.st[nm].i};")
-            L.append(f"    }} while (sch{gid} && ++sit{gid} < ZT_SPEC_MAX);")
-            L.append(f"    if (sch{gid}) {{   // no fixed point within the budget (a pattern that keeps moving along the chunk): the serial loop")
-            serial_loop(comps, "      ")
-            for nm in names:
-                s = plan.st[nm].i
-                L.append(f"      s{s} = k{s};")
-            L.append("    }")
-            for nm in names:
-                s = plan.st[nm].i
-                L.append(f"    const double n{s} = s{s};")
+                val[n.i] = _np_op(n.op, [V(a) for a in n.args])
+        for gn in self.guards:
+            if _truthy(np.float64(V(gn))):
+                raise TparAbort(0, "a rare-event branch the lowering left out is due")
+        cell_addr = {name: int(V(a)) for name, a in self.cells.items()}
+        if len(set(cell_addr.values())) != len(cell_addr) or any(a >= len(memv) for a in cell_addr.values()):
+            raise TparAbort(0, "mem[] cells alias each other or lie past the arena")
+        for Lp in self.loops:
+            if Lp.cells:
+                address_pass(Lp)
+        carry = {name: np.float64(inv_value(name)) for name in self.st}
+        hcarry = {name: np.float64(inv_value(name)) for name in self.holdvars}
+        y = np.zeros_like(x)
+        final_vals: Dict[str, float] = {}
+        for f0 in range(0, max(frames, 0), WAVE):
+            tn = min(WAVE, frames - f0)
+            last = tn - 1
+            for n in self.inputs:
+                col = np.zeros(WAVE)
+                col[:tn] = x[int(n.val), f0:f0 + tn].astype(np.float64)
+                val[n.i] = col
+            sites: Dict[int, dict] = {}
+            try:
+                run_items(top, carry, f0, tn, sites)
+            except TparAbort:
+                for st_ in reversed(self.stores):          # what this chunk's early writes replaced
+                    if st_.mode == "early" and st_.j in sites and "old" in sites[st_.j]:
+                        memv[sites[st_.j]["A"][:tn]] = sites[st_.j]["old"]
+                raise
+            for st_ in self.stores:                    # the chunk's writes land after all of its reads are resolved
+                si = sites[st_.j]
+                if st_.mode == "sparse":
+                    Vv = vec(st_.value)
+                    for t in np.flatnonzero(si["on"]):
+                        memv[si["A"][t]] = Vv[t]
+                        mem_high[0] = max(mem_high[0], int(si["A"][t]) + 1)
+                    continue
+                if not si["live"]:
+                    continue
+                if st_.mode == "late":
+                    memv[si["A"][:tn]] = vec(st_.value)[:tn]
+                mem_high[0] = max(mem_high[0], int(si["A"][:tn].max()) + 1)
+            for ch in range(self.nch):
+                y[ch, f0:f0 + tn] = vec(self.spl_out[ch])[:tn].astype(np.float32)
+            for name in self.st:
+                carry[name] = np.float64(vec(self.outs[name])[last])
+            for name in self.holdvars:
+                v = vec(self.outs[name])
+                on = ~_is_hold(v)
+                on[tn:] = False
+                if on.any():
+                    hcarry[name] = np.float64(v[np.flatnonzero(on)[-1]])
+            if stream is not None:
+                stream.end_chunk(int(carry[RNG_INDEX]))
+            if f0 + WAVE >= frames:
+                for name, o in list(self.outs.items()) + [(f"spl{ch}", self.spl_out[ch]) for ch in range(self.nch)]:
+                    final_vals[name] = float(hcarry[name]) if name in hcarry else float(vec(o)[last])
+    vars_after = dict(vars0)
+    spl_after = dict(spl_state)
+    self.mt_after = stream.state(int(final_vals.get(RNG_INDEX, 0))) if stream is not None else mt
+    final_vals.pop(RNG_INDEX, None)
+    for name, v in final_vals.items():
+        k = is_spl_name(name)
+        if name.startswith("memw@"):
+            continue
+        if name in self.cells:
+            if final_vals.get("memw@" + name[4:], 0.0) != 0.0:       # stored to at least once in this launch
+                memv[cell_addr[name]] = v
+                mem_high[0] = max(mem_high[0], cell_addr[name] + 1)
+        elif k is not None:
+            spl_after[k] = v
         else:
-            raise AssertionError(kind)
-        retire()
-    if has_streams:
-        L.append("    if (zt_bad || __ballot(valid && zt_badl)) {")
-        L.append("      // a condition of the delay-line handling does not hold in this chunk: put the states back as they were before it")
-        L.append("      // and leave the rest of the launch to the generic kernel (za_launch_fast runs it right behind this one)")
-        L.append("      if (lane == 0) {")
-        for k, name in enumerate(cname):
-            if name.startswith("memw@") or name == RNG_INDEX:
-                continue
-            if name in plan.cells:
-                flag = "memw@" + name[4:]
-                if flag in cname:
-                    fk = list(cname).index(flag)
-                    L.append(f"        if (zt_snap[{fk}] != 0.0) {{ {dst(name)} = zt_snap[{k}]; zt_high = zt_high > ca{plan.cells[name].i} + 1 ? zt_high : ca{plan.cells[name].i} + 1; }}")
-                continue
-            L.append(f"        {dst(name)} = zt_snap[{k}];")
-        L.append("        b.mem_high[inst] = zt_high;")
-        L.append("        b.resume[inst] = f0;")
-        L.append("      }")
-        L.append("      return;")
-        L.append("    }")
-        L.append("    // the chunk's writes land after all of its reads are resolved")
-        for st_ in plan.stores:
-            L.append(f"    if (valid) memp[(int64_t){ref(st_.addr)} * mse] = {ref(st_.value)};")
-            L.append(f"    {{ const int64_t h0 = s0{st_.j} + sk{st_.j}, h1 = sk{st_.j} < tn ? s1{st_.j} + (tn - sk{st_.j}) : 0; zt_high = h0 > zt_high ? h0 : zt_high; zt_high = h1 > zt_high ? h1 : zt_high; }}")
-    retire(final=True)
-    if has_mem:
-        L.append("    if (fin && lane == last) { b.mem_high[inst] = zt_high > zt_hc ? zt_high : zt_hc; b.resume[inst] = frames; }")
-    if pin:
-        L.append(f"    asm volatile(\"\" : {pin});   // the next chunk's audio has landed; its wait comes before this chunk's stores")
-    L.append("    if (valid) {")
-    for ch in range(plan.nch):
-        L.append(f"      out_[{ch} * a.frame_stride + f0 + lane] = (float){ref(plan.spl_out[ch])};")
-    L.append("    }")
-    if plan.uses_rand:
-        L.append(f"    zt_mt_retire(zt_mt, zt_pos0, (int){cname[RNG_INDEX]}, lane);")
-    L.append("  }")
-    if plan.uses_rand:
-        L.append(f"  zt_mt_end(zt_mt, zt_pos0, (int){cname[RNG_INDEX]}, zt_gmt, b.mt_se, b.mti + inst, lane);")
-    L.append("}")
-    if has_mem:
-        # the generic code of the leaf, one lane per instance, from wherever the kernel above stopped (normally: nowhere)
-        L.append("// instances the time-parallel kernel handed back (b.resume[i] < frames) finish the launch here, frame by frame, with the")
-        L.append("// generic section code -- the exact serial semantics; every other lane leaves at once")
-        L.append(f'extern "C" __global__ void __launch_bounds__(64) {kernel_macro[:-1]}_tail)(ZabBatch b, ZabAudio a) {{')
-        L.append("  ZA_KERNEL_ENTRY();")
-        L.append("  const int inst = blockIdx.x * 64 + threadIdx.x;")
-        L.append("  if (inst >= b.n_inst) return;")
-        L.append("  const int64_t from = b.resume[inst];")
-        L.append("  if (from >= a.frames) return;")
-        L.append("  ZaS s;")
-        L.append("  za_state_load(s, b, inst);")
-        L.append(f"  const float* in = a.in + (int64_t)inst * {plan.nch} * a.frame_stride;")
-        L.append(f"  float* out = a.out + (int64_t)inst * {plan.nch} * a.frame_stride;")
-        L.append("  for (int64_t t = from; t < a.frames; ++t) {")
-        for ch in range(plan.nch):
-            L.append(f"    s.spl[{ch}] = (double)in[{ch} * a.frame_stride + t];")
-        L.append("    za_section_sample(s);")
-        for ch in range(plan.nch):
-            L.append(f"    out[{ch} * a.frame_stride + t] = (float)s.spl[{ch}];")
-        L.append("  }")
-        L.append("  za_state_store(s, b, inst);")
-        L.append("  b.resume[inst] = a.frames;")
-        L.append("}")
-    L.append("static int32_t za_fast_applies(const ZabBatch* b, const ZabAudio* a) { (void)b; return a->frames > 0 ? 1 : 0; }")
-    L.append("static hipError_t za_launch_fast(const ZabBatch* b, const ZabAudio* a, hipStream_t st) {")
-    L.append(f"  hipLaunchKernelGGL({kernel_macro}, dim3(b->n_inst), dim3(64), 0, st, *b, *a);")
-    if has_mem:
-        L.append(f"  hipLaunchKernelGGL({kernel_macro[:-1]}_tail), dim3((b->n_inst + 63) / 64), dim3(64), 0, st, *b, *a);")
-    L.append("  return hipGetLastError();")
-    L.append("}")
-    return "\n".join(L) + "\n"
+            vars_after[name] = v
+    self.mem_after, self.mem_high_after = memv, mem_high[0]
+    return y, vars_after, spl_after
+
+
+Plan.simulate = _simulate
