@@ -945,6 +945,7 @@ def build_plan(prog: Program, nch: int) -> Plan:
         return r
 
     loop_by_id = {L.id: L for L in g.loops}
+    g.loop_of = loop_by_id
     plan.holdvars = [name for name in written if may_hold(plan.outs[name])]
     for name in plan.holdvars:
         if name in plan.st or name.startswith("mem") or name == RNG_INDEX:
@@ -1511,10 +1512,11 @@ def _persistent_rounding(g: FrameGraph, reg: Region, c: Component, mem) -> bool:
     decays), and scripts put thresholds exactly where such sums are meant to land -- `pos += 1 / N; pos < 1 ? ...` reaches
     1 after N steps only up to rounding, so the frame at which the test flips depends on the ORDER of the additions. A scan
     re-associates them. Such components therefore keep their serial loop (exact order); integer-valued steps (counters,
-    hold timers) are exact in any order and stay scans, |a| < 1 forgets its rounding, and a step that is itself a signal
-    (`energy += x * x`) has no value it is meant to land on: thresholds on those are generic.
+    hold timers) are exact in any order and stay scans, |a| < 1 forgets its rounding, and a step computed from this frame's
+    input (`energy += x * x`) has no value it is meant to land on: thresholds on those are generic.
     Decided on the branch-wise affine forms of the new state: (coefficient on itself, constant term) per path through ?: /
-    min / max; any path with coefficient 1 and a block-constant term that is not an integer literal marks the component."""
+    min / max; any path with coefficient 1 and a term that is not an integer literal and is built from invariants and states
+    only (a rate that changes now and then is still a rate) marks the component."""
     nm = c.names[0]
     limit = 256
 
@@ -1563,6 +1565,25 @@ def _persistent_rounding(g: FrameGraph, reg: Region, c: Component, mem) -> bool:
             return [(g.op("/", ka, vb), g.op("/", va, vb)) for ka, va in a for _, vb in b]
         return None
 
+    sig_memo: Dict[int, bool] = {}
+
+    def from_input(n: N) -> bool:
+        """Built from this frame's audio (an input sample or a delay-line read), not only from invariants and states."""
+        if n.i in sig_memo:
+            return sig_memo[n.i]
+        sig_memo[n.i] = False
+        if n.kind in ("in", "ld"):
+            r = True
+        elif n.kind in ("phi", "lout"):
+            L = g.loop_of[n.val]
+            r = from_input(L.init[n.name]) or from_input(L.next[n.name])
+        elif n.kind == "op" and n.op == "sel":       # (which value is taken may follow the input; the values are what is summed)
+            r = from_input(n.args[1]) or from_input(n.args[2])
+        else:
+            r = any(from_input(a) for a in n.args)
+        sig_memo[n.i] = r
+        return r
+
     fs = forms(reg.outs[nm])
     if fs is None:
         return False                              # not affine even branch-wise: the classification below decides
@@ -1571,7 +1592,7 @@ def _persistent_rounding(g: FrameGraph, reg: Region, c: Component, mem) -> bool:
             cv = _const_value(v)
             if cv is not None and cv == math.floor(cv):
                 continue
-            if v.su or os.environ.get("ZA_TPAR_STRICT_SUMS"):
+            if not from_input(v) or os.environ.get("ZA_TPAR_STRICT_SUMS"):
                 return True
     return False
 
