@@ -15,7 +15,8 @@ def _run(leaf, n, x, block, poke):
     meta = zabatch.leaf_meta(leaf)
     rows = np.tile(np.array(meta["default_sliders"], dtype=np.float64), (n, 1))
     rows[:, 0] += np.linspace(0.0, 1.0, n) * 0.5            # instances differ a little
-    with zabatch.Engine(leaf, n, mem_cap=1 << 14, max_block=block) as e:
+    # (the window belongs to the lane-per-instance kernel; leaves with a time-parallel kernel would take that one by default)
+    with zabatch.Engine(leaf, n, mem_cap=1 << 14, max_block=block, path=zabatch.ZAB_PATH_GENERIC) as e:
         e.set_sliders(rows); e.prepare()
         third = x.shape[-1] // 3
         ys = [e.process_host(np.ascontiguousarray(x[..., :third]), block=block)]

@@ -96,6 +96,15 @@ __device__ __forceinline__ bool zt_sites_ok(int64_t a0, int64_t s0, int64_t lo0,
   return (a1 - a0) % s0 != 0;
 }
 
+// an integer small enough that sums and products of a few of them stay exact in a double (loop counters run in strips: i0 + k * step)
+__device__ __forceinline__ bool zt_small_int(double x) { return x == floor(x) && fabs(x) < 1.0e12; }
+
+// LDS doubles for the staged windows of the rings a uniform loop gathers from (zajit/tpar.py RingGroup): 24 KB keeps four
+// wavefronts per CU beside the other tables; a window that does not fit leaves its loop on the gathers from memory
+#ifndef ZT_RING_DOUBLES
+#define ZT_RING_DOUBLES 3072
+#endif
+
 // value of the previous lane; lane 0 receives `first` (the value carried in from the previous chunk)
 __device__ __forceinline__ double zt_shift1(double v, double first) { return zt_dpp<ZT_WAVE_SHR1, 0xF>(v, first); }
 

@@ -288,7 +288,7 @@ class FrameGraph:
         # variables assigned anywhere in @sample (or a function it can reach): everything else is constant over a block, which
         # lets the walk tell block-constant addresses (mem[] cells used as named state) from moving ones (delay lines)
         self.wsyn = _assigned_names(prog, self.stmts)
-        self.exposed = exposed_vars(prog, self.stmts)
+        self.exposed = set(prog.vars) if os.environ.get("ZA_TPAR_NO_HOLD") else exposed_vars(prog, self.stmts)
         self.pred: Optional[N] = None            # path condition of the statement being walked (None: unconditional)
         self.mem_seq = 0                         # program order of the memory operations of a frame
         self.cells: Dict[str, N] = {}            # "mem@<id>" -> its (block-constant) address node
@@ -761,6 +761,20 @@ class StoreSite:
         self.mode = "late"
 
 
+class RingGroup:
+    """Gathers of one uniform loop that read ONE ring relative to a per-lane position: address = S + ((P +- U) & mask) with S and
+    mask block-constant, P the same for every trip (one ring position per frame, consecutive frames one cell apart) and U
+    wave-uniform per trip (a tap's lag). All the cells such a loop reads lie in the window [P(frame 0) + min offset, P(frame 63)
+    + max offset] of the ring, which the kernel stages in LDS once per chunk: a tap then is one conflict-free LDS read instead of
+    a 512-byte gather that misses L2 (TSEQ: 3466 taps per frame; DOT; the DDT-class fixture)."""
+
+    def __init__(self, idx, loop, S, P, mask):
+        self.idx, self.loop, self.S, self.P, self.mask = idx, loop, S, P, mask
+        self.loads: List[tuple] = []             # (ld node, U node, sign)
+        self.site: Optional[StoreSite] = None    # this chunk's (early) write into the same ring, if any
+        self.region = ""
+
+
 class Component:
     """One recurrence: the state variables whose state-in nodes lie on a common cycle."""
 
@@ -815,6 +829,7 @@ class Plan:
         self.top: Region = None
         self.regions: Dict[int, Region] = {}     # loop id -> region
         self.guards: List[N] = []                # rare-event conditions taken to be false (split_guards)
+        self.rings: Dict[int, List[RingGroup]] = {}   # loop id -> its ring windows
         self.holdvars: List[str] = []            # written variables that may carry the HOLD marker at the end of a frame
         self.has_block = False                   # the kernel runs @block (and the pending-mask @slider) between the blocks
         self.has_pending = False                 # the script can raise slider masks: pending ones run @slider before a launch
@@ -1187,6 +1202,29 @@ def build_plan(prog: Program, nch: int) -> Plan:
     for r in regions.values():
         loop_ext(r)                           # (coefficient nodes may read further outside values)
 
+    # ---- gathers that read a ring relative to the frame's position: staged through LDS (RingGroup) -------------------------------
+    plan.rings = {}
+    if not os.environ.get("ZA_TPAR_NO_RING"):
+        for L in loops:
+            groups: List[RingGroup] = []
+            for ld in plan.loads:
+                if ld.loop is not L or ld.i not in live:
+                    continue
+                f = _ring_form(ld, L)
+                sites = [s_ for s_ in plan.stores if ",".join(map(str, s_.region)) == ld.name]
+                if f is None or any(s_.mode != "early" or s_.pred is not None for s_ in sites):
+                    continue
+                S, P, U, sign, mask = f
+                key = (tuple(x.i for x in S), P.i, mask.i)
+                grp = next((q for q in groups if q.key == key), None)
+                if grp is None:
+                    grp = RingGroup(len(groups), L, S, P, mask)
+                    grp.key, grp.region, grp.site = key, ld.name, (sites[0] if sites else None)
+                    groups.append(grp)
+                grp.loads.append((ld, U, sign))
+            if groups and len(groups) <= 4:
+                plan.rings[L.id] = groups
+
     # ---- schedules -------------------------------------------------------------------------------------------------------------------
     plan.uniform = [n for n in top.nodes if n.uniform]
     plan.invariants = [n for n in plan.uniform if n.kind == "inv"]
@@ -1218,6 +1256,40 @@ def build_plan(prog: Program, nch: int) -> Plan:
         "block": int(plan.has_block), "pending": int(plan.has_pending),
     }
     return plan
+
+
+def _sum_terms(n: N) -> List[N]:
+    out, todo = [], [n]
+    while todo:
+        x = todo.pop()
+        if x.kind == "op" and x.op == "+":
+            todo.extend(reversed(x.args))
+        else:
+            out.append(x)
+    return out
+
+
+def _ring_form(ld: N, L: LoopInfo):
+    """(S terms, P, U, sign, mask) when the load's address is za_addr(S.., ((P +- U) & mask)) as RingGroup describes it."""
+    a = ld.args[0]
+    if a.kind != "op" or a.op != "addr":
+        return None
+    terms = _sum_terms(a.args[0]) + _sum_terms(a.args[1])
+    S = [t for t in terms if t.uniform and t.loop is None]
+    rest = [t for t in terms if not (t.uniform and t.loop is None)]
+    if len(rest) != 1 or rest[0].kind != "op" or rest[0].op != "&":
+        return None
+    d, mask = rest[0].args
+    if not (mask.uniform and mask.loop is None) or d.kind != "op" or d.op not in ("+", "-"):
+        return None
+    x, y = d.args
+    if d.op == "+" and x.loop is L and y.loop is not L:
+        x, y = y, x
+    if x.loop is L or y.loop is not L or not y.uniform or x.kind == "const":
+        return None
+    if _in_subtree(x, L):
+        return None
+    return S, x, y, (1 if d.op == "+" else -1), mask
 
 
 def _schedule(plan: Plan, r: Region, comp_of: Dict[int, Component]):
@@ -1662,13 +1734,17 @@ class _Emit:
         self.ulds = mode == "1" or (mode == "auto" and self.n_uni > ULDS_THRESHOLD)
         self.uslot = {n.i: k for k, n in enumerate(x for x in p.uniform if x.kind not in ("const", "hold"))}
         self.in_loop = False
+        self.bctx = None
+        self.sctx = None
         self.cname = {name: f"c{k}" for k, name in enumerate(p.st)}
         self.hname = {name: f"h{k}" for k, name in enumerate(p.holdvars)}
         self.cell_addrs: List[N] = []
         for a in p.cells.values():
             if a not in self.cell_addrs:
                 self.cell_addrs.append(a)
-        self.lcell_loops = [L for L in p.loops if L.cells]
+        self.lcell_loops = [L for L in p.loops if L.cells or L.id in p.rings]
+        self.ring_lds: Dict[int, str] = {}        # ld node id -> its LDS address, while a loop's staged form is being emitted
+        self.ring_u: Dict[int, N] = {}
         self.has_mem = bool(p.cells or p.stores or p.loads or self.lcell_loops)
         self.has_streams = bool(p.stores)
         self.has_serial = p.has_block or p.has_pending
@@ -1688,6 +1764,20 @@ class _Emit:
             return c_double(n.val)
         if n.kind == "hold":
             return "ZT_HOLD"
+        if self.sctx is not None and n.loop is self.sctx[0] and n.kind != "lout":      # a strip of 64 trips (emit_strip)
+            Lp, mode = self.sctx
+            if n.uniform:
+                if mode == "vec":                     # lane j = trip k0 + j
+                    return f"t{n.i}"
+                return f"e{n.i}"                      # per trip: the strip's value for this trip (v_readlane)
+            if n.kind == "phi":
+                return self.phi_name[n.i]
+            return f"k{n.i}" if mode == "cold" else f"n{n.i}"
+        if self.bctx is not None and n.loop is self.bctx[0] and n.kind != "lout":      # a batch of trips (emit_batched): sub-trip names
+            Lp, u = self.bctx
+            if n.kind == "phi":
+                return self.phi_name[n.i] if u == 0 else self.bref(Lp.next[n.name], u - 1)
+            return f"n{n.i}_{u}"
         if n.kind in ("phi", "lout"):
             return self.phi_name[n.i]
         if n.uniform and n.loop is None:
@@ -1695,6 +1785,14 @@ class _Emit:
                 return f"zt_u[{self.uslot[n.i]} + zo]"
             return f"u{n.i}"
         return f"n{n.i}"
+
+    def bref(self, n: N, u: int) -> str:
+        """Name of node n in sub-trip u of the batch being emitted."""
+        save, self.bctx = self.bctx, (self.bctx[0], u)
+        try:
+            return self.ref(n)
+        finally:
+            self.bctx = save
 
     def inv_src(self, name: str) -> str:
         p, prog = self.plan, self.prog
@@ -1777,6 +1875,8 @@ class _Emit:
         if self.inv_coefs:
             L.append(f"  __shared__ double zt_w[{len(self.inv_coefs)} * 64];      // a^((lane & 15) + 1) per block-constant coefficient")
             L.append(f"  __shared__ double zt_q[{len(self.inv_coefs)} * 4];       // a^2, a^4, a^8, a^16")
+        if p.rings:
+            L.append("  __shared__ double zt_ring[ZT_RING_DOUBLES];     // a chunk's window of the ring a loop gathers from (RingGroup)")
         if self.has_abort:
             L.append(f"  __shared__ double zt_snap[{max(1, len(self.cname))}];")
         if self.has_mem:
@@ -1912,6 +2012,11 @@ class _Emit:
                 L.append(f"    if ({clash}) {{   // cells that alias each other (or lie past the arena): not a case for this kernel")
                 self.emit_leave("      ", "pos")
                 L.append("    }")
+        for lid, groups in p.rings.items():
+            L.append(f"    bool zrok{lid} = true;     // ring reads of loop {lid}: offsets of every trip (integers), per read")
+            for grp in groups:
+                for ld, _, _ in grp.loads:
+                    L.append(f"    int zro_lo{ld.i} = 2147483647, zro_hi{ld.i} = -2147483647;")
         for Lp in self.lcell_loops:
             self.emit_address_pass(Lp)
         if self.inv_mats:
@@ -1940,8 +2045,9 @@ class _Emit:
         p, L, ref = self.plan, self.L, self.ref
         reg = p.regions[Lp.id]
         keys = [k for k in Lp.cells if (k in Lp.cin and Lp.cin[k].i in self.live_ids()) or k in Lp.cell_out]
+        rloads = [x for grp in p.rings.get(Lp.id, []) for x in grp.loads]
         need: Dict[int, N] = {}
-        todo = [Lp.cells[k] for k in keys] + ([Lp.cond] if Lp.cond is not None else [])
+        todo = [Lp.cells[k] for k in keys] + ([Lp.cond] if Lp.cond is not None else []) + [u for _, u, _ in rloads]
         uphis = []
         while todo:
             n = todo.pop()
@@ -1952,8 +2058,10 @@ class _Emit:
                 if n.name not in uphis:
                     uphis.append(n.name)
                 todo.append(Lp.next[n.name])
+            if n.kind == "lcin":
+                todo.append(Lp.cells[n.name])
             todo.extend(n.args)
-        L.append(f"    {{   // per-trip cells of loop {Lp.id}: addresses step evenly through the trips and never meet")
+        L.append(f"    {{   // per-trip cells of loop {Lp.id}: addresses step evenly through the trips and never meet; offsets of its ring reads")
         L.append("      bool zt_abad = false;")
         for v in uphis:
             L.append(f"      double {self.phi_name[Lp.phis[v].i]} = {ref(Lp.init[v])};")
@@ -1968,14 +2076,21 @@ class _Emit:
             n = need[i]
             if n.kind == "phi":
                 continue
+            if n.kind == "lcin":
+                an = ref(Lp.cells[n.name])
+                L.append(f"        const double n{n.i} = ZT_UNI((int64_t){an} < mcap ? memp[(int64_t){an} * mse] : 0.0);")
+                continue
             L.append(f"        const double n{n.i} = ZT_UNI({_expr(n.op, [ref(x) for x in n.args])});")
             if n is Lp.cond:
                 L.append(f"        if (!za_truthy(n{n.i})) break;")
         if Lp.cond is not None and Lp.cond.i not in need:
             L.append(f"        if (!za_truthy({ref(Lp.cond)})) break;")
+        for ld, u, sign in rloads:
+            L.append(f"        {{ const double o = {'' if sign > 0 else '-'}{ref(u)}; const int oi = (int)o; zrok{Lp.id} &= (double)oi == o && fabs(o) < 1.0e9;")
+            L.append(f"          zro_lo{ld.i} = oi < zro_lo{ld.i} ? oi : zro_lo{ld.i}; zro_hi{ld.i} = oi > zro_hi{ld.i} ? oi : zro_hi{ld.i}; }}")
         for j, k in enumerate(keys):
             an = ref(Lp.cells[k])
-            L.append(f"        {{ const int64_t A = (int64_t){an}; zt_abad |= A >= mcap;")
+            L.append(f"        {{ const int64_t A = (int64_t){an};{' zt_abad |= A >= mcap;' if k in Lp.cell_out else ''}")
             L.append(f"          if (zk == 0) {{ za0_{j} = zalo_{j} = zahi_{j} = A; }} else {{ if (zk == 1) zas_{j} = A - zap_{j}; else zt_abad |= (A - zap_{j}) != zas_{j};")
             L.append(f"            zalo_{j} = A < zalo_{j} ? A : zalo_{j}; zahi_{j} = A > zahi_{j} ? A : zahi_{j}; }}")
             L.append(f"          zap_{j} = A; }}")
@@ -2248,6 +2363,9 @@ class _Emit:
 
     def emit_load(self, n: N, ind: str):
         p, L, ref = self.plan, self.L, self.ref
+        if n.i in self.ring_lds:
+            L.append(f"{ind}const double n{n.i} = zt_ring[{self.ring_lds[n.i].replace('{U%d}' % n.i, ref(self.ring_u[n.i]))}];     // (staged: emit_ring_stage)")
+            return
         L.append(f"{ind}double n{n.i};   // delay-line read: memory as it was before this chunk, or the value an earlier frame of the chunk writes")
         L.append(f"{ind}{{")
         if n.i in self.raw_issued:
@@ -2256,32 +2374,43 @@ class _Emit:
         else:
             L.append(f"{ind}  const int64_t B = (int64_t){ref(n.args[0])};")
             L.append(f"{ind}  double v = B < mcap ? memp[B * mse] : 0.0;")
-        need_best = any(s.mode == "late" and ",".join(map(str, s.region)) == n.name for s in p.stores)
-        if need_best:
-            L.append(f"{ind}  int best = -1;")
+        self.load_checks(n, "B", ind + "  ", forward=True)
+        L.append(f"{ind}  n{n.i} = v;")
+        L.append(f"{ind}}}")
+
+    def has_late_site(self, n: N) -> bool:
+        return any(s.mode == "late" and ",".join(map(str, s.region)) == n.name for s in self.plan.stores)
+
+    def load_checks(self, n: N, B: str, ind: str, forward: bool):
+        """A read at address B against this chunk's writes: other buffers' spans and cells must not be hit; its own buffer's
+        late write is forwarded from the writing frame's lane (`v`, only with forward), an early one is already in memory."""
+        p, L, ref = self.plan, self.L, self.ref
+        if forward and self.has_late_site(n):
+            L.append(f"{ind}int best = -1;")
         for st_ in p.stores:
             j = st_.j
             if st_.mode == "sparse":
-                L.append(f"{ind}  zt_badl |= B >= zlo{j} && B <= zhi{j};")
+                L.append(f"{ind}zt_badl |= {B} >= zlo{j} && {B} <= zhi{j};")
                 continue
             on = f"zsu{j} && " if st_.pred is not None else ""
-            L.append(f"{ind}  {{ int tw = -1; const int64_t d0 = B - s0{j}, d1 = B - s1{j};")
-            L.append(f"{ind}    if ((uint64_t)d0 < (uint64_t)sk{j}) tw = (int)d0;")
-            L.append(f"{ind}    if ((uint64_t)d1 < (uint64_t)(tn - sk{j})) tw = sk{j} + (int)d1;")
-            if ",".join(map(str, st_.region)) != n.name:
-                L.append(f"{ind}    zt_badl |= {on}tw >= 0; }}")
-            elif st_.mode == "early":
+            same = ",".join(map(str, st_.region)) == n.name
+            if not same:
+                L.append(f"{ind}zt_badl |= {on}((uint64_t)({B} - s0{j}) < (uint64_t)sk{j} || (uint64_t)({B} - s1{j}) < (uint64_t)(tn - sk{j}));")
+                continue
+            L.append(f"{ind}{{ int tw = -1; const int64_t d0 = {B} - s0{j}, d1 = {B} - s1{j};")
+            L.append(f"{ind}  if ((uint64_t)d0 < (uint64_t)sk{j}) tw = (int)d0;")
+            L.append(f"{ind}  if ((uint64_t)d1 < (uint64_t)(tn - sk{j})) tw = sk{j} + (int)d1;")
+            if st_.mode == "early":
                 # memory already holds this chunk's values: right for frames at or before this one, wrong for later ones
                 before = "false" if st_.seq < n.val else "true"
-                L.append(f"{ind}    zt_badl |= {on}(tw > lane || (tw == lane && {before})); }}")
+                L.append(f"{ind}  zt_badl |= {on}(tw > lane || (tw == lane && {before})); }}")
             else:
+                assert forward
                 before = "true" if st_.seq < n.val else "false"
-                L.append(f"{ind}    const bool vis = {on}valid && tw >= 0 && (tw < lane || (tw == lane && {before})) && tw >= best;")
-                L.append(f"{ind}    if (__ballot(vis)) {{ const double fw = zt_bperm({ref(st_.value)}, tw); v = vis ? fw : v; best = vis ? tw : best; }} }}")
+                L.append(f"{ind}  const bool vis = {on}valid && tw >= 0 && (tw < lane || (tw == lane && {before})) && tw >= best;")
+                L.append(f"{ind}  if (__ballot(vis)) {{ const double fw = zt_bperm({ref(st_.value)}, tw); v = vis ? fw : v; best = vis ? tw : best; }} }}")
         if self.cell_addrs:
-            L.append(f"{ind}  zt_badl |= B >= cmin && B <= cmax;")
-        L.append(f"{ind}  n{n.i} = v;")
-        L.append(f"{ind}}}")
+            L.append(f"{ind}zt_badl |= {B} >= cmin && {B} <= cmax;")
 
     def emit_region(self, reg: Region, ind: str):
         p, L, ref = self.plan, self.L, self.ref
@@ -2486,9 +2615,276 @@ class _Emit:
         L.append(f"{ind}// uniform loop {Lp.id}: every frame runs the same trips; {len(carried)} values handed from trip to trip, {len(Lp.cell_out)} per-trip cells")
         for v in carried:
             L.append(f"{ind}double {self.phi_name[Lp.phis[v].i]} = {ref(Lp.init[v])};   // {v}")
+        groups = p.rings.get(Lp.id)
+        steps = self.strip_steps(reg)
+        if steps is not None:
+            # counters that step by integers: 64 trips' worth of the loop's wave-uniform work can be done at once, one trip per
+            # lane (emit_strip); checked here, per chunk
+            conds = []
+            for v, (c, sg) in steps.items():
+                conds.append(f"zt_small_int({ref(Lp.init[v])}) && zt_small_int({ref(c)})")
+            L.append(f"{ind}const bool zs{Lp.id} = {' && '.join(conds) if conds else 'true'};")
+        if groups:
+            self.emit_ring_stage(reg, groups, ind)
+            L.append(f"{ind}if (zw{Lp.id}{' && zs%d' % Lp.id if steps is not None else ''}) {{")
+            if steps is not None:
+                self.emit_strip(reg, ind + "  ", carried, steps)
+            else:
+                self.emit_loop_body(reg, ind + "  ", carried)
+            self.ring_lds = {}
+            L.append(f"{ind}}} else {{     // (a window that does not fit, or a ring this is not: gathers from memory)")
+            self.emit_loop_body(reg, ind + "  ", carried)
+            L.append(f"{ind}}}")
+        elif steps is not None and any(it[1].kind in ("ld", "lcin") for it in reg.items):
+            L.append(f"{ind}if (zs{Lp.id}) {{")
+            self.emit_strip(reg, ind + "  ", carried, steps)
+            L.append(f"{ind}}} else {{")
+            self.emit_loop_body(reg, ind + "  ", carried)
+            L.append(f"{ind}}}")
+        else:
+            self.emit_loop_body(reg, ind, carried)
+
+    def strip_steps(self, reg: Region):
+        """{counter: (step node, sign)} when the loop can run in strips of 64 trips: a counted loop of plain nodes whose wave-uniform
+        values handed from trip to trip are all counters, next = this + / - a loop-invariant step. None otherwise."""
+        Lp = reg.loop
+        if os.environ.get("ZA_TPAR_NO_STRIP"):
+            return None
+        if Lp.count is None or reg.comps or reg.subs or Lp.cell_out or any(it[0] != "par" for it in reg.items):
+            return None
+        if any(it[1].kind == "ld" and self.has_late_site(it[1]) for it in reg.items):
+            return None
+        live = self.live_ids()
+        out = {}
+        for v in Lp.order:
+            ph = Lp.phis[v]
+            if not ph.uniform:
+                continue
+            if ph.i not in live and not (v in Lp.louts and Lp.louts[v].i in live):
+                continue
+            nx = Lp.next[v]
+            if nx is ph:
+                continue
+            if nx.kind != "op" or nx.op not in ("+", "-") or len(nx.args) != 2:
+                return None
+            a, b = nx.args
+            if a is ph and not _in_subtree(b, Lp) and (b.uniform or b.kind == "const"):
+                out[v] = (b, 1 if nx.op == "+" else -1)
+            elif nx.op == "+" and b is ph and not _in_subtree(a, Lp) and (a.uniform or a.kind == "const"):
+                out[v] = (a, 1)
+            else:
+                return None
+        return out
+
+    def emit_strip(self, reg: Region, ind: str, carried: List[str], steps):
+        """The loop in strips of 64 trips. Everything wave-uniform in a trip (counters, tap offsets, table reads) depends on the trip
+        number only, so a strip computes it for 64 trips at once, one trip per lane; a trip then fetches its values from its lane
+        (v_readlane) and does the per-frame work: for a FIR tap that is one LDS read and one multiply-add. Same operations on the
+        same values as the trip-by-trip form (integer counters are exact either way), in the same order per frame."""
+        p, L = self.plan, self.L
+        Lp = reg.loop
+        live = self.live_ids()
+        nodes = [it[1] for it in reg.items]
+        uni = [n for n in nodes if n.uniform]
+        per = [n for n in nodes if not n.uniform]
+        # per-frame nodes that only feed values nobody reads inside the loop (locals of a called function: `idx`, `lag`): needed
+        # after the LAST trip only
+        by_id = {n.i: n for n in nodes}
+
+        def cone(roots) -> set:
+            seen: set = set()
+            todo = list(roots)
+            while todo:
+                n = todo.pop()
+                if n.i in seen or n.loop is not Lp or n.i not in by_id:
+                    continue
+                seen.add(n.i)
+                if not (n.kind == "ld" and n.i in self.ring_lds):     # (a staged read does not need its address)
+                    todo.extend(n.args)
+                if n.kind == "lcin":
+                    todo.append(Lp.cells[n.name])
+            return seen
+
+        dead = [v for v in carried if Lp.phis[v].i not in live and not Lp.phis[v].uniform]
+        while True:
+            ccone = cone([Lp.next[v] for v in dead])
+            clash = [v for v in dead if any(a.kind == "phi" and a.loop is Lp and not a.uniform
+                                            for i in cone([Lp.next[v]]) for a in by_id[i].args)]
+            if not clash:
+                break
+            dead = [v for v in dead if v not in clash]
+        hot = cone([Lp.next[v] for v in carried if v not in dead and not Lp.phis[v].uniform])
+        per_hot = [n for n in per if n.i in hot]
+        cold = [n for n in per if n.i in ccone]
+        ring_u_hot = [self.ring_u[m.i] for m in per_hot if m.i in self.ring_lds]
+        uni_x = [Lp.phis[v] for v in steps] + uni         # (the counters are wave-uniform values of a trip too)
+        exports_hot = [n for n in uni_x if any(n in m.args for m in per_hot if not (m.kind == "ld" and m.i in self.ring_lds))]
+        exports_cold = [n for n in uni_x if any(n in m.args for m in cold if not (m.kind == "ld" and m.i in self.ring_lds))
+                        or any(Lp.next[v] is n for v in dead)]
+        uph = [v for v in steps]
+        ind2, ind3 = ind + "  ", ind + "    "
+        L.append(f"{ind}const int64_t zc{Lp.id} = za_loopcount(ZT_UNI({self.ref(Lp.count)}));")
+        L.append(f"{ind}for (int64_t zs0 = 0; zs0 < zc{Lp.id}; zs0 += 64) {{     // a strip: lane j holds what trip zs0 + j needs")
+        self.sctx = (Lp, "vec")
+        for v in uph:
+            c, sg = steps[v]
+            nm = f"t{Lp.phis[v].i}"
+            L.append(f"{ind2}const double {nm} = {self.ref_out(Lp.init[v])} {'+' if sg > 0 else '-'} (double)(zs0 + lane) * {self.ref_out(c)};   // {v}")
+        for n in uni:
+            if n.kind == "lcin":
+                a = self.ref(Lp.cells[n.name])
+                L.append(f"{ind2}const int64_t ta{n.i} = (int64_t)(int){a};")
+                L.append(f"{ind2}const double t{n.i} = (zs0 + lane < zc{Lp.id} && ta{n.i} < mcap) ? memp[ta{n.i} * mse] : 0.0;     // (a cell this loop only reads)")
+            else:
+                L.append(f"{ind2}const double t{n.i} = {_expr(n.op, [self.ref(x) for x in n.args])};")
+        # ring offsets as integers (one v_readlane per trip instead of two and a conversion)
+        ring_int = {}
+        for m in per_hot + [c_ for c_ in cold if c_ not in per_hot]:
+            if m.i in self.ring_lds:
+                u = self.ring_u[m.i]
+                ring_int[m.i] = f"to{m.i}"
+                expr = self.ring_lds[m.i].replace('{U%d}' % m.i, self.ref(u))
+                expr = expr.replace("lane + ", "")       # (the frame's lane is added per trip)
+                L.append(f"{ind2}const int to{m.i} = {expr};")
+        self.sctx = (Lp, "trip")
+        L.append(f"{ind2}const int zm = (int)(zc{Lp.id} - zs0 < 64 ? zc{Lp.id} - zs0 : 64);")
+        L.append("#pragma unroll 4")
+        L.append(f"{ind2}for (int zj = 0; zj < zm; ++zj) {{")
+        for n in exports_hot:
+            L.append(f"{ind3}const double e{n.i} = zt_readlane(t{n.i}, zj);")
+
+        def ring_read(n: N) -> str:
+            lane_term = "lane + " if "lane + " in self.ring_lds[n.i] else ""
+            return f"zt_ring[{lane_term}__builtin_amdgcn_readlane({ring_int[n.i]}, zj)]"
+
+        for n in per_hot:
+            if n.kind == "ld" and n.i in self.ring_lds:
+                L.append(f"{ind3}const double n{n.i} = {ring_read(n)};")
+            elif n.kind == "ld":
+                L.append(f"{ind3}const int64_t B{n.i} = (int64_t)(int){self.ref(n.args[0])};")
+                L.append(f"{ind3}const double n{n.i} = B{n.i} < mcap ? memp[B{n.i} * mse] : 0.0;")
+                self.load_checks(n, f"B{n.i}", ind3, forward=False)
+            else:
+                L.append(f"{ind3}const double n{n.i} = {_expr(n.op, [self.ref(x) for x in n.args])};")
+        lv = [v for v in carried if v not in dead and not Lp.phis[v].uniform and Lp.next[v] is not Lp.phis[v]]
+        tmp = [v for v in lv if Lp.next[v].kind == "phi"]
+        for v in tmp:
+            L.append(f"{ind3}const double q{self.phi_name[Lp.phis[v].i]} = {self.ref(Lp.next[v])};")
+        for v in lv:
+            src = f"q{self.phi_name[Lp.phis[v].i]}" if v in tmp else self.ref(Lp.next[v])
+            L.append(f"{ind3}{self.phi_name[Lp.phis[v].i]} = {src};")
+        L.append(f"{ind2}}}")
+        if dead:
+            self.sctx = (Lp, "cold")
+            L.append(f"{ind2}if (zs0 + 64 >= zc{Lp.id}) {{   // after the last trip: values the loop hands on without reading them itself")
+            L.append(f"{ind3}const int zj = zm - 1;")
+            for n in exports_cold:
+                L.append(f"{ind3}const double e{n.i} = zt_readlane(t{n.i}, zj);")
+            for n in cold:
+                if n.kind == "ld" and n.i in self.ring_lds:
+                    L.append(f"{ind3}const double k{n.i} = {ring_read(n)};")
+                elif n.kind == "ld":
+                    L.append(f"{ind3}const int64_t Bk{n.i} = (int64_t)(int){self.ref(n.args[0])};")
+                    L.append(f"{ind3}const double k{n.i} = Bk{n.i} < mcap ? memp[Bk{n.i} * mse] : 0.0;")
+                else:
+                    L.append(f"{ind3}const double k{n.i} = {_expr(n.op, [self.ref(x) for x in n.args])};")
+            for v in dead:
+                if Lp.next[v] is not Lp.phis[v]:
+                    L.append(f"{ind3}{self.phi_name[Lp.phis[v].i]} = {self.ref(Lp.next[v])};")
+            L.append(f"{ind2}}}")
+        L.append(f"{ind}}}")
+        self.sctx = None
+        for v in uph:                                     # the counters after the loop
+            c, sg = steps[v]
+            if Lp.phis[v].i in live or (v in Lp.louts and Lp.louts[v].i in live):
+                L.append(f"{ind}{self.phi_name[Lp.phis[v].i]} = {self.ref(Lp.init[v])} {'+' if sg > 0 else '-'} (double)zc{Lp.id} * {self.ref(c)};")
+
+    def ref_out(self, n: N) -> str:
+        """A node outside the loop, named from inside a strip."""
+        save, self.sctx = self.sctx, None
+        try:
+            return self.ref(n)
+        finally:
+            self.sctx = save
+
+    def emit_ring_stage(self, reg: Region, groups: List[RingGroup], ind: str):
+        """Stage, per RingGroup of the loop, the chunk's window of the ring in LDS -- after checking everything the LDS form of
+        the loop takes for granted: the mask is 2^k - 1, base and offsets are integers, consecutive frames sit one ring cell
+        apart, the window fits, no staged cell belongs to another buffer's freshly written span or to a mem[] cell, and no read
+        reaches a cell that a LATER frame of this chunk has already overwritten (the ring's own early write)."""
+        p, L, ref = self.plan, self.L, self.ref
+        Lp = reg.loop
+        cap = f"(ZT_RING_DOUBLES / {len(groups)})"
+        L.append(f"{ind}bool zw{Lp.id} = zrok{Lp.id};")
+        for grp in groups:
+            g = f"{Lp.id}_{grp.idx}"
+            ssum = " + ".join(ref(x) for x in grp.S) if grp.S else "0.0"
+            lo = " , ".join(f"zro_lo{ld.i}" for ld, _, _ in grp.loads)
+            L.append(f"{ind}const double zwSd{g} = {ssum}, zwMd{g} = {ref(grp.mask)};")
+            L.append(f"{ind}const int zwS{g} = (int)zwSd{g}, zwM{g} = (int)zwMd{g};")
+            L.append(f"{ind}zw{Lp.id} &= (double)zwS{g} == zwSd{g} && zwS{g} >= 0 && (double)zwM{g} == zwMd{g} && zwM{g} >= 63 && (zwM{g} & (zwM{g} + 1)) == 0;")
+            L.append(f"{ind}int zwo{g} = 2147483647, zwh{g} = -2147483647;")
+            for ld, _, _ in grp.loads:
+                L.append(f"{ind}zwo{g} = zro_lo{ld.i} < zwo{g} ? zro_lo{ld.i} : zwo{g}; zwh{g} = zro_hi{ld.i} > zwh{g} ? zro_hi{ld.i} : zwh{g};")
+            step = 0 if grp.P.uniform else 1
+            L.append(f"{ind}const int zwn{g} = zwh{g} >= zwo{g} ? zwh{g} - zwo{g} + {64 if step else 1} : 0;")
+            L.append(f"{ind}zw{Lp.id} &= zwn{g} > 0 && zwn{g} <= {cap} && zwn{g} <= zwM{g} - 63;")
+            if step:
+                L.append(f"{ind}const double zwPd{g} = zt_readlane({ref(grp.P)}, 0);")
+                L.append(f"{ind}const int zwP{g} = (int)zwPd{g};")
+                L.append(f"{ind}zw{Lp.id} &= (double)zwP{g} == zwPd{g} && fabs(zwPd{g}) < 1.0e9 && __ballot(valid && ({ref(grp.P)} != zwPd{g} + (double)lane) && "
+                         f"({ref(grp.P)} != zwPd{g} + (double)lane - (double)(zwM{g} + 1))) == 0ull;")
+            else:
+                L.append(f"{ind}const double zwPd{g} = {ref(grp.P)};")
+                L.append(f"{ind}const int zwP{g} = (int)zwPd{g};")
+                L.append(f"{ind}zw{Lp.id} &= (double)zwP{g} == zwPd{g} && fabs(zwPd{g}) < 1.0e9;")
+            if grp.site is not None:
+                j = grp.site.j
+                L.append(f"{ind}if (zw{Lp.id}) {{   // the ring's own write of this chunk is in memory already: no read may reach a cell a later frame wrote")
+                L.append(f"{ind}  const int M1 = zwM{g} + 1, w0 = (int)(s0{j} - zwS{g});")
+                L.append(f"{ind}  const bool ring = w0 >= 0 && w0 <= zwM{g} && (sk{j} >= tn || (s1{j} == zwS{g} && ((w0 + sk{j}) & zwM{g}) == 0));")
+                L.append(f"{ind}  const int a = (zwP{g} - w0 + zwo{g}) & zwM{g}, len = zwh{g} - zwo{g} + 1;")
+                L.append(f"{ind}  zw{Lp.id} &= ring && !(len >= M1 - 64 || (a <= 63 && a + len - 1 >= 1) || a + len - 1 >= M1 + 1);")
+                L.append(f"{ind}}}")
+        L.append(f"{ind}if (zw{Lp.id}) {{")
+        L.append(f"{ind}  bool zwb = false;")
+        for grp in groups:
+            g = f"{Lp.id}_{grp.idx}"
+            off = f"{grp.idx} * {cap}"
+            L.append(f"{ind}  for (int j = lane; j < zwn{g}; j += 64) {{")
+            L.append(f"{ind}    const int64_t Be = (int64_t)zwS{g} + ((zwP{g} + zwo{g} + j) & zwM{g});")
+            L.append(f"{ind}    zt_ring[{off} + j] = Be < mcap ? memp[Be * mse] : 0.0;")
+            for st_ in p.stores:
+                if st_ is grp.site:
+                    continue
+                j2 = st_.j
+                if st_.mode == "sparse":
+                    L.append(f"{ind}    zwb |= Be >= zlo{j2} && Be <= zhi{j2};")
+                else:
+                    on = f"zsu{j2} && " if st_.pred is not None else ""
+                    L.append(f"{ind}    zwb |= {on}((uint64_t)(Be - s0{j2}) < (uint64_t)sk{j2} || (uint64_t)(Be - s1{j2}) < (uint64_t)(tn - sk{j2}));")
+            if self.cell_addrs:
+                L.append(f"{ind}    zwb |= Be >= cmin && Be <= cmax;")
+            L.append(f"{ind}  }}")
+            for ld, u, sign in grp.loads:
+                lane_term = "lane + " if not grp.P.uniform else ""
+                self.ring_lds[ld.i] = f"{off} + {lane_term}((int){'' if sign > 0 else '-'}{{U{ld.i}}} - zwo{g})"
+        L.append(f"{ind}  zt_bad |= __ballot(zwb) != 0ull;")
+        L.append(f"{ind}  __syncthreads();")
+        L.append(f"{ind}}}")
+        # (the offsets name each load's own U node: resolved where the load is emitted, plain or per sub-trip of a batch)
+        self.ring_u = {ld.i: u for grp in groups for ld, u, _ in grp.loads}
+
+    def emit_loop_body(self, reg: Region, ind: str, carried: List[str]):
+        p, L, ref = self.plan, self.L, self.ref
+        Lp = reg.loop
         if Lp.count is not None:
             L.append(f"{ind}const int64_t zc{Lp.id} = za_loopcount(ZT_UNI({ref(Lp.count)}));")
-            L.append(f"{ind}for (int64_t zk{Lp.id} = 0; zk{Lp.id} < zc{Lp.id}; ++zk{Lp.id}) {{")
+            L.append(f"{ind}int64_t zk{Lp.id} = 0;")
+            G = self.batch_width(reg)
+            if G > 1:
+                self.emit_batched(reg, ind, G, carried)
+            L.append(f"{ind}for (; zk{Lp.id} < zc{Lp.id}; ++zk{Lp.id}) {{")
         else:
             L.append(f"{ind}for (int64_t zk{Lp.id} = 0; zk{Lp.id} < ZA_LOOP_CAP; ++zk{Lp.id}) {{")
             if Lp.cond is not None and not _in_subtree(Lp.cond, Lp):
@@ -2509,6 +2905,114 @@ class _Emit:
                 continue
             src = f"q{self.phi_name[Lp.phis[v].i]}" if v in tmp else ref(Lp.next[v])
             L.append(f"{ind}  {self.phi_name[Lp.phis[v].i]} = {src};")
+        L.append(f"{ind}}}")
+
+    def batch_levels(self, reg: Region):
+        """Per node of a gather loop's trip: how many loads lie in front of it (None: it follows a value handed from trip to trip,
+        i.e. it belongs to the accumulation phase). None for the whole loop when its trips cannot be batched."""
+        Lp = reg.loop
+        if Lp.count is None or reg.comps or reg.subs or Lp.cell_out or any(it[0] != "par" for it in reg.items):
+            return None
+        nodes = [it[1] for it in reg.items]
+        if not any(n.kind in ("ld", "lcin") for n in nodes) or any(n.kind == "ld" and self.has_late_site(n) for n in nodes):
+            return None
+        lev: Dict[int, Optional[int]] = {}
+        for n in nodes:
+            deps = (Lp.cells[n.name],) if n.kind == "lcin" else n.args
+            v: Optional[int] = 0
+            for d in deps:
+                if d.loop is not Lp or d.kind == "const":
+                    continue
+                if d.kind == "phi":
+                    dl = 0 if d.uniform else None
+                else:
+                    dl = lev.get(d.i, 0)
+                    if dl is not None and d.kind in ("ld", "lcin"):
+                        dl += 1
+                if dl is None:
+                    v = None
+                    break
+                v = max(v, dl)
+            lev[n.i] = v
+        for v_ in Lp.order:                       # a counter's next value must not wait for a load
+            ph = Lp.phis[v_]
+            if ph.uniform and ph.i in self.live_ids():
+                nx = Lp.next[v_]
+                if nx.loop is Lp and nx.kind != "phi" and lev.get(nx.i, 0) != 0:
+                    return None
+        return lev
+
+    def batch_width(self, reg: Region) -> int:
+        env = os.environ.get("ZA_TPAR_GATHER_BATCH")
+        if env is not None and int(env) <= 1:
+            return 1
+        lev = self.batch_levels(reg)
+        if lev is None:
+            return 1
+        loads = sum(1 for it in reg.items if it[1].kind in ("ld", "lcin"))
+        return int(env) if env is not None else (8 if loads <= 3 else 4)
+
+    def emit_batched(self, reg: Region, ind: str, G: int, carried: List[str]):
+        """G trips of a gather loop at a time: the trips' addresses first, then all of their loads (G memory latencies overlap
+        instead of adding up), then the accumulation in trip order -- the same operations per trip as the plain loop behind it,
+        which takes the remaining trips."""
+        p, L = self.plan, self.L
+        Lp = reg.loop
+        lev = self.batch_levels(reg)
+        nodes = [it[1] for it in reg.items]
+        top = max((v for v in lev.values() if v is not None), default=0)
+        ind2 = ind + "  "
+        L.append(f"{ind}for (; zk{Lp.id} + {G} <= zc{Lp.id}; zk{Lp.id} += {G}) {{     // {G} trips per pass: their loads are in flight together")
+
+        def finish(level: int):
+            for u in range(G):
+                self.bctx = (Lp, u)
+                for n in nodes:
+                    if lev[n.i] != level:
+                        continue
+                    if n.kind == "lcin":
+                        L.append(f"{ind2}const double n{n.i}_{u} = ZT_UNI(r{n.i}_{u});")
+                    elif n.kind == "ld":
+                        if n.i not in self.ring_lds:
+                            self.load_checks(n, f"B{n.i}_{u}", ind2, forward=False)
+                        L.append(f"{ind2}const double n{n.i}_{u} = r{n.i}_{u};")
+
+        for level in range(top + 1):
+            if level:
+                finish(level - 1)
+            for u in range(G):
+                self.bctx = (Lp, u)
+                for n in nodes:
+                    if lev[n.i] != level:
+                        continue
+                    if n.kind == "lcin":
+                        a = self.ref(Lp.cells[n.name])
+                        L.append(f"{ind2}const int64_t la{n.i}_{u} = (int64_t){a};")
+                        L.append(f"{ind2}const double r{n.i}_{u} = la{n.i}_{u} < mcap ? memp[la{n.i}_{u} * mse] : 0.0;     // (a cell this loop only reads)")
+                    elif n.kind == "ld" and n.i in self.ring_lds:
+                        L.append(f"{ind2}const double r{n.i}_{u} = zt_ring[{self.ring_lds[n.i].replace('{U%d}' % n.i, self.ref(self.ring_u[n.i]))}];")
+                    elif n.kind == "ld":
+                        L.append(f"{ind2}const int64_t B{n.i}_{u} = (int64_t){self.ref(n.args[0])};")
+                        L.append(f"{ind2}const double r{n.i}_{u} = B{n.i}_{u} < mcap ? memp[B{n.i}_{u} * mse] : 0.0;")
+                    else:
+                        e = _expr(n.op, [self.ref(x) for x in n.args])
+                        L.append(f"{ind2}const double n{n.i}_{u} = {('ZT_UNI(' + e + ')') if n.uniform else e};")
+        finish(top)
+        for u in range(G):                            # the accumulation, trip by trip
+            self.bctx = (Lp, u)
+            for n in nodes:
+                if lev[n.i] is None:
+                    e = _expr(n.op, [self.ref(x) for x in n.args])
+                    L.append(f"{ind2}const double n{n.i}_{u} = {e};")
+        self.bctx = (Lp, G - 1)
+        for v in carried:
+            if Lp.next[v] is Lp.phis[v]:
+                continue
+            L.append(f"{ind2}const double q{self.phi_name[Lp.phis[v].i]} = {self.ref(Lp.next[v])};")
+        self.bctx = None
+        for v in carried:
+            if Lp.next[v] is not Lp.phis[v]:
+                L.append(f"{ind2}{self.phi_name[Lp.phis[v].i]} = q{self.phi_name[Lp.phis[v].i]};")
         L.append(f"{ind}}}")
 
     # -- the serial finish ---------------------------------------------------------------------------------------------------------
