@@ -96,6 +96,11 @@ __device__ __forceinline__ bool zt_sites_ok(int64_t a0, int64_t s0, int64_t lo0,
   return (a1 - a0) % s0 != 0;
 }
 
+// LDS doubles for the per-trip cells of a block's uniform loops (band states: CMD 26 cells x 32 bands)
+#ifndef ZT_CELL_DOUBLES
+#define ZT_CELL_DOUBLES 2048
+#endif
+
 // an integer small enough that sums and products of a few of them stay exact in a double (loop counters run in strips: i0 + k * step)
 __device__ __forceinline__ bool zt_small_int(double x) { return x == floor(x) && fabs(x) < 1.0e12; }
 

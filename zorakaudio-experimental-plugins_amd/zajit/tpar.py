@@ -1766,6 +1766,19 @@ class _Emit:
             return "ZT_HOLD"
         if self.sctx is not None and n.loop is self.sctx[0] and n.kind != "lout":      # a strip of 64 trips (emit_strip)
             Lp, mode = self.sctx
+            if isinstance(mode, tuple):               # sub-trip u of a group of trips whose fetches go out together
+                u = mode[1]
+                if n.uniform:
+                    return f"e{n.i}_{u}"
+                if n.kind == "phi":
+                    if u == 0:
+                        return self.phi_name[n.i]
+                    self.sctx = (Lp, ("g", u - 1))
+                    try:
+                        return self.ref(Lp.next[n.name])
+                    finally:
+                        self.sctx = (Lp, mode)
+                return f"n{n.i}_{u}"
             if n.uniform:
                 if mode == "vec":                     # lane j = trip k0 + j
                     return f"t{n.i}"
@@ -1840,6 +1853,16 @@ class _Emit:
         L.append("#ifndef ZT_UNI")
         L.append("#define ZT_UNI(x) zt_uniform(x)")
         L.append("#endif")
+        self.stamps = bool(os.environ.get("ZA_TPAR_STAMPS"))
+        if self.stamps:      # in-kernel phase clock (tools/tpar_stamps.py): cycles per phase, summed over the waves of a launch
+            L.append("__device__ unsigned long long zt_stamps[64];")
+            L.append('extern "C" void zab_tpar_stamps(unsigned long long* out, int reset) {')
+            L.append("  if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(zt_stamps), sizeof(zt_stamps));")
+            L.append("  if (reset) { unsigned long long z[64] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(zt_stamps), z, sizeof(z)); }")
+            L.append("}")
+            L.append("#define ZT_STAMP(k) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) atomicAdd(&zt_stamps[k], t_ - zt_t0); zt_t0 = __builtin_amdgcn_s_memtime(); }")
+        else:
+            L.append("#define ZT_STAMP(k)")
         L.append(f'extern "C" __global__ void __launch_bounds__(64) {km}(ZabBatch b, ZabAudio a) {{')
         if self.has_serial:
             L.append("  ZA_KERNEL_ENTRY();")
@@ -1847,6 +1870,8 @@ class _Emit:
         L.append("  const int64_t inst = blockIdx.x;")
         L.append("  const int64_t frames = a.frames;")
         L.append("  if (frames <= 0 || inst >= b.n_inst) return;")
+        if self.stamps:
+            L.append("  unsigned long long zt_t0 = __builtin_amdgcn_s_memtime();")
         if p.uses_rand:
             L.append("  __shared__ uint32_t zt_mt[2 * ZT_MT_N];      // rand(): current and next generation of the instance's MT19937")
             L.append("  uint32_t* const zt_gmt = b.mt + inst * b.mt_si;")
@@ -1877,6 +1902,9 @@ class _Emit:
             L.append(f"  __shared__ double zt_q[{len(self.inv_coefs)} * 4];       // a^2, a^4, a^8, a^16")
         if p.rings:
             L.append("  __shared__ double zt_ring[ZT_RING_DOUBLES];     // a chunk's window of the ring a loop gathers from (RingGroup)")
+        self.cell_loops = [L_ for L_ in p.loops if L_.cell_out and not os.environ.get("ZA_TPAR_NO_LDS_CELLS")]
+        if self.cell_loops:
+            L.append("  __shared__ double zt_cells[ZT_CELL_DOUBLES];    // the per-trip cells of a block's loops: staged per block, kept here from chunk to chunk")
         if self.has_abort:
             L.append(f"  __shared__ double zt_snap[{max(1, len(self.cname))}];")
         if self.has_mem:
@@ -1898,15 +1926,38 @@ class _Emit:
         self.pin = ", ".join(f'"+v"(x{n.i})' for n in p.inputs)
         if self.pin:
             L.append(f"  asm volatile(\"\" : {self.pin});")
+        self.cell_slot: Dict[tuple, int] = {}
+        for lid, groups in p.rings.items():
+            L.append(f"  bool zrok{lid} = true;     // ring reads of loop {lid}: offsets of every trip (integers), per read")
+            for grp in groups:
+                for ld, _, _ in grp.loads:
+                    L.append(f"  int zro_lo{ld.i} = 2147483647, zro_hi{ld.i} = -2147483647;")
+        for Lp in self.cell_loops:
+            keys = self.pass_keys(Lp)
+            for j, k in enumerate(keys):
+                self.cell_slot[(Lp.id, k)] = j
+            L.append(f"  int zln{Lp.id} = 0, zlo{Lp.id} = 0; bool zlds{Lp.id} = false;     // loop {Lp.id}: trips, its place in zt_cells, staged or not")
+            L.append(f"  int64_t zla{Lp.id}[{len(keys)}], zls{Lp.id}[{len(keys)}];")
         L.append(f"  const int64_t blk = {'a.block > 0 ? (int64_t)a.block : frames' if p.has_block else 'frames'};   // a script without @block sees one block per launch")
+        self.pass_memo: Dict[int, tuple] = {}
+        memo_at = len(L)
         L.append("  for (int64_t pos = 0; pos < frames; pos += blk) {")
         L.append("    const int64_t bn = frames - pos < blk ? frames - pos : blk;")
         L.append("    const int64_t bend = pos + bn;")
+        L.append("    ZT_STAMP(7)")
         if self.has_serial:
             self.emit_serial_phase()
+        L.append("    ZT_STAMP(0)")
         self.emit_block_prologue()
+        L.append("    ZT_STAMP(1)")
         self.emit_chunk_loop()
         L.append("  }")
+        decl = []
+        for lid, (memo, xs) in self.pass_memo.items():
+            decl.append(f"  bool zpv{lid} = false; int64_t zph{lid} = 0;     // address pass of loop {lid}: done for these inputs, high-water mark it found")
+            if memo and xs:
+                decl.append("  uint64_t " + ", ".join(f"zpi{lid}_{k} = 0" for k in range(len(xs))) + ";")
+        L[memo_at:memo_at] = decl
         if self.has_serial:
             L.append("  if (lane == 0 && zt_pend_seen) b.pend[3 * (int64_t)b.n_pad + inst] |= zt_pend_seen;")
         if self.has_abort:
@@ -1938,9 +1989,25 @@ class _Emit:
         L.append("#else")
         L.append("      const bool zt_run = lane == 0;")
         L.append("#endif")
+        # Only what @block (and @slider, where the script can raise a mask) names is loaded, only what they assign is stored: the
+        # rest of the state stays where it is -- a script's few hundred variables need not all be live across its @block.
+        prog = self.prog
+        secs = list(prog.sections.get("block", [])) if p.has_block else []
+        if p.has_pending:
+            secs += list(prog.sections.get("slider", []))
+        rd = sorted(prog.vars[nm] for nm in _read_names(prog, secs) if nm in prog.vars)
+        wr = sorted(prog.vars[nm] for nm in _assigned_names(prog, secs) if nm in prog.vars)
         L.append("      if (zt_run) {")
         L.append("        ZaS s;")
-        L.append("        za_state_load(s, b, (int)inst);")
+        L.append("        za_state_bind(s, b, (int)inst);")
+        for k0 in range(0, len(rd), 8):
+            L.append("        " + " ".join(f"s.v[{k}] = b.vars[{k} * b.var_se + inst * b.var_si];" for k in rd[k0:k0 + 8]))
+        L.append("#define ZA_X(k) s.sl[k] = b.sliders[(k) * b.sl_se + inst * b.sl_si];")
+        L.append("        ZA_FOR_USED_SL(ZA_X)")
+        L.append("#undef ZA_X")
+        L.append("#define ZA_X(k) s.spl[k] = b.spl[(k) * b.sl_se + inst * b.sl_si];")
+        L.append("        ZA_FOR_USED_SPL(ZA_X)")
+        L.append("#undef ZA_X")
         L.append("#ifdef ZA_REPLICAS")
         L.append("        s.replica = lane != 0 ? 1u : 0u; s.rep_i = (uint32_t)lane; s.rep_n = 64u; s.rep_stride = 1u;")
         L.append("#endif")
@@ -1951,10 +2018,24 @@ class _Emit:
             L.append("        za_msg_begin_block(s);")
             L.append("#endif")
             L.append("        za_section_block(s);")
-        L.append("        if (s.pend_change | s.pend_automate | s.pend_automate_end) za_section_slider(s);")
-        L.append("        zt_pend_seen |= s.pend_change | s.pend_automate | s.pend_automate_end;")
-        L.append("        s.pend_change = s.pend_automate = s.pend_automate_end = 0;")
-        L.append("        if (lane == 0) za_state_store(s, b, (int)inst);")
+        if p.has_pending:
+            L.append("        if (s.pend_change | s.pend_automate | s.pend_automate_end) za_section_slider(s);")
+            L.append("        zt_pend_seen |= s.pend_change | s.pend_automate | s.pend_automate_end;")
+            L.append("        s.pend_change = s.pend_automate = s.pend_automate_end = 0;")
+        L.append("        if (lane == 0) {")
+        for k0 in range(0, len(wr), 8):
+            L.append("          " + " ".join(f"b.vars[{k} * b.var_se + inst * b.var_si] = s.v[{k}];" for k in wr[k0:k0 + 8]))
+        L.append("#define ZA_X(k) b.sliders[(k) * b.sl_se + inst * b.sl_si] = s.sl[k];")
+        L.append("          ZA_FOR_USED_SL(ZA_X)")
+        L.append("#undef ZA_X")
+        L.append("#define ZA_X(k) b.spl[(k) * b.sl_se + inst * b.sl_si] = s.spl[k];")
+        L.append("          ZA_FOR_USED_SPL(ZA_X)")
+        L.append("#undef ZA_X")
+        L.append("          b.mem_high[inst] = s.mem_high; b.mem_need[inst] = s.mem_need; b.mti[inst] = s.mti; b.err[inst] = s.err;")
+        L.append("          b.pend[inst] = s.pend_change; b.pend[b.n_pad + inst] = s.pend_automate; b.pend[2 * (int64_t)b.n_pad + inst] = s.pend_automate_end;")
+        L.append("          b.vis_mask[inst] = s.vis_mask; b.vis_init[inst] = s.vis_init;")
+        L.append("          if (b.gmem_att) b.gmem_att[inst] = s.gmem_attached;")
+        L.append("        }")
         L.append("      }")
         L.append("      __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"workgroup\");")
         L.append("      __builtin_amdgcn_wave_barrier();")
@@ -2012,13 +2093,20 @@ class _Emit:
                 L.append(f"    if ({clash}) {{   // cells that alias each other (or lie past the arena): not a case for this kernel")
                 self.emit_leave("      ", "pos")
                 L.append("    }")
-        for lid, groups in p.rings.items():
-            L.append(f"    bool zrok{lid} = true;     // ring reads of loop {lid}: offsets of every trip (integers), per read")
-            for grp in groups:
-                for ld, _, _ in grp.loads:
-                    L.append(f"    int zro_lo{ld.i} = 2147483647, zro_hi{ld.i} = -2147483647;")
         for Lp in self.lcell_loops:
             self.emit_address_pass(Lp)
+        if self.cell_loops:
+            L.append("    {   // per-trip cells into LDS for the length of the block (a loop whose cells do not fit keeps them in memory)")
+            L.append("      int zoff = 0;")
+            for Lp in self.cell_loops:
+                nk = len(self.pass_keys(Lp))
+                L.append(f"      zlo{Lp.id} = zoff; zlds{Lp.id} = zln{Lp.id} > 0 && zoff + {nk} * zln{Lp.id} <= ZT_CELL_DOUBLES; if (zlds{Lp.id}) zoff += {nk} * zln{Lp.id};")
+                L.append(f"      if (zlds{Lp.id}) {{")
+                L.append(f"        for (int q = lane; q < {nk} * zln{Lp.id}; q += 64) {{ const int j = q / zln{Lp.id}, k = q - j * zln{Lp.id}; const int64_t A = zla{Lp.id}[j] + (int64_t)k * zls{Lp.id}[j];")
+                L.append(f"          zt_cells[zlo{Lp.id} + q] = A < mcap ? memp[A * mse] : 0.0; }}")
+                L.append("      }")
+            L.append("      __syncthreads();")
+            L.append("    }")
         if self.inv_mats:
             L.append("    __syncthreads();")
             for k, key in enumerate(self.inv_mats):
@@ -2044,7 +2132,7 @@ class _Emit:
         (zt_sites_ok: disjoint ranges, or interleaved records -- same stride, offsets that differ by less than a multiple of it)."""
         p, L, ref = self.plan, self.L, self.ref
         reg = p.regions[Lp.id]
-        keys = [k for k in Lp.cells if (k in Lp.cin and Lp.cin[k].i in self.live_ids()) or k in Lp.cell_out]
+        keys = self.pass_keys(Lp)
         rloads = [x for grp in p.rings.get(Lp.id, []) for x in grp.loads]
         need: Dict[int, N] = {}
         todo = [Lp.cells[k] for k in keys] + ([Lp.cond] if Lp.cond is not None else []) + [u for _, u, _ in rloads]
@@ -2061,17 +2149,39 @@ class _Emit:
             if n.kind == "lcin":
                 todo.append(Lp.cells[n.name])
             todo.extend(n.args)
+        # what the pass reads from outside: when none of it has changed since the previous block, neither has the result
+        ext: Dict[int, N] = {}
+        for n in list(need.values()) + [Lp.init[v] for v in uphis] + ([Lp.count] if Lp.count is not None else []) + list(self.cell_addrs):
+            for x in ((n,) if not _in_subtree(n, Lp) else n.args):
+                if not _in_subtree(x, Lp) and x.kind not in ("const", "hold"):
+                    ext[x.i] = x
+        memo = not any(n.kind == "lcin" for n in need.values()) and all(x.uniform for x in ext.values())
+        self.pass_memo[Lp.id] = (memo, [ext[i] for i in sorted(ext)])
         L.append(f"    {{   // per-trip cells of loop {Lp.id}: addresses step evenly through the trips and never meet; offsets of its ring reads")
+        if memo:
+            same = " && ".join([f"zpv{Lp.id}"] + [f"__builtin_bit_cast(uint64_t, {ref(x)}) == zpi{Lp.id}_{k}" for k, x in enumerate(self.pass_memo[Lp.id][1])])
+            L.append(f"      if (!({same})) {{")
+            for k, x in enumerate(self.pass_memo[Lp.id][1]):
+                L.append(f"      zpi{Lp.id}_{k} = __builtin_bit_cast(uint64_t, {ref(x)});")
+            L.append(f"      zpv{Lp.id} = true; zph{Lp.id} = 0;")
+        else:
+            L.append(f"      zph{Lp.id} = 0;")
+            L.append("      {")
+        if Lp.id in p.rings:
+            L.append(f"      zrok{Lp.id} = true;")
+            for ld, _, _ in rloads:
+                L.append(f"      zro_lo{ld.i} = 2147483647; zro_hi{ld.i} = -2147483647;")
         L.append("      bool zt_abad = false;")
         for v in uphis:
             L.append(f"      double {self.phi_name[Lp.phis[v].i]} = {ref(Lp.init[v])};")
         for j, k in enumerate(keys):
             L.append(f"      int64_t za0_{j} = 0, zas_{j} = 1, zap_{j} = 0, zalo_{j} = 0, zahi_{j} = -1;")
+        L.append("      int64_t zkn = 0;")
         if Lp.count is not None:
             L.append(f"      const int64_t zt_cnt = za_loopcount(ZT_UNI({ref(Lp.count)}));")
-            L.append("      for (int64_t zk = 0; zk < zt_cnt; ++zk) {")
+            L.append("      for (int64_t zk = 0; zk < zt_cnt; ++zk, ++zkn) {")
         else:
-            L.append("      for (int64_t zk = 0; zk < ZA_LOOP_CAP; ++zk) {")
+            L.append("      for (int64_t zk = 0; zk < ZA_LOOP_CAP; ++zk, ++zkn) {")
         for i in sorted(need):
             n = need[i]
             if n.kind == "phi":
@@ -2099,6 +2209,10 @@ class _Emit:
         for v in uphis:
             L.append(f"        {self.phi_name[Lp.phis[v].i]} = q{self.phi_name[Lp.phis[v].i]};")
         L.append("      }")
+        if Lp in getattr(self, "cell_loops", []):
+            L.append(f"      zln{Lp.id} = (int)zkn;")
+            for j, k in enumerate(keys):
+                L.append(f"      zla{Lp.id}[{j}] = za0_{j}; zls{Lp.id}[{j}] = zas_{j};")
         for j, k in enumerate(keys):
             for j2 in range(j + 1, len(keys)):
                 if k in Lp.cell_out or keys[j2] in Lp.cell_out:
@@ -2106,11 +2220,24 @@ class _Emit:
             for a in self.cell_addrs:
                 L.append(f"      zt_abad |= ca{a.i} >= zalo_{j} && ca{a.i} <= zahi_{j};")
             if k in Lp.cell_out and not (k in Lp.cell_flag and Lp.cell_flag[k].kind != "const"):
-                L.append(f"      if (zahi_{j} >= 0) zt_high = zahi_{j} + 1 > zt_high ? zahi_{j} + 1 : zt_high;     // (stored to in every frame)")
+                L.append(f"      if (zahi_{j} >= 0) zph{Lp.id} = zahi_{j} + 1 > zph{Lp.id} ? zahi_{j} + 1 : zph{Lp.id};     // (stored to in every frame)")
         L.append("      if (zt_abad) {")
         self.emit_leave("        ", "pos")
         L.append("      }")
+        L.append("      }")
+        L.append(f"      zt_high = zph{Lp.id} > zt_high ? zph{Lp.id} : zt_high;")
         L.append("    }")
+
+    def pass_keys(self, Lp: LoopInfo) -> List[str]:
+        return [k for k in Lp.cells if (k in Lp.cin and Lp.cin[k].i in self.live_ids()) or k in Lp.cell_out]
+
+    def cell_ld(self, Lp: LoopInfo, key: str, A: str) -> str:
+        """A per-trip cell's value before the chunk: from LDS when the block staged the loop's cells, else from the arena."""
+        mem = f"({A} < mcap ? memp[{A} * mse] : 0.0)"
+        if (Lp.id, key) not in self.cell_slot:
+            return mem
+        j = self.cell_slot[(Lp.id, key)]
+        return f"(zlds{Lp.id} ? zt_cells[zlo{Lp.id} + {j} * zln{Lp.id} + (int)zk{Lp.id}] : {mem})"
 
     def live_ids(self):
         if not hasattr(self, "_live"):
@@ -2160,6 +2287,7 @@ class _Emit:
         self.finals += [(f"spl{ch}", p.spl_out[ch]) for ch in range(p.nch) if f"spl{ch}" not in p.outs]
         self.pending: List[tuple] = []
         self.emit_region(p.top, "    ")
+        L.append("    ZT_STAMP(2)")
         if self.has_abort:
             self.emit_abort_block()
         if self.has_streams:
@@ -2199,10 +2327,19 @@ class _Emit:
         L.append("    }")
         if p.uses_rand:
             L.append(f"    zt_mt_retire(zt_mt, zt_pos0, (int){cname[RNG_INDEX]}, lane);")
+        L.append("    ZT_STAMP(5)")
         L.append("    }")
         self.in_loop = False
         if p.uses_rand:
             L.append(f"    zt_mt_end(zt_mt, zt_pos0, (int){cname[RNG_INDEX]}, zt_gmt, b.mt_se, b.mti + inst, lane);")
+        if self.cell_loops:
+            L.append("    __syncthreads();")
+            for Lp in self.cell_loops:
+                stored = [(self.cell_slot[(Lp.id, k)], k) for k in self.pass_keys(Lp) if k in Lp.cell_out]
+                L.append(f"    if (zlds{Lp.id}) {{   // the block's cells go back to the arena")
+                for j, k in stored:
+                    L.append(f"      for (int k = lane; k < zln{Lp.id}; k += 64) memp[(zla{Lp.id}[{j}] + (int64_t)k * zls{Lp.id}[{j}]) * mse] = zt_cells[zlo{Lp.id} + {j} * zln{Lp.id} + k];")
+                L.append("    }")
         if p.has_block and (self.has_mem or True):
             L.append("    __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"workgroup\");     // the block's values are in vars[] / mem[] before @block reads them")
             L.append("    __builtin_amdgcn_wave_barrier();")
@@ -2444,13 +2581,17 @@ class _Emit:
                 sites_open = True
                 continue
             if kind == "loop":
+                if top:
+                    L.append(f"{ind}ZT_STAMP(2)")
                 self.emit_loop(it[1], ind)
+                if top:
+                    L.append(f"{ind}ZT_STAMP({8 + (it[1].loop.id // 2) % 48})")
             elif kind == "par" and it[1].kind == "ld":
                 self.emit_load(it[1], ind)
             elif kind == "par" and it[1].kind == "lcin":
                 n = it[1]
                 A = f"la{reg.loop.cells[n.name].i}"
-                L.append(f"{ind}const double n{n.i} = ZT_UNI({A} < mcap ? memp[{A} * mse] : 0.0);     // a cell this loop only reads")
+                L.append(f"{ind}const double n{n.i} = ZT_UNI({self.cell_ld(reg.loop, n.name, A)});     // a cell this loop only reads")
             elif kind == "par":
                 n = it[1]
                 e = _expr(n.op, [ref(x) for x in n.args])
@@ -2467,7 +2608,7 @@ class _Emit:
                         if a is n:
                             L.append(f"{ind}const int64_t la{n.i} = (int64_t)n{n.i};")
                             if key in reg.st:
-                                L.append(f"{ind}const double lc{reg.loop.cin[key].i} = ZT_UNI(memp[la{n.i} * mse]);")
+                                L.append(f"{ind}const double lc{reg.loop.cin[key].i} = ZT_UNI({self.cell_ld(reg.loop, key, 'la%d' % n.i)});")
                             break
             elif kind == "shift":
                 name = it[1]
@@ -2477,12 +2618,20 @@ class _Emit:
             elif kind == "serial":
                 names = [nm for c in it[1] for nm in c.names]
                 L.append(f"{ind}// serial recurrences sharing one loop: {', '.join(names)}")
+                if top:
+                    L.append(f"{ind}ZT_STAMP(2)")
                 self.serial_loop(reg, it[1], ind)
+                if top:
+                    L.append(f"{ind}ZT_STAMP(3)")
                 for nm in names:
                     s = reg.st[nm].i
                     L.append(f"{ind}const double n{s} = k{s};")
             elif kind == "spec":
+                if top:
+                    L.append(f"{ind}ZT_STAMP(2)")
                 self.emit_spec(reg, it[1], gid, ind)
+                if top:
+                    L.append(f"{ind}ZT_STAMP(4)")
             else:
                 raise AssertionError(kind)
             if top:
@@ -2739,6 +2888,7 @@ class _Emit:
                 L.append(f"{ind2}const double t{n.i} = {_expr(n.op, [self.ref(x) for x in n.args])};")
         # ring offsets as integers (one v_readlane per trip instead of two and a conversion)
         ring_int = {}
+        self.sctx = (Lp, "vec")
         for m in per_hot + [c_ for c_ in cold if c_ not in per_hot]:
             if m.i in self.ring_lds:
                 u = self.ring_u[m.i]
@@ -2746,10 +2896,35 @@ class _Emit:
                 expr = self.ring_lds[m.i].replace('{U%d}' % m.i, self.ref(u))
                 expr = expr.replace("lane + ", "")       # (the frame's lane is added per trip)
                 L.append(f"{ind2}const int to{m.i} = {expr};")
-        self.sctx = (Lp, "trip")
         L.append(f"{ind2}const int zm = (int)(zc{Lp.id} - zs0 < 64 ? zc{Lp.id} - zs0 : 64);")
-        L.append("#pragma unroll 4")
-        L.append(f"{ind2}for (int zj = 0; zj < zm; ++zj) {{")
+        L.append(f"{ind2}int zj = 0;")
+        lv = [v for v in carried if v not in dead and not Lp.phis[v].uniform and Lp.next[v] is not Lp.phis[v]]
+        G = int(os.environ.get("ZA_TPAR_STRIP_GROUP", "8"))
+        if G > 1 and not any(n.kind == "ld" and n.i not in self.ring_lds for n in per_hot):
+            # groups of G trips: every fetch of the group (lane reads, LDS reads) before its arithmetic, so that their latencies
+            # overlap instead of adding up trip by trip
+            L.append(f"{ind2}for (; zj + {G} <= zm; zj += {G}) {{")
+            for u in range(G):
+                self.sctx = (Lp, ("g", u))
+                for n in exports_hot:
+                    L.append(f"{ind3}const double e{n.i}_{u} = zt_readlane(t{n.i}, zj + {u});")
+                for n in per_hot:
+                    if n.kind == "ld":
+                        lane_term = "lane + " if "lane + " in self.ring_lds[n.i] else ""
+                        L.append(f"{ind3}const double n{n.i}_{u} = zt_ring[{lane_term}__builtin_amdgcn_readlane({ring_int[n.i]}, zj + {u})];")
+            for u in range(G):
+                self.sctx = (Lp, ("g", u))
+                for n in per_hot:
+                    if n.kind != "ld":
+                        L.append(f"{ind3}const double n{n.i}_{u} = {_expr(n.op, [self.ref(x) for x in n.args])};")
+            self.sctx = (Lp, ("g", G - 1))
+            for v in lv:
+                L.append(f"{ind3}const double q{self.phi_name[Lp.phis[v].i]} = {self.ref(Lp.next[v])};")
+            for v in lv:
+                L.append(f"{ind3}{self.phi_name[Lp.phis[v].i]} = q{self.phi_name[Lp.phis[v].i]};")
+            L.append(f"{ind2}}}")
+        self.sctx = (Lp, "trip")
+        L.append(f"{ind2}for (; zj < zm; ++zj) {{")
         for n in exports_hot:
             L.append(f"{ind3}const double e{n.i} = zt_readlane(t{n.i}, zj);")
 
@@ -2766,7 +2941,6 @@ class _Emit:
                 self.load_checks(n, f"B{n.i}", ind3, forward=False)
             else:
                 L.append(f"{ind3}const double n{n.i} = {_expr(n.op, [self.ref(x) for x in n.args])};")
-        lv = [v for v in carried if v not in dead and not Lp.phis[v].uniform and Lp.next[v] is not Lp.phis[v]]
         tmp = [v for v in lv if Lp.next[v].kind == "phi"]
         for v in tmp:
             L.append(f"{ind3}const double q{self.phi_name[Lp.phis[v].i]} = {self.ref(Lp.next[v])};")
@@ -2892,7 +3066,11 @@ class _Emit:
         self.emit_region(reg, ind + "  ")
         for key, o in Lp.cell_out.items():
             A = f"la{Lp.cells[key].i}"
-            L.append(f"{ind}  if (lane == last) memp[{A} * mse] = {ref(o)};     // {key}: the cell after the chunk's last frame")
+            if (Lp.id, key) in self.cell_slot:
+                j = self.cell_slot[(Lp.id, key)]
+                L.append(f"{ind}  if (lane == last) {{ if (zlds{Lp.id}) zt_cells[zlo{Lp.id} + {j} * zln{Lp.id} + (int)zk{Lp.id}] = {ref(o)}; else memp[{A} * mse] = {ref(o)}; }}     // {key}: the cell after the chunk's last frame")
+            else:
+                L.append(f"{ind}  if (lane == last) memp[{A} * mse] = {ref(o)};     // {key}: the cell after the chunk's last frame")
             fl = Lp.cell_flag.get(key)
             if fl is not None and fl.kind != "const":
                 test = f"za_truthy({ref(fl)})" if fl.uniform else f"__ballot(valid && za_truthy({ref(fl)}))"
