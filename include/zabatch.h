@@ -147,6 +147,10 @@ typedef struct zab_host_state {
    * (bit 0: sliders changed, @slider runs at the next zab_process; upload: null leaves it alone). */
   int64_t* mem_high;
   uint32_t* flags;
+  /* slider masks the script raised in launches so far that zab_consume_slider_changes has not handed to the host yet (the
+   * reference collects them per processBlock, consumeDspSliderChanges src/JSFXJuceProcessor.cpp:3745; a checkpoint taken
+   * between a launch and the host's next look must carry them). upload: null leaves the word alone. */
+  uint64_t* slider_changes;
 } zab_host_state;
 /* zab_state_upload replaces the instance's whole image: arena cells above the uploaded prefix that an earlier run had stored
  * to are zeroed (the host image holds nothing there), the high-water mark becomes *mem_high (or mem_n). */

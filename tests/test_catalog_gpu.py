@@ -430,3 +430,31 @@ def test_script_originated_slider_changes_reach_the_host_mirror():
     assert np.allclose(v[:, names.index("g")], 0.45, atol=1e-12)
     assert (sl[:, 0] == 4.5).all() and (host[:, 0] == 4.5).all()
     assert (sl[:, 1] == 3.0).all() and (v[:, names.index("seen2")] == 3.0).all()   # the unannounced 6.3 was pushed over
+
+
+@pytest.mark.parametrize("path", ["fast", "generic"])
+def test_unconsumed_slider_changes_survive_a_checkpoint(path):
+    """the OR of the slider masks a script raised since the host last looked lives in its own word; a checkpoint
+    taken between the launch that raised one and the host's next zab_consume_slider_changes must carry it (on both kernels:
+    the time-parallel kernel runs @block / @slider itself and collects the masks the same way)."""
+    import zabatch
+    from zajit import noise
+    if not zabatch.module_path("fx_slidewrite").exists():
+        pytest.skip("fx_slidewrite not built")
+    sel = zabatch.ZAB_PATH_FAST if path == "fast" else zabatch.ZAB_PATH_GENERIC
+    n, block = 3, 64
+    x = noise.white_noise(range(n), block * 4)
+    with zabatch.Engine("fx_slidewrite", n, max_block=block, path=sel) as e:
+        e.set_sliders(zabatch.leaf_meta("fx_slidewrite")["default_sliders"]); e.prepare()
+        e.consume_slider_changes()
+        e.process_host(x, block=block)                       # block 3 of the launch raises slider 1's mask
+        ck = e.checkpoint()
+        assert (ck["changes"] == 1).all(), ck["changes"]
+        masks, rows = e.consume_slider_changes()
+        assert (masks == 1).all() and (rows[:, 0] == 4.5).all()
+        assert (e.consume_slider_changes()[0] == 0).all()
+    with zabatch.Engine("fx_slidewrite", n, max_block=block, path=sel) as e2:
+        e2.set_sliders(zabatch.leaf_meta("fx_slidewrite")["default_sliders"]); e2.prepare()
+        e2.restore(ck)
+        masks, rows = e2.consume_slider_changes()
+        assert (masks == 1).all() and (rows[:, 0] == 4.5).all()

@@ -826,8 +826,8 @@ static hipError_t ddt_wide_launch(const ZabBatch* b, const ZabAudio* a, hipStrea
   ddt_geometry(b, W, nw);
   if (W == 0) return hipErrorInvalidValue;
   const size_t lds = ddt_lds_bytes(W < 0 ? -W : W, nw, W < 0);
-  static std::once_flag once;
-  std::call_once(once, [] {
+  static ZaPerDevice once;               // (function attributes are per device: a group runs one engine per GPU)
+  once.once([] {
     const int cap = 160 * 1024 - 512;
     (void)hipFuncSetAttribute((const void*)zab_ddt_wide, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     (void)hipFuncSetAttribute((const void*)zab_ddt_wide_nw2, hipFuncAttributeMaxDynamicSharedMemorySize, cap);

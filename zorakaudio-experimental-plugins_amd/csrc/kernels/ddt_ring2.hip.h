@@ -805,8 +805,8 @@ static hipError_t za_launch_fast(const ZabBatch* b, const ZabAudio* a, hipStream
   if (d2_wanted(a->frames)) d2_geometry(b, a->frames, W, nw, nh);
   if (W == 0) return ddt_wide_launch(b, a, st);
   const size_t lds = d2_lds_bytes(W, nw);
-  static std::once_flag once;
-  std::call_once(once, [] {
+  static ZaPerDevice once;               // (function attributes are per device: a group runs one engine per GPU)
+  once.once([] {
     const int cap = 160 * 1024 - 512;
     (void)hipFuncSetAttribute((const void*)zab_ddt_fast, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     (void)hipFuncSetAttribute((const void*)zab_ddt_fast_nw2, hipFuncAttributeMaxDynamicSharedMemorySize, cap);

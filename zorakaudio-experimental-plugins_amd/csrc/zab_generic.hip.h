@@ -374,8 +374,8 @@ static hipError_t za_launch_slider(const ZabBatch* b, hipStream_t st) {
 }
 static hipError_t za_launch_prepare(const ZabBatch* b, hipStream_t st) {
 #if ZA_USES_FFT
-  static std::once_flag za_fft_once;
-  std::call_once(za_fft_once, [st] { hipLaunchKernelGGL(za_fft_table_kernel, dim3(ZA_FFT_MAX / 2 / 256), dim3(256), 0, st); });
+  static ZaPerDevice za_fft_once;        // (the twiddle / permutation tables are __device__ globals: one copy per GPU)
+  za_fft_once.once([st] { hipLaunchKernelGGL(za_fft_table_kernel, dim3(ZA_FFT_MAX / 2 / 256), dim3(256), 0, st); });
 #endif
   hipLaunchKernelGGL(ZA_KERNEL(prepare), dim3((b->n_inst + b->ipw - 1) / b->ipw), dim3(64), 0, st, *b);
   return hipGetLastError();
@@ -389,11 +389,17 @@ static hipError_t za_launch_process(const ZabBatch* b, const ZabAudio* a, hipStr
   lds += (size_t)ZA_NCH * (size_t)b->ipw * (ZA_TT + 1) * sizeof(float);      // the audio tile (za_process_body)
 #endif
 #if ZA_USES_LMEM
-  static size_t za_lds_allowed = 0;                 // dynamic LDS beyond the default limit has to be asked for once
-  if (lds > za_lds_allowed) {
-    const hipError_t e = hipFuncSetAttribute((const void*)ZA_KERNEL(process), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    za_lds_allowed = lds;
+  static size_t za_lds_allowed[256];                // dynamic LDS beyond the default limit has to be asked for, per device
+  static std::mutex za_lds_mu;
+  {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> g(za_lds_mu);
+    if (lds > za_lds_allowed[dev & 255]) {
+      const hipError_t e = hipFuncSetAttribute((const void*)ZA_KERNEL(process), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      za_lds_allowed[dev & 255] = lds;
+    }
   }
 #endif
   hipLaunchKernelGGL(ZA_KERNEL(process), dim3((b->n_inst + b->ipw - 1) / b->ipw), dim3(64), lds, st, *b, *a);

@@ -6,6 +6,23 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
+// One-time initialisations of a module are per DEVICE, not per process: __device__ tables and function attributes belong to the
+// device that was current when they were set, and one process may hold engines on several GPUs (zab_group_*). Runs f() the
+// first time it is reached with a given device current.
+struct ZaPerDevice {
+  std::mutex mu;
+  uint64_t done[4] = {0, 0, 0, 0};
+  template <class F> void once(F&& f) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> g(mu);
+    uint64_t& w = done[(dev >> 6) & 3];
+    if (!((w >> (dev & 63)) & 1ull)) { f(); w |= 1ull << (dev & 63); }
+  }
+};
+
 #define ZAB_MODULE_ABI 14
 
 enum { ZAB_FLAG_SLIDER_DIRTY = 1u, ZAB_FLAG_PREPARED = 2u };

@@ -1021,6 +1021,7 @@ int zab_state_upload(zab_engine* e, int32_t inst, const zab_host_state* h) {
     HIP_TRY(hipStreamSynchronize(e->stream));
     if (f & ZAB_FLAG_SLIDER_DIRTY) e->sliders_dirty = true;
   }
+  if (h->slider_changes) HIP_TRY(hipMemcpyAsync(b.pend + 3 * (int64_t)b.n_pad + inst, h->slider_changes, 8, hipMemcpyHostToDevice, e->stream));
   if (h->pending_masks) {
     for (int k = 0; k < 3; ++k) HIP_TRY(hipMemcpyAsync(b.pend + (int64_t)k * b.n_pad + inst, h->pending_masks + k, 8, hipMemcpyHostToDevice, e->stream));
   }
@@ -1048,6 +1049,7 @@ int zab_state_download(zab_engine* e, int32_t inst, zab_host_state* h) {
     const int64_t n = h->mem_n < b.mem_cap ? h->mem_n : b.mem_cap;
     if ((rc = get_strided(e, "mem", b.mem + inst * b.mem_si, b.mem_se, n, h->mem))) return rc;
   }
+  if (h->slider_changes) HIP_TRY(hipMemcpy(h->slider_changes, b.pend + 3 * (int64_t)b.n_pad + inst, 8, hipMemcpyDeviceToHost));
   if (h->pending_masks) {
     for (int k = 0; k < 3; ++k) HIP_TRY(hipMemcpy(h->pending_masks + k, b.pend + (int64_t)k * b.n_pad + inst, 8, hipMemcpyDeviceToHost));
   }
@@ -1245,10 +1247,12 @@ int zab_group_reduce(zab_group* g, const double* shard_values, zab_group_stats* 
   out->n_shards = (int32_t)n;
   if (group_rccl(g)) {
     // {max: kernel ms, caller value} and {sum: kernel ms, units}: two all-reduces per shard on its own stream, grouped
+    std::vector<double> hs(4 * n);            // (outlives the asynchronous copies: they are joined below, before it goes)
     for (size_t k = 0; k < n; ++k) {
-      const double h[4] = {ms[k], shard_values ? shard_values[k] : 0.0, ms[k], units[k]};
+      double* h = &hs[4 * k];
+      h[0] = ms[k]; h[1] = shard_values ? shard_values[k] : 0.0; h[2] = ms[k]; h[3] = units[k];
       HIP_TRY(hipSetDevice(g->device[k]));
-      HIP_TRY(hipMemcpyAsync(g->d_stat[k], h, sizeof h, hipMemcpyHostToDevice, g->eng[k]->stream));
+      HIP_TRY(hipMemcpyAsync(g->d_stat[k], h, 4 * sizeof(double), hipMemcpyHostToDevice, g->eng[k]->stream));
     }
     if (g->p_gstart() != ncclSuccess) return fail(ZAB_E_HIP, "ncclGroupStart failed");
     for (size_t k = 0; k < n; ++k) {

@@ -37,7 +37,7 @@ class zab_host_state(C.Structure):      # include/zabatch.h
                 ("mem", C.POINTER(C.c_double)), ("mem_n", C.c_int64), ("pending_masks", C.POINTER(C.c_int64)),
                 ("rand_mt", C.POINTER(C.c_uint32)), ("rand_index", C.POINTER(C.c_uint32)),
                 ("slider_visible_mask", C.POINTER(C.c_int64)), ("slider_visibility_init", C.POINTER(C.c_int32)),
-                ("mem_high", C.POINTER(C.c_int64)), ("flags", C.POINTER(C.c_uint32))]
+                ("mem_high", C.POINTER(C.c_int64)), ("flags", C.POINTER(C.c_uint32)), ("slider_changes", C.POINTER(C.c_uint64))]
 
 
 class zab_group_stats(C.Structure):
@@ -404,6 +404,8 @@ class Engine:
         h.slider_visibility_init = arrs["visi"].ctypes.data_as(P(C.c_int32))
         h.mem_high = arrs["high"].ctypes.data_as(P(C.c_int64))
         h.flags = arrs["flags"].ctypes.data_as(P(C.c_uint32))
+        if "changes" in arrs:
+            h.slider_changes = arrs["changes"].ctypes.data_as(P(C.c_uint64))
         return h
 
     def checkpoint(self) -> dict:
@@ -416,10 +418,11 @@ class Engine:
         out = {"leaf": np.array(self.leaf), "srate": np.array(self.srate), "spl": np.zeros((n, 64)), "sliders": np.zeros((n, 64)),
                "vars": np.zeros((n, nv)), "masks": np.zeros((n, 3), np.int64), "mt": np.zeros((n, 624), np.uint32),
                "mti": np.zeros(n, np.uint32), "vis": np.zeros(n, np.int64), "visi": np.zeros(n, np.int32),
-               "mem_high": high.astype(np.int64), "flags": np.zeros(n, np.uint32), "mem_cap": np.array(self.mem_cap, np.int64)}
+               "mem_high": high.astype(np.int64), "flags": np.zeros(n, np.uint32), "mem_cap": np.array(self.mem_cap, np.int64),
+               "changes": np.zeros(n, np.uint64)}      # (slider masks raised but not yet consumed by the host)
         mems = []
         for i in range(n):
-            a = {k: out[k][i:i + 1].reshape(-1) if out[k].ndim > 1 else out[k][i:i + 1] for k in ("spl", "sliders", "vars", "masks", "mt", "mti", "vis", "visi", "flags")}
+            a = {k: out[k][i:i + 1].reshape(-1) if out[k].ndim > 1 else out[k][i:i + 1] for k in ("spl", "sliders", "vars", "masks", "mt", "mti", "vis", "visi", "flags", "changes")}
             a["high"] = out["mem_high"][i:i + 1]
             a["mem"] = np.zeros(int(min(high[i], self.mem_cap)))
             h = self._host_state(a)
@@ -445,6 +448,7 @@ class Engine:
             a = {k: np.ascontiguousarray(ck[k][i:i + 1].reshape(-1) if ck[k].ndim > 1 else ck[k][i:i + 1]) for k in ("spl", "sliders", "vars", "masks", "mt", "mti", "vis", "visi")}
             a["high"] = np.ascontiguousarray(ck["mem_high"][i:i + 1], dtype=np.int64)
             a["flags"] = np.ascontiguousarray(flags[i:i + 1], dtype=np.uint32)
+            a["changes"] = np.ascontiguousarray(ck["changes"][i:i + 1] if "changes" in ck else np.zeros(1), dtype=np.uint64)
             a["mem"] = np.ascontiguousarray(ck["mem_data"][off[i]:off[i + 1]])
             h = self._host_state(a)
             self._chk(self.L.zab_state_upload(self.h, i, C.byref(h)))
