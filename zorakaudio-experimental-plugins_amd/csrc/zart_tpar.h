@@ -110,6 +110,19 @@ __device__ __forceinline__ bool zt_small_int(double x) { return x == floor(x) &&
 #define ZT_RING_DOUBLES 3072
 #endif
 
+// All address expressions of a loop against each other (zs: [5][n] = first address, stride, previous, lowest, highest; bit j of
+// `stored`: expression j is stored to): one pair per lane and pass, not inlined -- with 26 expressions (CMD) the 325 inline pair
+// tests, each with a 64-bit remainder, were most of the kernel's code.
+static __device__ __attribute__((noinline)) bool zt_sites_all_ok(const long long* zs, int n, unsigned long long stored, int lane) {
+  bool bad = false;
+  for (int q = lane; q < n * n; q += 64) {
+    const int j = q / n, k = q - j * n;
+    if (k <= j || !(((stored >> j) | (stored >> k)) & 1ull)) continue;
+    bad |= !zt_sites_ok(zs[j], zs[n + j], zs[3 * n + j], zs[4 * n + j], zs[k], zs[n + k], zs[3 * n + k], zs[4 * n + k]);
+  }
+  return __ballot(bad) == 0ull;
+}
+
 // value of the previous lane; lane 0 receives `first` (the value carried in from the previous chunk)
 __device__ __forceinline__ double zt_shift1(double v, double first) { return zt_dpp<ZT_WAVE_SHR1, 0xF>(v, first); }
 

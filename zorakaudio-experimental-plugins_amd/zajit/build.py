@@ -53,6 +53,7 @@ NO_TPAR: Dict[str, str] = {
     # state in registers from block to block (256 instances x 48 000 frames: 1124 ms against 1570 ms here)
     "3DPannerManager": "@sample is empty: nothing to run time-parallel",
 }
+LONG_BRANCH_LIMIT = 32
 # leaves whose state the hand-written kernel wants contiguous per instance
 INSTANCE_MAJOR = {"DDT"}
 
@@ -124,6 +125,25 @@ def tpar_plan(unit: codegen.Unit):
     if unit.prog.name in NO_TPAR:
         return None, NO_TPAR[unit.prog.name]
     return tpar.try_plan(unit.prog, int(unit.defines["ZA_NCH"]))
+
+
+def long_branches(so: Path, kernel: str) -> int:
+    """Long-branch expansions (s_getpc / s_setpc through a scratch register pair) inside one kernel of a built module. A branch
+    needs them when its target is more than 2^17 bytes away, i.e. in very large kernels. CMD's time-parallel kernel, while its
+    address pass wrote out 325 pair tests inline (90 000 instructions, 490 expansions, 12 000 scalar-register spills), faulted
+    on the device with an access beyond the largest legal address -- same source text as the 8 000-instruction form that runs;
+    TSEQ's runs with 4 - 17 of them and passes every parity test. Kernels with more than LONG_BRANCH_LIMIT are not trusted: the
+    leaf is rebuilt without its time-parallel kernel (build_module) and says so in its metadata."""
+    import re
+    import tempfile
+    llvm = Path("/opt/rocm/lib/llvm/bin")
+    with tempfile.TemporaryDirectory() as d:
+        fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "dev.co")
+        subprocess.run([str(llvm / "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", str(so), fat], check=True)
+        subprocess.run([str(llvm / "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={fat}", f"--output={co}",
+                        f"--targets=hipv4-amdgcn-amd-amdhsa--{ARCH}"], check=True, capture_output=True)
+        dis = subprocess.run([str(llvm / "llvm-objdump"), "-d", f"--disassemble-symbols={kernel}", co], capture_output=True, text=True).stdout
+    return sum(1 for m in re.finditer(r"s_setpc_b64 s\[(\d+):", dis) if m.group(1) != "30")
 
 
 def module_source(unit: codegen.Unit) -> str:
@@ -215,12 +235,24 @@ def build_module(jsfx_path, name: Optional[str] = None, force=False, verbose=Fal
             deps.append(CSRC / extra)
     stale = (force or not so.exists() or not src.exists() or src.read_text() != text
              or any(so.stat().st_mtime < d.stat().st_mtime for d in deps))
+    lb_note = LIB / f"{prog.name}.longbranch"
     if stale:
         src.write_text(text)
         t0 = time.time()
         _run([HIPCC] + HIP_FLAGS + leaf_flags + ["-I", str(CSRC), "-o", str(so), str(src)])
         if verbose:
             print(f"  hipcc {prog.name}: {time.time() - t0:.1f}s")
+        lb_note.unlink(missing_ok=True)
+        if "ZA_FAST_KERNEL_NAME \"zab_" in text and "_tpar\"" in text and prog.name not in NO_TPAR:
+            nlb = long_branches(so, f"zab_{_cid(prog.name)}_tpar")
+            if nlb > LONG_BRANCH_LIMIT:          # see long_branches(): the generic kernel stays the leaf's only one
+                lb_note.write_text(str(nlb))
+    if lb_note.exists() and not os.environ.get("ZA_TPAR_ALLOW_LONG_BRANCHES"):
+        NO_TPAR[prog.name] = f"the device compiler needed {lb_note.read_text()} long-branch expansions in the time-parallel kernel (not trusted)"
+        text = module_source(unit)
+        if src.read_text() != text:
+            src.write_text(text)
+            _run([HIPCC] + HIP_FLAGS + leaf_flags + ["-I", str(CSRC), "-o", str(so), str(src)])
     meta = unit.meta()
     meta["sliders"] = {str(i): {"default": d.default, "min": d.vmin, "max": d.vmax, "step": d.step,
                                 "is_choice": d.is_choice, "is_string": d.is_string, "var": d.var_name, "label": d.label}

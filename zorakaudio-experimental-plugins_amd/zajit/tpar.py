@@ -1863,6 +1863,8 @@ class _Emit:
             L.append("#define ZT_STAMP(k) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) atomicAdd(&zt_stamps[k], t_ - zt_t0); zt_t0 = __builtin_amdgcn_s_memtime(); }")
         else:
             L.append("#define ZT_STAMP(k)")
+        if self.has_serial:
+            self.emit_serial_fn()
         L.append(f'extern "C" __global__ void __launch_bounds__(64) {km}(ZabBatch b, ZabAudio a) {{')
         if self.has_serial:
             L.append("  ZA_KERNEL_ENTRY();")
@@ -1937,9 +1939,20 @@ class _Emit:
             for j, k in enumerate(keys):
                 self.cell_slot[(Lp.id, k)] = j
             L.append(f"  int zln{Lp.id} = 0, zlo{Lp.id} = 0; bool zlds{Lp.id} = false;     // loop {Lp.id}: trips, its place in zt_cells, staged or not")
-            L.append(f"  int64_t zla{Lp.id}[{len(keys)}], zls{Lp.id}[{len(keys)}];")
         L.append(f"  const int64_t blk = {'a.block > 0 ? (int64_t)a.block : frames' if p.has_block else 'frames'};   // a script without @block sees one block per launch")
         self.pass_memo: Dict[int, tuple] = {}
+        self.memo_off: Dict[int, int] = {}
+        self.site_off: Dict[int, int] = {}
+        tot_m = tot_s = 0
+        for Lp in self.lcell_loops:                  # (sizes are needed before the passes are written: count their inputs first)
+            self.memo_off[Lp.id] = tot_m
+            tot_m += self.pass_inputs(Lp)
+            self.site_off[Lp.id] = tot_s
+            tot_s += 5 * len(self.pass_keys(Lp))
+        if tot_m:
+            L.append(f"  __shared__ unsigned long long zt_memo[{tot_m}];     // what the address passes read last time (bit patterns)")
+        if tot_s:
+            L.append(f"  __shared__ long long zt_site[{tot_s}];     // per address expression of a loop with per-trip cells: a0, stride, previous, lo, hi")
         memo_at = len(L)
         L.append("  for (int64_t pos = 0; pos < frames; pos += blk) {")
         L.append("    const int64_t bn = frames - pos < blk ? frames - pos : blk;")
@@ -1955,8 +1968,6 @@ class _Emit:
         decl = []
         for lid, (memo, xs) in self.pass_memo.items():
             decl.append(f"  bool zpv{lid} = false; int64_t zph{lid} = 0;     // address pass of loop {lid}: done for these inputs, high-water mark it found")
-            if memo and xs:
-                decl.append("  uint64_t " + ", ".join(f"zpi{lid}_{k} = 0" for k in range(len(xs))) + ";")
         L[memo_at:memo_at] = decl
         if self.has_serial:
             L.append("  if (lane == 0 && zt_pend_seen) b.pend[3 * (int64_t)b.n_pad + inst] |= zt_pend_seen;")
@@ -1975,68 +1986,84 @@ class _Emit:
         return "\n".join(L) + "\n"
 
     # -- between the blocks: @block and the pending-mask @slider, run by the wavefront with the leaf's section code -----------------
-    def emit_serial_phase(self):
+    def emit_serial_fn(self):
+        """`zt_serial`: what jsfx_process_block does before a block's frames (dsp_jsfx_aot.py:5766-5804) -- samplesblock, @block,
+        @slider if a mask is pending -- as a function of its own, called by the kernel between the blocks. The state is in vars[] /
+        mem[] there (every block ends with its values stored), so the section code runs on it as in the generic kernel: on lane 0,
+        or -- leaves with cooperative builtins -- on all 64 lanes as replicas of the instance. Only what @block (and @slider, where
+        the script can raise a mask) names is loaded, only what they assign is stored: a script's few hundred variables need not
+        all be live across its @block. Not inlined: the section code keeps its own registers and stack frame instead of sharing
+        the kernel's allocation (CMD's @block inside the kernel body put it at 512 registers plus scratch, where the device compiler
+        has produced wrong code before: DESIGN.md "compiler hazard")."""
         p, L = self.plan, self.L
-        L.append("    // jsfx_process_block's block prologue (dsp_jsfx_aot.py:5766-5804): samplesblock, @block, @slider if a mask is pending.")
-        L.append("    // The state is in vars[] / mem[] here (every block ends with its values stored), so the section code runs on it as in")
-        L.append("    // the generic kernel: on lane 0, or -- leaves with cooperative builtins -- on all 64 lanes as replicas of the instance.")
-        if p.has_block:
-            L.append("    {")
-        else:
-            L.append("    if (pos == 0 && (b.pend[inst] | b.pend[b.n_pad + inst] | b.pend[2 * (int64_t)b.n_pad + inst]) != 0ull) {")
-        L.append("#ifdef ZA_REPLICAS")
-        L.append("      const bool zt_run = true;")
-        L.append("#else")
-        L.append("      const bool zt_run = lane == 0;")
-        L.append("#endif")
-        # Only what @block (and @slider, where the script can raise a mask) names is loaded, only what they assign is stored: the
-        # rest of the state stays where it is -- a script's few hundred variables need not all be live across its @block.
         prog = self.prog
         secs = list(prog.sections.get("block", [])) if p.has_block else []
         if p.has_pending:
             secs += list(prog.sections.get("slider", []))
         rd = sorted(prog.vars[nm] for nm in _read_names(prog, secs) if nm in prog.vars)
         wr = sorted(prog.vars[nm] for nm in _assigned_names(prog, secs) if nm in prog.vars)
-        L.append("      if (zt_run) {")
-        L.append("        ZaS s;")
-        L.append("        za_state_bind(s, b, (int)inst);")
+        if os.environ.get("ZA_TPAR_FULL_STATE"):
+            rd = wr = list(range(prog.nvars))
+        L.append("// between the blocks: @block and the pending-mask @slider, run by the wavefront with the leaf's section code")
+        L.append("static __device__ __attribute__((noinline)) unsigned long long zt_serial(const ZabBatch* __restrict__ zt_pb, const int64_t inst, const int64_t bn, const int lane) {")
+        L.append("  const ZabBatch& b = *zt_pb;")
+        L.append("  unsigned long long seen = 0;")
+        L.append("#ifdef ZA_REPLICAS")
+        L.append("  const bool zt_run = true;")
+        L.append("#else")
+        L.append("  const bool zt_run = lane == 0;")
+        L.append("#endif")
+        L.append("  if (zt_run) {")
+        L.append("    ZaS s;")
+        L.append("    za_state_bind(s, b, (int)inst);")
         for k0 in range(0, len(rd), 8):
-            L.append("        " + " ".join(f"s.v[{k}] = b.vars[{k} * b.var_se + inst * b.var_si];" for k in rd[k0:k0 + 8]))
+            L.append("    " + " ".join(f"s.v[{k}] = b.vars[{k} * b.var_se + inst * b.var_si];" for k in rd[k0:k0 + 8]))
         L.append("#define ZA_X(k) s.sl[k] = b.sliders[(k) * b.sl_se + inst * b.sl_si];")
-        L.append("        ZA_FOR_USED_SL(ZA_X)")
+        L.append("    ZA_FOR_USED_SL(ZA_X)")
         L.append("#undef ZA_X")
         L.append("#define ZA_X(k) s.spl[k] = b.spl[(k) * b.sl_se + inst * b.sl_si];")
-        L.append("        ZA_FOR_USED_SPL(ZA_X)")
+        L.append("    ZA_FOR_USED_SPL(ZA_X)")
         L.append("#undef ZA_X")
         L.append("#ifdef ZA_REPLICAS")
-        L.append("        s.replica = lane != 0 ? 1u : 0u; s.rep_i = (uint32_t)lane; s.rep_n = 64u; s.rep_stride = 1u;")
+        L.append("    s.replica = lane != 0 ? 1u : 0u; s.rep_i = (uint32_t)lane; s.rep_n = 64u; s.rep_stride = 1u;")
         L.append("#endif")
-        L.append("        s.samplesblock = (double)bn;")
-        L.append("        s.block_size = (int)bn;")
+        L.append("    s.samplesblock = (double)bn;")
+        L.append("    s.block_size = (int)bn;")
         if p.has_block:
             L.append("#if ZA_USES_MSG")
-            L.append("        za_msg_begin_block(s);")
+            L.append("    za_msg_begin_block(s);")
             L.append("#endif")
-            L.append("        za_section_block(s);")
+            L.append("    za_section_block(s);")
         if p.has_pending:
-            L.append("        if (s.pend_change | s.pend_automate | s.pend_automate_end) za_section_slider(s);")
-            L.append("        zt_pend_seen |= s.pend_change | s.pend_automate | s.pend_automate_end;")
-            L.append("        s.pend_change = s.pend_automate = s.pend_automate_end = 0;")
-        L.append("        if (lane == 0) {")
+            L.append("    if (s.pend_change | s.pend_automate | s.pend_automate_end) za_section_slider(s);")
+            L.append("    seen = s.pend_change | s.pend_automate | s.pend_automate_end;")
+            L.append("    s.pend_change = s.pend_automate = s.pend_automate_end = 0;")
+        L.append("    if (lane == 0) {")
         for k0 in range(0, len(wr), 8):
-            L.append("          " + " ".join(f"b.vars[{k} * b.var_se + inst * b.var_si] = s.v[{k}];" for k in wr[k0:k0 + 8]))
+            L.append("      " + " ".join(f"b.vars[{k} * b.var_se + inst * b.var_si] = s.v[{k}];" for k in wr[k0:k0 + 8]))
         L.append("#define ZA_X(k) b.sliders[(k) * b.sl_se + inst * b.sl_si] = s.sl[k];")
-        L.append("          ZA_FOR_USED_SL(ZA_X)")
+        L.append("      ZA_FOR_USED_SL(ZA_X)")
         L.append("#undef ZA_X")
         L.append("#define ZA_X(k) b.spl[(k) * b.sl_se + inst * b.sl_si] = s.spl[k];")
-        L.append("          ZA_FOR_USED_SPL(ZA_X)")
+        L.append("      ZA_FOR_USED_SPL(ZA_X)")
         L.append("#undef ZA_X")
-        L.append("          b.mem_high[inst] = s.mem_high; b.mem_need[inst] = s.mem_need; b.mti[inst] = s.mti; b.err[inst] = s.err;")
-        L.append("          b.pend[inst] = s.pend_change; b.pend[b.n_pad + inst] = s.pend_automate; b.pend[2 * (int64_t)b.n_pad + inst] = s.pend_automate_end;")
-        L.append("          b.vis_mask[inst] = s.vis_mask; b.vis_init[inst] = s.vis_init;")
-        L.append("          if (b.gmem_att) b.gmem_att[inst] = s.gmem_attached;")
-        L.append("        }")
-        L.append("      }")
+        L.append("      b.mem_high[inst] = s.mem_high; b.mem_need[inst] = s.mem_need; b.mti[inst] = s.mti; b.err[inst] = s.err;")
+        L.append("      b.pend[inst] = s.pend_change; b.pend[b.n_pad + inst] = s.pend_automate; b.pend[2 * (int64_t)b.n_pad + inst] = s.pend_automate_end;")
+        L.append("      b.vis_mask[inst] = s.vis_mask; b.vis_init[inst] = s.vis_init;")
+        L.append("      if (b.gmem_att) b.gmem_att[inst] = s.gmem_attached;")
+        L.append("    }")
+        L.append("  }")
+        L.append("  return seen;")
+        L.append("}")
+
+    def emit_serial_phase(self):
+        p, L = self.plan, self.L
+        if p.has_block:
+            L.append("    {")
+        else:
+            L.append("    if (pos == 0 && (b.pend[inst] | b.pend[b.n_pad + inst] | b.pend[2 * (int64_t)b.n_pad + inst]) != 0ull) {")
+        L.append("      // (the ZabBatch the function reads is this kernel's own first argument, where it lies in the kernarg segment)")
+        L.append("      zt_pend_seen |= zt_serial((const ZabBatch*)__builtin_amdgcn_kernarg_segment_ptr(), inst, bn, lane);")
         L.append("      __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"workgroup\");")
         L.append("      __builtin_amdgcn_wave_barrier();")
         L.append("      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"workgroup\");")
@@ -2102,7 +2129,8 @@ class _Emit:
                 nk = len(self.pass_keys(Lp))
                 L.append(f"      zlo{Lp.id} = zoff; zlds{Lp.id} = zln{Lp.id} > 0 && zoff + {nk} * zln{Lp.id} <= ZT_CELL_DOUBLES; if (zlds{Lp.id}) zoff += {nk} * zln{Lp.id};")
                 L.append(f"      if (zlds{Lp.id}) {{")
-                L.append(f"        for (int q = lane; q < {nk} * zln{Lp.id}; q += 64) {{ const int j = q / zln{Lp.id}, k = q - j * zln{Lp.id}; const int64_t A = zla{Lp.id}[j] + (int64_t)k * zls{Lp.id}[j];")
+                so = self.site_off[Lp.id]
+                L.append(f"        for (int q = lane; q < {nk} * zln{Lp.id}; q += 64) {{ const int j = q / zln{Lp.id}, k = q - j * zln{Lp.id}; const int64_t A = zt_site[{so} + j] + (int64_t)k * zt_site[{so + nk} + j];")
                 L.append(f"          zt_cells[zlo{Lp.id} + q] = A < mcap ? memp[A * mse] : 0.0; }}")
                 L.append("      }")
             L.append("      __syncthreads();")
@@ -2126,12 +2154,12 @@ class _Emit:
         for name, h in self.hname.items():
             L.append(f"    double {h} = {self.inv_src(name)};   // {name}: its last written value (frames may leave it alone)")
 
-    def emit_address_pass(self, Lp: LoopInfo):
-        """Before a block's first chunk: walk the trips of a loop with per-trip cells once, addresses only. Every address expression
-        must step evenly through the trips (a[k] = a[0] + k * stride) inside the arena, and two expressions may never name one cell
-        (zt_sites_ok: disjoint ranges, or interleaved records -- same stride, offsets that differ by less than a multiple of it)."""
-        p, L, ref = self.plan, self.L, self.ref
-        reg = p.regions[Lp.id]
+    def pass_inputs(self, Lp: LoopInfo) -> int:
+        return len(self.pass_analysis(Lp)[3])
+
+    def pass_analysis(self, Lp: LoopInfo):
+        """(need, uphis, rloads, outside inputs) of a loop's address pass."""
+        p = self.plan
         keys = self.pass_keys(Lp)
         rloads = [x for grp in p.rings.get(Lp.id, []) for x in grp.loads]
         need: Dict[int, N] = {}
@@ -2149,20 +2177,37 @@ class _Emit:
             if n.kind == "lcin":
                 todo.append(Lp.cells[n.name])
             todo.extend(n.args)
-        # what the pass reads from outside: when none of it has changed since the previous block, neither has the result
         ext: Dict[int, N] = {}
         for n in list(need.values()) + [Lp.init[v] for v in uphis] + ([Lp.count] if Lp.count is not None else []) + list(self.cell_addrs):
             for x in ((n,) if not _in_subtree(n, Lp) else n.args):
                 if not _in_subtree(x, Lp) and x.kind not in ("const", "hold"):
                     ext[x.i] = x
-        memo = not any(n.kind == "lcin" for n in need.values()) and all(x.uniform for x in ext.values())
-        self.pass_memo[Lp.id] = (memo, [ext[i] for i in sorted(ext)])
+        return need, uphis, rloads, [ext[i] for i in sorted(ext)]
+
+    def emit_address_pass(self, Lp: LoopInfo):
+        """Before a block's first chunk: walk the trips of a loop with per-trip cells once, addresses only. Every address expression
+        must step evenly through the trips (a[k] = a[0] + k * stride) inside the arena, and two expressions may never name one cell
+        (zt_sites_ok: disjoint ranges, or interleaved records -- same stride, offsets that differ by less than a multiple of it)."""
+        p, L, ref = self.plan, self.L, self.ref
+        reg = p.regions[Lp.id]
+        keys = self.pass_keys(Lp)
+        need, uphis, rloads, exts = self.pass_analysis(Lp)
+        memo = (not any(n.kind == "lcin" for n in need.values()) and all(x.uniform for x in exts)
+                and not os.environ.get("ZA_TPAR_NO_MEMO"))
+        self.pass_memo[Lp.id] = (memo, exts)
         L.append(f"    {{   // per-trip cells of loop {Lp.id}: addresses step evenly through the trips and never meet; offsets of its ring reads")
+        xs = self.pass_memo[Lp.id][1]
+        mo = self.memo_off[Lp.id]
+        so = self.site_off.get(Lp.id, 0)
+        nk = len(keys)
         if memo:
-            same = " && ".join([f"zpv{Lp.id}"] + [f"__builtin_bit_cast(uint64_t, {ref(x)}) == zpi{Lp.id}_{k}" for k, x in enumerate(self.pass_memo[Lp.id][1])])
-            L.append(f"      if (!({same})) {{")
-            for k, x in enumerate(self.pass_memo[Lp.id][1]):
-                L.append(f"      zpi{Lp.id}_{k} = __builtin_bit_cast(uint64_t, {ref(x)});")
+            L.append(f"      bool zsame = zpv{Lp.id};")
+            for k, x in enumerate(xs):
+                L.append(f"      zsame &= __builtin_bit_cast(unsigned long long, {ref(x)}) == zt_memo[{mo + k}];")
+            L.append("      if (!zsame) {")
+            L.append("      __syncthreads();")
+            for k, x in enumerate(xs):
+                L.append(f"      zt_memo[{mo + k}] = __builtin_bit_cast(unsigned long long, {ref(x)});")
             L.append(f"      zpv{Lp.id} = true; zph{Lp.id} = 0;")
         else:
             L.append(f"      zph{Lp.id} = 0;")
@@ -2174,8 +2219,11 @@ class _Emit:
         L.append("      bool zt_abad = false;")
         for v in uphis:
             L.append(f"      double {self.phi_name[Lp.phis[v].i]} = {ref(Lp.init[v])};")
-        for j, k in enumerate(keys):
-            L.append(f"      int64_t za0_{j} = 0, zas_{j} = 1, zap_{j} = 0, zalo_{j} = 0, zahi_{j} = -1;")
+        # per address expression j: first address, stride, previous, lowest, highest -- in LDS (zt_site), every lane the same values
+        if nk:
+            L.append(f"      long long* const zs = zt_site + {so};      // [5][{nk}]: a0, stride, previous, lo, hi")
+            L.append(f"      for (int j = lane; j < {nk}; j += 64) {{ zs[j] = 0; zs[{nk} + j] = 1; zs[{2 * nk} + j] = 0; zs[{3 * nk} + j] = 0; zs[{4 * nk} + j] = -1; }}")
+            L.append("      __syncthreads();")
         L.append("      int64_t zkn = 0;")
         if Lp.count is not None:
             L.append(f"      const int64_t zt_cnt = za_loopcount(ZT_UNI({ref(Lp.count)}));")
@@ -2198,29 +2246,38 @@ class _Emit:
         for ld, u, sign in rloads:
             L.append(f"        {{ const double o = {'' if sign > 0 else '-'}{ref(u)}; const int oi = (int)o; zrok{Lp.id} &= (double)oi == o && fabs(o) < 1.0e9;")
             L.append(f"          zro_lo{ld.i} = oi < zro_lo{ld.i} ? oi : zro_lo{ld.i}; zro_hi{ld.i} = oi > zro_hi{ld.i} ? oi : zro_hi{ld.i}; }}")
-        for j, k in enumerate(keys):
-            an = ref(Lp.cells[k])
-            L.append(f"        {{ const int64_t A = (int64_t){an};{' zt_abad |= A >= mcap;' if k in Lp.cell_out else ''}")
-            L.append(f"          if (zk == 0) {{ za0_{j} = zalo_{j} = zahi_{j} = A; }} else {{ if (zk == 1) zas_{j} = A - zap_{j}; else zt_abad |= (A - zap_{j}) != zas_{j};")
-            L.append(f"            zalo_{j} = A < zalo_{j} ? A : zalo_{j}; zahi_{j} = A > zahi_{j} ? A : zahi_{j}; }}")
-            L.append(f"          zap_{j} = A; }}")
+        if nk:
+            # lane j follows address expression j (the addresses of a trip are wave-uniform values: every lane has them all)
+            L.append("        {")
+            L.append("          long long A = 0;")
+            for j, k in enumerate(keys):
+                L.append(f"          A = lane == {j} ? (long long)(int){ref(Lp.cells[k])} : A;")
+            stored = sum(1 << j for j, k in enumerate(keys) if k in Lp.cell_out)
+            L.append(f"          if (lane < {nk}) {{")
+            L.append(f"            zt_abad |= ((0x{stored:x}ull >> lane) & 1ull) && A >= mcap;")
+            L.append(f"            if (zk == 0) {{ zs[lane] = A; zs[{3 * nk} + lane] = A; zs[{4 * nk} + lane] = A; }}")
+            L.append(f"            else {{ if (zk == 1) zs[{nk} + lane] = A - zs[{2 * nk} + lane]; else zt_abad |= (A - zs[{2 * nk} + lane]) != zs[{nk} + lane];")
+            L.append(f"              zs[{3 * nk} + lane] = A < zs[{3 * nk} + lane] ? A : zs[{3 * nk} + lane]; zs[{4 * nk} + lane] = A > zs[{4 * nk} + lane] ? A : zs[{4 * nk} + lane]; }}")
+            L.append(f"            zs[{2 * nk} + lane] = A;")
+            L.append("          }")
+            L.append("        }")
         for v in uphis:
             L.append(f"        const double q{self.phi_name[Lp.phis[v].i]} = {ref(Lp.next[v])};")
         for v in uphis:
             L.append(f"        {self.phi_name[Lp.phis[v].i]} = q{self.phi_name[Lp.phis[v].i]};")
         L.append("      }")
+        if nk:
+            L.append("      __syncthreads();")
+            stored = sum(1 << j for j, k in enumerate(keys) if k in Lp.cell_out)
+            always = sum(1 << j for j, k in enumerate(keys) if k in Lp.cell_out and not (k in Lp.cell_flag and Lp.cell_flag[k].kind != "const"))
+            L.append(f"      zt_abad = __ballot(zt_abad) != 0ull;")
+            L.append(f"      zt_abad |= !zt_sites_all_ok(zs, {nk}, 0x{stored:x}ull, lane);")
+            for a in self.cell_addrs:
+                L.append(f"      zt_abad |= __ballot(lane < {nk} && ca{a.i} >= zs[{3 * nk} + lane] && ca{a.i} <= zs[{4 * nk} + lane]) != 0ull;")
+            L.append(f"      {{ const long long h = (lane < {nk} && ((0x{always:x}ull >> lane) & 1ull) && zs[{4 * nk} + lane] >= 0) ? zs[{4 * nk} + lane] + 1 : 0;")
+            L.append(f"        zph{Lp.id} = zt_wave_max_i64(h); }}     // (cells stored to in every frame)")
         if Lp in getattr(self, "cell_loops", []):
             L.append(f"      zln{Lp.id} = (int)zkn;")
-            for j, k in enumerate(keys):
-                L.append(f"      zla{Lp.id}[{j}] = za0_{j}; zls{Lp.id}[{j}] = zas_{j};")
-        for j, k in enumerate(keys):
-            for j2 in range(j + 1, len(keys)):
-                if k in Lp.cell_out or keys[j2] in Lp.cell_out:
-                    L.append(f"      zt_abad |= !zt_sites_ok(za0_{j}, zas_{j}, zalo_{j}, zahi_{j}, za0_{j2}, zas_{j2}, zalo_{j2}, zahi_{j2});")
-            for a in self.cell_addrs:
-                L.append(f"      zt_abad |= ca{a.i} >= zalo_{j} && ca{a.i} <= zahi_{j};")
-            if k in Lp.cell_out and not (k in Lp.cell_flag and Lp.cell_flag[k].kind != "const"):
-                L.append(f"      if (zahi_{j} >= 0) zph{Lp.id} = zahi_{j} + 1 > zph{Lp.id} ? zahi_{j} + 1 : zph{Lp.id};     // (stored to in every frame)")
         L.append("      if (zt_abad) {")
         self.emit_leave("        ", "pos")
         L.append("      }")
@@ -2338,7 +2395,8 @@ class _Emit:
                 stored = [(self.cell_slot[(Lp.id, k)], k) for k in self.pass_keys(Lp) if k in Lp.cell_out]
                 L.append(f"    if (zlds{Lp.id}) {{   // the block's cells go back to the arena")
                 for j, k in stored:
-                    L.append(f"      for (int k = lane; k < zln{Lp.id}; k += 64) memp[(zla{Lp.id}[{j}] + (int64_t)k * zls{Lp.id}[{j}]) * mse] = zt_cells[zlo{Lp.id} + {j} * zln{Lp.id} + k];")
+                    so, nk = self.site_off[Lp.id], len(self.pass_keys(Lp))
+                    L.append(f"      for (int k = lane; k < zln{Lp.id}; k += 64) memp[(zt_site[{so + j}] + (int64_t)k * zt_site[{so + nk + j}]) * mse] = zt_cells[zlo{Lp.id} + {j} * zln{Lp.id} + k];")
                 L.append("    }")
         if p.has_block and (self.has_mem or True):
             L.append("    __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"workgroup\");     // the block's values are in vars[] / mem[] before @block reads them")
@@ -2781,14 +2839,14 @@ class _Emit:
             else:
                 self.emit_loop_body(reg, ind + "  ", carried)
             self.ring_lds = {}
-            L.append(f"{ind}}} else {{     // (a window that does not fit, or a ring this is not: gathers from memory)")
-            self.emit_loop_body(reg, ind + "  ", carried)
+            L.append(f"{ind}}} else {{     // (a window that does not fit, or a ring this is not: gathers from memory, trip by trip)")
+            self.emit_loop_body(reg, ind + "  ", carried, batch=steps is None)
             L.append(f"{ind}}}")
         elif steps is not None and any(it[1].kind in ("ld", "lcin") for it in reg.items):
             L.append(f"{ind}if (zs{Lp.id}) {{")
             self.emit_strip(reg, ind + "  ", carried, steps)
-            L.append(f"{ind}}} else {{")
-            self.emit_loop_body(reg, ind + "  ", carried)
+            L.append(f"{ind}}} else {{     // (counters that are not small integers: trip by trip)")
+            self.emit_loop_body(reg, ind + "  ", carried, batch=False)
             L.append(f"{ind}}}")
         else:
             self.emit_loop_body(reg, ind, carried)
@@ -3049,13 +3107,13 @@ class _Emit:
         # (the offsets name each load's own U node: resolved where the load is emitted, plain or per sub-trip of a batch)
         self.ring_u = {ld.i: u for grp in groups for ld, u, _ in grp.loads}
 
-    def emit_loop_body(self, reg: Region, ind: str, carried: List[str]):
+    def emit_loop_body(self, reg: Region, ind: str, carried: List[str], batch: bool = True):
         p, L, ref = self.plan, self.L, self.ref
         Lp = reg.loop
         if Lp.count is not None:
             L.append(f"{ind}const int64_t zc{Lp.id} = za_loopcount(ZT_UNI({ref(Lp.count)}));")
             L.append(f"{ind}int64_t zk{Lp.id} = 0;")
-            G = self.batch_width(reg)
+            G = self.batch_width(reg) if batch else 1
             if G > 1:
                 self.emit_batched(reg, ind, G, carried)
             L.append(f"{ind}for (; zk{Lp.id} < zc{Lp.id}; ++zk{Lp.id}) {{")
