@@ -74,6 +74,25 @@ CASES = [
     ("Contour", "default", {}, 2048, 512),
     ("Texture", "default", {}, 1024, 256),
     ("TextureXY", "default", {}, 2048, 512),
+    ("fx_convkat", "default", {}, 3072, 512),         # fft_real / ifft_real / convolve_c on the audio path, through the reference VM
+    ("fx_convkat", "dense", {0: 0.9, 1: 3}, 2500, 500),
+    # round 3: one setting away from the defaults per catalog leaf -- the other side of its mode / flavor switches, detector
+    # filters on, extremes of times and amounts -- so that a translation error on a branch the defaults never take shows against
+    # the reference VM, not only device-vs-port
+    ("ADS", "alt", {0: 20, 1: 10, 2: 100, 3: 90, 4: 110, 5: 0, 6: -6, 7: 15}, 2048, 512),
+    ("ATTACK", "alt", {0: 80, 1: -60, 2: 100, 3: -100, 4: 10, 5: 1}, 2048, 512),
+    ("RTT", "alt", {0: 24, 1: 95, 2: 60, 3: 2, 4: 70, 5: 90, 6: 800, 7: 10}, 2048, 512),
+    ("SaliencePush", "alt", {0: 3, 1: 100, 2: 0, 3: 10, 4: 6}, 2048, 512),
+    ("EasyExpander", "alt", {0: -12, 1: 60, 2: 0, 3: 300, 4: 4000}, 2048, 512),
+    ("Roomalizer", "alt", {0: 3, 1: 100, 2: 90, 3: 100, 4: 80, 5: -9, 6: 0}, 2048, 512),
+    ("ERBTilt", "alt", {0: 12, 1: 300, 2: 30, 3: 100}, 2048, 512),
+    ("SpectralStabilizer", "alt", {0: 2.0, 1: 100, 2: 0}, 2048, 512),
+    ("TSEQ", "alt", {0: -70, 1: 6, 2: 80, 3: -50, 4: 100, 5: -100, 6: 40, 7: -20, 11: 0}, 2048, 512),
+    ("DPT", "alt", {0: -80, 1: 10, 2: 0, 3: -6}, 2048, 512),
+    ("SOMA", "alt", {0: 18, 1: -6, 2: 12, 3: 20, 4: 100, 5: 80, 6: 30, 7: 3, 8: 0, 10: 60, 11: 90}, 2048, 512),
+    ("BedRock", "alt", {0: 2, 1: 100, 2: 80, 3: 10, 4: 90}, 2048, 512),
+    ("Alias", "alt", {0: 80, 1: 0, 2: 100, 3: 60, 4: 400, 6: 24, 7: 0, 8: 3, 11: 1}, 2048, 512),
+    ("NeuroCV", "alt", {0: 2, 3: 2, 4: 20, 6: 0.2, 7: 5, 8: 3}, 1024, 256),
 ]
 
 

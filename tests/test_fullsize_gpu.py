@@ -208,3 +208,40 @@ def test_pending_slider_flag_survives_a_checkpoint():
     with zabatch.Engine("DPT", n) as e2:
         e2.restore(ck)
         assert np.array_equal(e2.process_host(x[:, :, frames:], block=256), want)
+
+
+def test_headline_batch_4096_instances_sampled_against_the_serial_kernel():
+    """The benchmark's own batch (north-star headline: DDT x 4096 x 480 000 frames): every 64th instance of the 4096-instance
+    launch of the hand-written kernel against the same instance run by the serial kernel (own noise per instance id, so an
+    engine of 64 instances with those ids sees the same inputs) -- and, ADVICE / VERDICT round 2, the cross-shard spread:
+    the same instances in a 512-instance engine (the per-GPU shard of an 8-GPU run picks another number of wavefronts per
+    instance, d2_pick_nw) leave states within 1e-12 of the 4096-instance run's."""
+    import zabatch
+    meta = zabatch.leaf_meta("DDT")
+    n_big, frames = 4096, FRAMES
+    pick = list(range(0, n_big, 64))                      # 64 instances spread over the batch
+    big = zabatch.Engine("DDT", n_big, path=zabatch.ZAB_PATH_FAST, max_block=BLOCK)
+    big.set_sliders(meta["default_sliders"]); big.prepare()
+    nbytes = n_big * 2 * frames * 4
+    d_in, d_out = big.device_alloc(nbytes), big.device_alloc(nbytes)
+    big.device_noise(d_in, frames)
+    big.process_device(d_in, d_out, frames, block=BLOCK); big.sync()
+    assert big.used_fast_path() and "ddt_fast" in big.last_kernel_name()
+    v_big = big.read_vars()
+    row = 2 * frames * 4
+    xs = np.stack([big.download(d_in + i * row, (1, 2, frames))[0] for i in pick])
+    ys = np.stack([big.download(d_out + i * row, (1, 2, frames))[0] for i in pick])
+    big.close()
+    for label, path, tol_audio, tol_state in (("serial kernel", zabatch.ZAB_PATH_GENERIC, AUDIO_EPS, 1e-8), ("512-instance shard", zabatch.ZAB_PATH_FAST, 2.5e-7, 1e-12)):
+        n_small = len(pick) if path == zabatch.ZAB_PATH_GENERIC else 512
+        with zabatch.Engine("DDT", n_small, path=path, max_block=BLOCK) as e:
+            e.set_sliders(meta["default_sliders"]); e.prepare()
+            x = np.zeros((n_small, 2, frames), np.float32)
+            x[:len(pick)] = xs                              # (instances beyond the sample run silence: the kernels are per instance)
+            y = e.process_host(x, block=BLOCK)
+            v = e.read_vars()
+            kern = e.last_kernel_name()
+        err = float(np.abs(y[:len(pick)].astype(np.float64) - ys).max())
+        dv = float(np.abs(v[:len(pick)] - v_big[pick]).max() / max(1.0, float(np.abs(v_big[pick]).max())))
+        print(f"4096-instance launch vs {label} ({kern}): audio max |diff| = {err:.3e}, state {dv:.3e}")
+        assert err <= tol_audio and dv <= tol_state, (label, err, dv)

@@ -145,6 +145,22 @@ def test_two_writes_that_touch_one_cell_hand_the_chunk_back():
     assert y[1, 100] == np.float32(np.float64(x[0, 81]) - np.float64(x[0, 98]))
 
 
+def test_delay_lines_that_share_a_buffer_hand_the_launch_back():
+    """Spectral/Alias: its six intdelay() lines all live at mem[0] (the instance variable `buf` is never set). The lowering takes
+    differently named buffers to be different; the run-time check on reads that fall into another write's span catches that they
+    are not, at the first chunk (the leaf therefore keeps the generic kernel: zajit/build.py NO_TPAR)."""
+    from zajit import tpar
+    plan, _ = _plan("Alias")
+    assert plan.stats["guards"] == 1 and plan.stats["delay_writes"] == 9 and plan.stats["sparse_writes"] == 3
+    g = load_golden("Alias_default")
+    names = [str(s) for s in g["var_names"]]
+    v0 = {n: (0.0 if np.isnan(v) else float(v)) for n, v in zip(names, g["vars_prepared"])}
+    mem0, _ = _prepared_arena("Alias", g)
+    with pytest.raises(tpar.TparAbort) as ei:
+        plan.simulate(v0, golden_input(g)[:, :256], sliders=g["sliders"], srate=float(g["srate"]), mem=mem0)
+    assert ei.value.f0 == 0 and "another buffer" in ei.value.why
+
+
 def test_what_used_to_be_unsupported_now_plans():
     """@block, scripts that raise slider masks, uniform loops with per-trip cells and gathers, conditional stores into buffers
     @sample never reads: round 3 took these blockers out."""
@@ -164,7 +180,7 @@ def test_what_used_to_be_unsupported_now_plans():
     assert plan.stats["sparse_writes"] == 1 and plan.holdvars == ["tmp"]
 
 
-@pytest.mark.parametrize("case", TPAR_FIXTURES + [f"{l}_default" for l in TPAR_CATALOG] + ["DDT_default", "DDT_far_extreme"])
+@pytest.mark.parametrize("case", TPAR_FIXTURES + [f"{l}_{c}" for l in TPAR_CATALOG for c in ("default", "alt")] + ["DDT_default", "DDT_far_extreme"])
 def test_staged_algorithm_matches_reference_vm(case):
     leaf = leaf_of(case)
     plan, _ = _plan(leaf)
@@ -219,7 +235,7 @@ def test_staged_algorithm_is_independent_of_launch_boundaries():
 
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", TPAR_FIXTURES + TPAR_ABORTS + [f"{l}_default" for l in TPAR_CATALOG + TPAR_BLOCK_CATALOG])
+@pytest.mark.parametrize("case", TPAR_FIXTURES + TPAR_ABORTS + [f"{l}_{c}" for l in TPAR_CATALOG + TPAR_BLOCK_CATALOG for c in ("default", "alt")])
 def test_tpar_kernel_matches_reference_vm(case):
     import zabatch
     leaf = leaf_of(case)
@@ -279,7 +295,7 @@ def test_tpar_kernel_tracks_generic_kernel_over_a_long_run_and_across_launches(l
             k = int(k)
             rows[:, k] = rows[:, k] + (np.arange(n) / n - 0.4) * 0.2 * (sd["max"] - sd["min"])
             rows[:, k] = np.clip(rows[:, k], sd["min"], sd["max"])
-    cap = 1 << 18 if leaf == "SOMA" else 1 << 16
+    cap = {"SOMA": 1 << 18, "Alias": 1 << 19}.get(leaf, 1 << 16)
     cuts = [0, 1, 66, 66 + 63, 4096 + 129, 30000, frames]
     # (a script with @block sees where a launch starts -- every launch begins a block -- so both engines get the same launches)
     ref_cuts = cuts if meta["has"]["block"] else [0, frames]

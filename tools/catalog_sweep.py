@@ -1,6 +1,11 @@
 """Catalog sweep: every discovered leaf through the engine, one line per leaf.
 
-    python tools/catalog_sweep.py [--instances 1024] [--frames 48000] [--out profiles/r01_catalog_sweep.json]
+    python tools/catalog_sweep.py [--instances 1024] [--frames 48000] [--out profiles/r03_catalog_sweep.json] [--cpu-seconds 2]
+
+Per row, beside the device numbers: `cpu_port_msamples_16c` -- the leaf's CPU checker (oracle/port.py, or oracle/faust_ref.c for
+the Faust leaves) on this box's host cores, one instance per thread for --cpu-seconds; `vs_cpu` = device rate / that;
+`hbm_frac` = the audio a launch must move (4 B in + 4 B out per channel and frame) / kernel time / 8 TB/s; `speedup_vs_r02` =
+the previous round's kernel time for the same batch / this one.
 
 Leaves whose script reaches a host-only builtin (buffer messages, peer names) are reported as "host-assisted": the engine
 refuses them loudly (ZAB_E_UNSUPPORTED) instead of running them with stubbed host calls. Timing is the engine's own HIP
@@ -28,6 +33,7 @@ def main() -> int:
     ap.add_argument("--block", type=int, default=512)
     ap.add_argument("--out", default="")
     ap.add_argument("--only", default="", help="comma-separated leaf names (default: every built leaf)")
+    ap.add_argument("--cpu-seconds", type=float, default=2.0, help="budget of the CPU checker per leaf (0: skip)")
     args = ap.parse_args()
     lib = ROOT / "zorakaudio-experimental-plugins_amd" / "lib"
     leaves = sorted(p.stem for p in lib.glob("*.json") if not p.stem.startswith("fx_"))
@@ -47,18 +53,68 @@ def main() -> int:
             row["instances"] = max(1, min(args.instances, (48 << 30) // (cap * 8)))
             row["mem_cap"] = cap
             run_one(zabatch, args, leaf, meta, nch, row, cap)
+        if row.get("kernel_ms"):
+            row["hbm_frac"] = round(row["instances"] * nch * args.frames * 8 / (row["kernel_ms"] * 1e-3) / 8.0e12, 6)
+            if args.cpu_seconds > 0:
+                cpu = cpu_rate(leaf, meta, nch, args.cpu_seconds, args.block)
+                if cpu:
+                    row["cpu_port_msamples_16c"], row["cpu_cores"] = round(cpu[0], 2), cpu[1]
+                    row["vs_cpu"] = round(row["msamples_per_s"] / cpu[0], 1)
         rows.append(row)
         print(json.dumps(row), flush=True)
-    base = ROOT / "profiles" / "r01_catalog_sweep.json"          # previous round's sweep: the ratio per leaf at the same batch size
+    base = ROOT / "profiles" / "r02_catalog_sweep.json"          # previous round's sweep: the ratio per leaf at the same batch size
     if base.exists():
         old = {r["leaf"]: r for r in json.loads(base.read_text())}
         for r in rows:
             o = old.get(r["leaf"])
             if o and r.get("kernel_ms") and o.get("kernel_ms") and o.get("instances") == r.get("instances") and o.get("frames") == r.get("frames"):
-                r["speedup_vs_r01"] = round(o["kernel_ms"] / r["kernel_ms"], 2)
+                r["speedup_vs_r02"] = round(o["kernel_ms"] / r["kernel_ms"], 2)
+                r["r02_kernel_ms"] = round(o["kernel_ms"], 3)
     if args.out:
         Path(args.out).write_text(json.dumps(rows, indent=1))
     return 0
+
+
+def cpu_rate(leaf, meta, nch, seconds, block):
+    """(Msamples/s over all threads, threads) of the leaf's CPU checker: one instance per thread, 24 000-frame passes of noise."""
+    import os
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+    from zajit import noise
+    try:
+        if meta.get("kind") == "faust":
+            from oracle import faust_ref
+            fresh = lambda: faust_ref.FaustRef(leaf, 48000.0)
+            run = lambda o, x: o.compute(x, meta["default_sliders"][:8], block=block)
+        else:
+            from oracle import port
+            if not port.port_path(leaf).exists():
+                return None
+
+            def fresh():
+                p = port.Port(leaf, 48000.0, mem_cap=1 << 25)
+                p.set_sliders(meta["default_sliders"]); p.prepare()
+                return p
+            run = lambda o, x: o.process(x, block)
+        cores = max(1, min(os.cpu_count() or 1, 16))
+        frames = 24000
+        x = noise.white_noise(range(cores), frames, channels=max(nch, 2))[:, :nch]
+        x = np.ascontiguousarray(x)
+
+        def work(i):
+            o = fresh()
+            t, reps = time.perf_counter(), 0
+            while True:
+                run(o, x[i]); reps += 1
+                if time.perf_counter() - t > seconds:
+                    return reps
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:
+            reps = list(ex.map(work, range(cores)))
+        return sum(reps) * frames * nch / (time.perf_counter() - t0) / 1e6, cores
+    except Exception as ex:        # noqa: BLE001  (a checker that cannot run this leaf here: the row simply has no CPU figure)
+        print(f"# cpu checker of {leaf}: {ex}", file=sys.stderr)
+        return None
 
 
 def run_one(zabatch, args, leaf, meta, nch, row, mem_cap):

@@ -4,8 +4,12 @@ Plays the role scripts/build.py + dsp_jsfx_aot.py play in the reference (scripts
 run the AOT translator, then compile), with the same leaf discovery contract (plugins/<Category>/<Key>/plugin.json,
 `pluginType` jsfx, `entry` -> src/*.jsfx; scripts/pluginlib.py:105-240) and CLI spelling (--only, --list).
 
-    python -m zajit.build --plugins-root /root/reference/plugins --only DDT
+    python -m zajit.build --plugins-root /root/reference/plugins --only DDT [--correctness-check]
     python -m zajit.build --list
+
+--only takes what scripts/build.py takes (scripts/pluginlib.py:243-257): a case-insensitive substring of the category, key, slug,
+name, path, bundleId or clapId. --correctness-check (scripts/build.py:556): after a leaf is built it is run on the device
+against the reference shadow VM's recorded results (zajit/check.py) and the build fails above the reference's tolerances.
 
 Outputs (all git-ignored, all travel to the GPU box):
     <pkg>/lib/libzabatch.so        host runtime + C ABI (include/zabatch.h)
@@ -52,6 +56,10 @@ NO_TPAR: Dict[str, str] = {
     # no audio path at all: the leaf is its @block (msg / gmem bookkeeping), which the lane-per-instance kernel runs with the
     # state in registers from block to block (256 instances x 48 000 frames: 1124 ms against 1570 ms here)
     "3DPannerManager": "@sample is empty: nothing to run time-parallel",
+    # its six intdelay() lines all sit at mem[0] (the instance variable `buf` is never set: Alias.jsfx:100-108), so what the
+    # lowering takes for six buffers is one: every chunk fails the check on reads that fall into another write's span and would
+    # be handed back to the serial code (tests/test_tpar.py pins that)
+    "Alias": "its delay lines share one buffer: every chunk would be handed back",
 }
 LONG_BRANCH_LIMIT = 32
 # leaves whose state the hand-written kernel wants contiguous per instance
@@ -79,6 +87,30 @@ def discover(plugins_root: Path) -> Dict[str, dict]:
             found = sorted((pj.parent / "src").glob(pat))
             src = found[0] if found else None
         out[key] = {"category": pj.parent.parent.name, "type": ptype, "meta": meta, "entry": src, "dir": pj.parent}
+    return out
+
+
+def matches(key: str, leaf: dict, needle: str) -> bool:
+    """plugin_matches of the reference (scripts/pluginlib.py:243-257): case-insensitive substring of category, slug, name, key,
+    directory, bundleId or clapId. A needle that equals a key exactly selects that leaf only (DDT, not also "DDT-anything")."""
+    q = needle.strip().lower()
+    if not q:
+        return True
+    meta = leaf.get("meta", {}) or {}
+    hay = [leaf.get("category", ""), str(meta.get("slug", "")), str(meta.get("name", "")), key,
+           str(Path(leaf.get("category", "")) / key), str(leaf.get("dir", "")), str(meta.get("bundleId", "")), str(meta.get("clapId", ""))]
+    return any(q in str(h).lower() for h in hay)
+
+
+def select(leaves: Dict[str, dict], needles: List[str]) -> List[str]:
+    if not needles:
+        return list(leaves)
+    out = []
+    for q in needles:
+        exact = [k for k in leaves if k.lower() == q.strip().lower()]
+        for k in (exact or [k for k, v in leaves.items() if matches(k, v, q)]):
+            if k not in out:
+                out.append(k)
     return out
 
 
@@ -269,7 +301,10 @@ def build_module(jsfx_path, name: Optional[str] = None, force=False, verbose=Fal
 def main(argv=None) -> int:
     ap = argparse.ArgumentParser(description="Build MI355X plugin modules from JSFX leaves")
     ap.add_argument("--plugins-root", default="/root/reference/plugins")
-    ap.add_argument("--only", action="append", default=[], help="leaf key(s) to build (repeatable / comma separated)")
+    ap.add_argument("--only", action="append", default=[],
+                    help="build only matching leaves: category, key, slug, name, path, bundleId or clapId (repeatable / comma separated)")
+    ap.add_argument("--correctness-check", action="store_true",
+                    help="run every built leaf on the device against the reference shadow VM's recorded results (needs a GPU)")
     ap.add_argument("--list", action="store_true")
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--keep-going", action="store_true")
@@ -279,11 +314,15 @@ def main(argv=None) -> int:
         for k, v in leaves.items():
             print(f"{v['category']}/{k}\t{v['type']}\t{v['entry']}")
         return 0
-    want = [w for arg in args.only for w in arg.split(",") if w]
+    want = select(leaves, [w for arg in args.only for w in arg.split(",") if w])
+    if args.only and not want:
+        print(f"no leaf matches {args.only}", file=sys.stderr)
+        return 2
     build_runtime(force=args.force)
     rc = 0
+    checked: List[dict] = []
     for key, leaf in leaves.items():
-        if want and key not in want:
+        if key not in want:
             continue
         if leaf["entry"] is None:
             continue
@@ -295,11 +334,22 @@ def main(argv=None) -> int:
             else:
                 so = build_module(leaf["entry"], name=key, force=args.force, verbose=True)
             print(f"built {so}")
+            if args.correctness_check and leaf["type"] != "faust":
+                from . import check
+                rows = check.check_leaf(key)
+                checked += rows
+                if not all(r["ok"] for r in rows):
+                    raise RuntimeError(f"{key}: correctness check above the reference's tolerances (audio 1e-5, vars / mem 1e-8)")
+            elif args.correctness_check:
+                print(f"  correctness {key}: Faust leaf -- the reference has no shadow runtime for FaustJuceProcessor; nothing to compare")
         except Exception as ex:  # noqa: BLE001
             print(f"FAILED {key}: {str(ex)[:2000]}", file=sys.stderr)
             rc = 1
             if not args.keep_going:
                 return rc
+    if args.correctness_check:
+        bad = [r for r in checked if not r["ok"]]
+        print(f"correctness check: {len(checked) - len(bad)} of {len(checked)} (case, kernel) runs within the reference's tolerances")
     return rc
 
 

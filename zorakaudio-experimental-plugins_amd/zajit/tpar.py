@@ -159,6 +159,23 @@ def _assigned_names(prog: Program, roots, shadow=()) -> set:
     return out
 
 
+def _outarg_names(prog: Program, roots) -> set:
+    """Variables handed to a runtime builtin as plain arguments: the builtin may assign them (msg_recv's outputs, file_var,
+    file_riff, midirecv, slider_next_chg ...)."""
+    out, seen, todo = set(), set(), list(roots)
+    while todo:
+        x = todo.pop()
+        if isinstance(x, S.Call):
+            if x.fn in prog.fns:
+                if x.fn not in seen:
+                    seen.add(x.fn)
+                    todo.append(prog.fns[x.fn].body)
+            elif ("fabs" if x.fn == "abs" else x.fn) not in (CALL1 | CALL2):
+                out |= {a.name for a in x.args if isinstance(a, S.Var)}
+        todo.extend(S.children(x))
+    return out
+
+
 def _read_names(prog: Program, roots) -> set:
     out, seen, todo = set(), set(), list(roots)
     while todo:
@@ -194,7 +211,8 @@ def split_guards(prog: Program):
     if len(items) == 1 and isinstance(items[0], S.Seq):
         items = list(items[0].items)
     cand = {k for k, st in enumerate(items)
-            if isinstance(st, (S.Cond, S.If)) and st.els is None and st.then is not None and _pure_scalar(prog, st.cond)
+            if isinstance(st, (S.Cond, S.If)) and (st.els is None or isinstance(st.els, S.Num)) and st.then is not None
+            and _pure_scalar(prog, st.cond)
             and (_assigned_names(prog, [st.then]) & _read_names(prog, [st.cond]))}
     while cand:
         rest = [st for k, st in enumerate(items) if k not in cand]
@@ -2001,7 +2019,7 @@ class _Emit:
         if p.has_pending:
             secs += list(prog.sections.get("slider", []))
         rd = sorted(prog.vars[nm] for nm in _read_names(prog, secs) if nm in prog.vars)
-        wr = sorted(prog.vars[nm] for nm in _assigned_names(prog, secs) if nm in prog.vars)
+        wr = sorted(prog.vars[nm] for nm in (_assigned_names(prog, secs) | _outarg_names(prog, secs)) if nm in prog.vars)
         if os.environ.get("ZA_TPAR_FULL_STATE"):
             rd = wr = list(range(prog.nvars))
         L.append("// between the blocks: @block and the pending-mask @slider, run by the wavefront with the leaf's section code")
