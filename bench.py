@@ -204,12 +204,20 @@ def main() -> int:
     ap.add_argument("--null-instances", type=int, default=4, help="instances per rank checked against the CPU checker")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-null-test", action="store_true")
+    ap.add_argument("--group", action="store_true",
+                    help="ONE process over the C library's zab_group_* (a host thread + stream per GPU, RCCL for the end-of-run "
+                         "statistics) instead of one torchrun rank per GPU; same shards, same JSON line")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
+    if args.group:
+        if world != 1:
+            print("bench.py: --group is a single process (do not start it under torchrun)", file=sys.stderr)
+            return 2
+        world = args.gpus
+    elif args.gpus != world:
         if world == 1 and "RANK" not in os.environ and args.gpus > 1:
             return spawn_ranks(args.gpus, sys.argv[1:])
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}", file=sys.stderr)
@@ -224,7 +232,10 @@ def main() -> int:
         return 2
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if args.group and torch.cuda.device_count() < args.gpus:
+        print(f"bench.py: --group --gpus {args.gpus} but {torch.cuda.device_count()} device(s) visible", file=sys.stderr)
+        return 2
+    if world > 1 and not args.group:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -232,41 +243,80 @@ def main() -> int:
     leaf = args.leaf
     meta = zabatch.leaf_meta(leaf)
     try:
-        shard = sharding.plan(rank, world, args.instances_total, args.instances_per_gpu)
+        if args.group:          # this process holds every shard (zab_group_create lays them out as sharding.plan does over ranks)
+            for r in range(world):
+                sharding.plan(r, world, args.instances_total, args.instances_per_gpu)
+            shard = sharding.Shard(0, args.instances_per_gpu * world or args.instances_total, args.instances_per_gpu * world or args.instances_total,
+                                   "weak" if args.instances_per_gpu else "strong")
+        else:
+            shard = sharding.plan(rank, world, args.instances_total, args.instances_per_gpu)
     except ValueError as ex:
         print(f"bench.py: {ex}", file=sys.stderr)
         return 2
     weak, lo, hi, n_total, n_inst = shard.scaling == "weak", shard.lo, shard.hi, shard.n_total, shard.count
     frames = args.frames
     path = {"auto": zabatch.ZAB_PATH_AUTO, "generic": zabatch.ZAB_PATH_GENERIC, "fast": zabatch.ZAB_PATH_FAST}[args.path]
-    eng = zabatch.Engine(leaf, n_inst, srate=SRATE, max_block=BLOCK, device=local_rank, path=path, first_instance_id=1 + lo)
-    nch = eng.nch
-    eng.set_sliders(meta["default_sliders"])
-    eng.prepare()
-    nbytes = n_inst * nch * frames * 4
-    d_in, d_out = eng.device_alloc(nbytes), eng.device_alloc(nbytes)
-    eng.device_noise(d_in, frames, id_offset=lo)      # synthetic white noise, generated in HBM; noise id = global instance index
-    eng.sync()
+    grp = None
+    if args.group:
+        # the whole job in this process: zab_group_create shards n_total instances over the devices exactly as sharding.plan
+        # does over ranks (contiguous ranges); shard 0's engine stands where rank 0's engine stands below
+        grp = zabatch.Group(leaf, n_total, devices=list(range(world)), srate=SRATE, max_block=BLOCK, path=path, first_instance_id=1)
+        grp.set_sliders(meta["default_sliders"])
+        grp.prepare()
+        eng = grp.shards[0][2]
+        nch = eng.nch
+        n_inst = grp.shards[0][1]
+        g_in, g_out = [], []
+        for first, count, view in grp.shards:
+            nb = count * nch * frames * 4
+            g_in.append(view.device_alloc(nb)); g_out.append(view.device_alloc(nb))
+            view.device_noise(g_in[-1], frames, id_offset=first)
+        grp.sync()
+        d_in, d_out = g_in[0], g_out[0]
+    else:
+        eng = zabatch.Engine(leaf, n_inst, srate=SRATE, max_block=BLOCK, device=local_rank, path=path, first_instance_id=1 + lo)
+        nch = eng.nch
+        eng.set_sliders(meta["default_sliders"])
+        eng.prepare()
+        nbytes = n_inst * nch * frames * 4
+        d_in, d_out = eng.device_alloc(nbytes), eng.device_alloc(nbytes)
+        eng.device_noise(d_in, frames, id_offset=lo)      # synthetic white noise, generated in HBM; noise id = global instance index
+        eng.sync()
+
+    def launch():
+        if grp is not None:
+            grp.process_device(g_in, g_out, frames, block=BLOCK)
+        else:
+            eng.process_device(d_in, d_out, frames, block=BLOCK)
+
+    def sync_all():
+        if grp is not None:
+            grp.sync()
+        else:
+            eng.sync()
 
     def barrier():
-        eng.sync()
+        sync_all()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
 
     # first launch of the timed engine: its output for a sample of instances is what the null test checks
-    eng.process_device(d_in, d_out, frames, block=BLOCK)
-    eng.sync()
+    launch()
+    sync_all()
     t_first = eng.last_timing()[0] * 1e-3
     sample_out = {}
     if not args.no_null_test:
-        k = max(1, min(args.null_instances, n_inst))
-        for j in sorted({int(round(q * (n_inst - 1) / max(1, k - 1))) for q in range(k)}):
-            off = j * nch * frames * 4
-            sample_out[lo + j] = (eng.download(d_in + off, (nch, frames)), eng.download(d_out + off, (nch, frames)))
+        # (a null test at EVERY shard: the waves per instance -- hence the last bits -- follow the shard's size, d2_pick_nw)
+        for first, count, view, bi, bo in ([(lo, n_inst, eng, d_in, d_out)] if grp is None else
+                                           [(f, c, v, g_in[k_], g_out[k_]) for k_, (f, c, v) in enumerate(grp.shards)]):
+            k = max(1, min(args.null_instances if grp is None else max(1, args.null_instances // world), count))
+            for j in sorted({int(round(q * (count - 1) / max(1, k - 1))) for q in range(k)}):
+                off = j * nch * frames * 4
+                sample_out[first + j] = (view.download(bi + off, (nch, frames)), view.download(bo + off, (nch, frames)))
     for _ in range(max(0, args.warmup - 1)):
-        eng.process_device(d_in, d_out, frames, block=BLOCK)
-    eng.sync()
+        launch()
+    sync_all()
     t_step = eng.last_timing()[0] * 1e-3
     steps = args.steps
     if steps <= 0:
@@ -278,8 +328,8 @@ def main() -> int:
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
-        eng.process_device(d_in, d_out, frames, block=BLOCK)
-    eng.sync()
+        launch()
+    sync_all()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
@@ -292,8 +342,10 @@ def main() -> int:
     null_mx, null_ss, null_n = (0.0, 0.0, 0)
     if sample_out:
         null_mx, null_ss, null_n = null_test(checker, sample_out)
-    job = sharding.reduce_stats(sharding.RunStats(elapsed_s=elapsed, units=float(n_inst) * nch * frames * steps, max_abs_err=null_mx),
+    units_here = float(n_total if grp is not None else n_inst) * nch * frames * steps
+    job = sharding.reduce_stats(sharding.RunStats(elapsed_s=elapsed, units=units_here, max_abs_err=null_mx),
                                 dist, device="cuda" if dist is not None else None)
+    group_stats = grp.reduce() if grp is not None else None      # (max / sum of the shards' kernel times: RCCL when they sit on several GPUs)
     if dist is not None:
         t = torch.tensor([null_ss, float(null_n)], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -352,7 +404,10 @@ def main() -> int:
             "config": {"workload": f"{leaf} x{n_total} instances in total ({'weak' if weak else 'strong'} scaling, "
                                    f"{n_inst} on rank 0), defaults, 48 kHz x{nch} ch, {frames} frames white noise, block={BLOCK}",
                        "leaf": leaf, "instances_total": n_total, "instances_rank0": n_inst, "frames_per_step": frames,
-                       "kernel": kernel_name, "sharding": f"sharding.instance_range over {world} rank(s), no data-path collective"},
+                       "kernel": kernel_name,
+                       "sharding": (f"zab_group_* in one process: {world} shard(s), a host thread + stream per GPU, no data-path collective"
+                                    if grp is not None else f"sharding.instance_range over {world} rank(s), no data-path collective"),
+                       "driver": "group" if grp is not None else "torchrun"},
             "mframes_per_s": total_samples / nch / elapsed / 1e6,
             "realtime_factor_per_instance": frames / SRATE / (elapsed / steps),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -383,6 +438,8 @@ def main() -> int:
             del src, dst
         except Exception:
             pass
+        if group_stats is not None:
+            line["group"] = {k: group_stats[k] for k in ("n_shards", "used_rccl", "max_kernel_ms", "sum_kernel_ms")}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(checker, nch)
             try:
@@ -392,7 +449,10 @@ def main() -> int:
             if ref:
                 line["cpu_baseline"]["reference_vm"] = ref
         print(json.dumps(line), flush=True)
-    eng.close()
+    if grp is not None:
+        grp.close()
+    else:
+        eng.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
