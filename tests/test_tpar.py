@@ -17,6 +17,8 @@ from conftest import AUDIO_EPS, GOLDEN, ROOT, SCALAR_EPS, assert_state_close, db
 REF_PLUGINS = Path("/root/reference/plugins")
 FIXTURES = ROOT / "tests" / "fixtures"
 TPAR_CATALOG = ["ADS", "ATTACK", "RTT", "SaliencePush", "BedRock", "DPT", "Roomalizer", "EasyExpander", "SOMA"]
+# leaves whose @sample has a rare heavy branch (tpar.split_events): the frame it falls on runs with the serial section code
+TPAR_EVENT_LEAVES = ["PsychoConvolver", "PsychoConvolver+IR", "fx_stft", "fx_stft4k", "fx_stftparts", "fx_convkat", "fx_mapkat", "fx_ringio"]
 TPAR_BLOCK_CATALOG = ["ERBTilt", "SpectralStabilizer", "TSEQ"]        # leaves with @block: the kernel runs it between the blocks
 TPAR_FIXTURES = ["fx_dynkat_default", "fx_dynkat_hot", "fx_randkat_default", "fx_ringkat_default", "fx_ringkat_long",
                  "fx_delaytaps_default", "fx_delaytaps_far"]
@@ -109,11 +111,36 @@ def _plan_of_text(sample, init="", block=""):
     return tpar.try_plan(program.analyse(text, name="t"), 2)
 
 
+def test_rare_heavy_branches_become_events():
+    """`cond ? ( loops / builtins with effects )` statements are cut out of the frame (tpar.split_events): the plan keeps their
+    conditions, evaluates them first in every chunk, and the frame one falls on runs with the script's own section code."""
+    from zajit import program, tpar
+    for name in ("stft", "stft4k", "stftparts", "convkat", "ringio", "mapkat"):
+        plan, msg = tpar.try_plan(program.analyse_file(FIXTURES / f"{name}.jsfx"), 2)
+        assert plan is not None and plan.stats["events"] == 1, (name, msg)
+        kinds = [it[0] for it in plan.top.items]
+        assert kinds.count("cut") == 1
+        before = plan.top.items[:kinds.index("cut")]
+        assert all(it[0] in ("par", "scan", "shift", "spec", "serial") for it in before)       # no loads, stores or loops before the cut
+        with pytest.raises(NotImplementedError):
+            plan.simulate({}, np.zeros((2, 64), dtype=np.float32))
+    # nested in a block-constant conditional: the event's condition carries the path's
+    plan, msg = _plan_of_text("on ? ( buf[n] = spl0; n += 1; n >= 256 ? ( fft(buf, 256); n = 0; ); ); spl0 = buf[0];")
+    assert plan is not None and plan.stats["events"] == 1, msg
+    # inside a loop, or with an else arm, or valued: left alone (and then unsupported for what the body holds)
+    plan, msg = _plan_of_text("k = 0; loop(2, k >= 1 ? ( fft(buf, 64); ); k += 1; ); spl0 = buf[0];")
+    assert plan is None and "fft" in msg, msg
+    plan, msg = _plan_of_text("n += 1; n >= 64 ? ( fft(buf, 64); n = 0; ) : ( buf[n] = spl0; );")
+    assert plan is None, msg
+    # the condition must not read memory
+    plan, msg = _plan_of_text("buf[9] += 1; buf[9] >= 64 ? ( fft(buf + 64, 64); buf[9] = 0; ); spl0 = buf[70];")
+    assert plan is None, msg
+
+
 def test_unsupported_scripts_keep_the_generic_kernel_only():
     from zajit import program, tpar
-    plan, msg = tpar.try_plan(program.analyse_file(FIXTURES / "stft.jsfx"), 2)
-    assert plan is None and "fft" in msg, msg
     for sample, why in (
+            ("buf[wp & 63] = spl0; wp += 1; fft(buf, 64); spl0 = buf[3];", "builtin fft"),      # (in every frame: no event to cut out)
             ("n = floor(abs(spl0) * 8); k = 0; loop(n, k += 1); spl0 = k;", "count differs from frame to frame"),
             ("k = 0; while (k < abs(spl0) * 4) ( k += 1; ); spl1 = k;", "condition differs from frame to frame"),
             ("acc = 0; k = 0; loop(4, acc = acc * 0.5 + st; k += 1; ); st = acc + spl0; spl0 = st;", "runs through a loop"),
@@ -273,17 +300,20 @@ def test_tpar_kernel_matches_reference_vm(case):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("leaf", ["fx_dynkat", "fx_randkat", "fx_ringkat", "fx_ringabort", "fx_delaytaps"] + TPAR_CATALOG + TPAR_BLOCK_CATALOG
-                         + ["CMD", "DOT"])
+                         + ["CMD", "DOT"] + TPAR_EVENT_LEAVES)
 def test_tpar_kernel_tracks_generic_kernel_over_a_long_run_and_across_launches(leaf):
     """One second of audio, distinct noise and sliders per instance: the time-parallel kernel in ragged launches (lengths with
     chunk remainders 1, 63, 0 and a single frame) against the generic kernel in one launch -- audio within the reference's
     1e-5, final state within 1e-8 (affine recurrences are re-associated, nothing else differs)."""
     import zabatch
     from zajit import noise
+    loaded, leaf = leaf.endswith("+IR"), leaf.split("+")[0]
     if not zabatch.module_path(leaf).exists():
         pytest.skip(f"module for {leaf} not built")
     meta = zabatch.leaf_meta(leaf)
     n, frames = 6, 48000
+    # (an impulse response in file slot 0: 0.25 s of decaying stereo noise -- the convolver's partitions then run, every 2048 frames)
+    ir = (noise.white_noise([321], 12000)[0].T * np.exp(-np.arange(12000) / 3000.0)[:, None]).reshape(-1).astype(np.float64)
     if "gmem" in meta["features"]:
         n = 1             # instances of one engine share its gmem segment: what one reads depends on when the others wrote
     nch = int(meta["nch"])
@@ -295,16 +325,20 @@ def test_tpar_kernel_tracks_generic_kernel_over_a_long_run_and_across_launches(l
             k = int(k)
             rows[:, k] = rows[:, k] + (np.arange(n) / n - 0.4) * 0.2 * (sd["max"] - sd["min"])
             rows[:, k] = np.clip(rows[:, k], sd["min"], sd["max"])
-    cap = {"SOMA": 1 << 18, "Alias": 1 << 19}.get(leaf, 1 << 16)
+    cap = {"SOMA": 1 << 18, "Alias": 1 << 19, "PsychoConvolver": 1 << 22}.get(leaf, 1 << 16)
     cuts = [0, 1, 66, 66 + 63, 4096 + 129, 30000, frames]
     # (a script with @block sees where a launch starts -- every launch begins a block -- so both engines get the same launches)
     ref_cuts = cuts if meta["has"]["block"] else [0, frames]
     with zabatch.Engine(leaf, n, path=zabatch.ZAB_PATH_GENERIC, mem_cap=cap) as e:
+        if loaded:
+            e.file_slot_set(0, ir, channels=2, sample_rate=48000.0)
         e.set_sliders(rows); e.prepare()
         want = np.concatenate([e.process_host(x[:, :, a:b], block=512) for a, b in zip(ref_cuts[:-1], ref_cuts[1:])], axis=2)
         want_v = e.read_vars(); names = e.var_names()
         want_ck = e.checkpoint()                                 # (arena up to the write high-water mark, marks, rand() state)
     with zabatch.Engine(leaf, n, path=zabatch.ZAB_PATH_FAST, mem_cap=cap) as e:
+        if loaded:
+            e.file_slot_set(0, ir, channels=2, sample_rate=48000.0)
         e.set_sliders(rows); e.prepare()
         got = np.concatenate([e.process_host(x[:, :, a:b], block=512) for a, b in zip(cuts[:-1], cuts[1:])], axis=2)
         assert e.used_fast_path()

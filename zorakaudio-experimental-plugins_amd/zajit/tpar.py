@@ -170,7 +170,7 @@ def _outarg_names(prog: Program, roots) -> set:
                 if x.fn not in seen:
                     seen.add(x.fn)
                     todo.append(prog.fns[x.fn].body)
-            elif ("fabs" if x.fn == "abs" else x.fn) not in (CALL1 | CALL2):
+            elif ("fabs" if x.fn == "abs" else x.fn) not in (CALL1 | CALL2) and x.fn != EVENT:
                 out |= {a.name for a in x.args if isinstance(a, S.Var)}
         todo.extend(S.children(x))
     return out
@@ -222,6 +222,53 @@ def split_guards(prog: Program):
             break
         cand -= bad
     return [st for k, st in enumerate(items) if k not in cand], [items[k].cond for k in sorted(cand)]
+
+
+def _heavy(prog: Program, x, seen=None) -> bool:
+    """Something the per-frame dataflow cannot take, or should not pay for in every frame: a loop, or a builtin with effects
+    (memcpy, fft, convolve_c, file and string calls ...), here or in a function called from here."""
+    seen = set() if seen is None else seen
+    if isinstance(x, (S.Loop, S.While)):
+        return True
+    if isinstance(x, S.Call):
+        fn = "fabs" if x.fn == "abs" else x.fn
+        if fn in prog.fns:
+            if fn not in seen:
+                seen.add(fn)
+                if _heavy(prog, prog.fns[fn].body, seen):
+                    return True
+        elif not (fn in (CALL1 | CALL2) or fn in NOOP_CALLS or fn.startswith("gfx_") or fn in ("rand", "__memtop")):
+            return True
+    return any(_heavy(prog, c, seen) for c in S.children(x))
+
+
+EVENT = "__event"
+
+
+def split_events(prog: Program, stmts):
+    """Statements `C ? ( ... )` (no else) of @sample -- at the top or inside other conditionals, not inside loops or functions --
+    whose body is heavy (_heavy) and whose condition is a plain expression: the "every hop: run the FFT" / "buffer full: convolve
+    a block" idiom. The lowering replaces each by a marker that keeps the condition; the kernel evaluates the conditions first in
+    every chunk, lets the frames before the first one that holds take the parallel path, runs that one frame with the serial
+    section code (zt_frame) and starts over behind it. Returns (rewritten statements, bodies dropped)."""
+    dropped = []
+
+    def rw(x, stmt: bool):
+        if isinstance(x, S.Seq):
+            n = len(x.items)
+            return S.Seq([rw(it, stmt or k + 1 < n) for k, it in enumerate(x.items)], line=x.line, col=x.col)
+        if isinstance(x, (S.Cond, S.If)):
+            st = stmt or isinstance(x, S.If)
+            if (st and x.then is not None and (x.els is None or isinstance(x.els, S.Num)) and _pure_scalar(prog, x.cond)
+                    and _heavy(prog, x.then)):
+                dropped.append(x)
+                return S.Call(EVENT, [x.cond], line=x.line, col=x.col)
+            return type(x)(x.cond, rw(x.then, st) if x.then is not None else None,
+                           rw(x.els, st) if x.els is not None else None, line=x.line, col=x.col)
+        return x
+
+    out = [rw(st, True) for st in stmts]
+    return out, dropped
 
 
 def exposed_vars(prog: Program, stmts) -> set:
@@ -317,6 +364,7 @@ class FrameGraph:
         self.loop_ids = 0
         self.lcell_addr: Dict[str, N] = {}       # "lmem@<id>" -> address node (cells of uniform loops)
         self.holds: Dict[str, N] = {}
+        self.events: List[N] = []                # path condition && condition of every event marker (split_events)
         self.ZERO, self.ONE = self.const(0.0), self.const(1.0)
 
     # -- node construction -------------------------------------------------------------------------------------------------
@@ -732,6 +780,12 @@ class FrameGraph:
                 self.env.pop(k, None)
             self.depth -= 1
             return v
+        if fn == EVENT:
+            if self.loop_stack or self.depth:
+                raise Unsupported("event inside a loop")
+            c = self.ev(n.args[0])
+            self.events.append(c if self.pred is None else self.op("land", self.pred, c))
+            return self.ZERO
         if fn.startswith("gfx_") or fn in NOOP_CALLS:
             for a in n.args:
                 self.ev(a)
@@ -830,6 +884,7 @@ class Region:
 
 class Plan:
     def __init__(self):
+        self.events: List[N] = []
         self.g: FrameGraph = None
         self.nch = 0
         self.outs: Dict[str, N] = {}             # variable (or splK) -> node holding its value at the end of a frame
@@ -929,6 +984,9 @@ def build_plan(prog: Program, nch: int) -> Plan:
     if os.environ.get("ZA_TPAR_NO_BLOCK") and prog.has("block"):
         raise Unsupported("@block present")
     stmts, guard_asts = (list(prog.sections["sample"]), []) if os.environ.get("ZA_TPAR_NO_GUARDS") else split_guards(prog)
+    ev_bodies = []
+    if not os.environ.get("ZA_TPAR_NO_EVENTS"):
+        stmts, ev_bodies = split_events(prog, stmts)
     g = FrameGraph(prog, nch, stmts)
     guards = [g.ev(c) for c in guard_asts]
     if any(not x.su for x in guards) or g.env:
@@ -944,6 +1002,7 @@ def build_plan(prog: Program, nch: int) -> Plan:
     plan.has_block = prog.has("block")
     plan.has_pending = prog.uses("sliderchange", "slider_automate")
     plan.guards = guards
+    plan.events = [e for e in g.events if not (e.kind == "const" and e.val == 0.0)]
     written = list(g.written)
     # variables @sample leaves as they were (x = x) are not state
     for name in list(written):
@@ -1028,7 +1087,7 @@ def build_plan(prog: Program, nch: int) -> Plan:
     # ---- live nodes -------------------------------------------------------------------------------------------------------------
     live: Dict[int, N] = {}
     live_loops: Dict[int, LoopInfo] = {}
-    todo = list(plan.outs.values()) + list(plan.spl_out) + list(guards)
+    todo = list(plan.outs.values()) + list(plan.spl_out) + list(guards) + list(plan.events)
     todo += [x for st_ in plan.stores for x in (st_.addr, st_.value) + ((st_.pred,) if st_.pred is not None else ())]
     todo += [a for a in plan.cells.values()]
 
@@ -1256,7 +1315,7 @@ def build_plan(prog: Program, nch: int) -> Plan:
         return sum(1 for r in all_regions for it in r.items if it[0] == kind and pred(it))
 
     plan.stats = {
-        "nodes": len(live), "uniform": len(plan.uniform), "par": count_items("par"), "shift": count_items("shift"),
+        "nodes": len(live), "uniform": len(plan.uniform), "events": len(plan.events), "par": count_items("par"), "shift": count_items("shift"),
         "scan1": count_items("scan", lambda it: len(it[1].names) == 1), "scan2": count_items("scan", lambda it: len(it[1].names) == 2),
         "spec_loops": count_items("spec"),
         "spec_chains": sum(len(it[1]) for r in all_regions for it in r.items if it[0] == "spec"),
@@ -1360,8 +1419,40 @@ def _schedule(plan: Plan, r: Region, comp_of: Dict[int, Component]):
                 items.append(("site", st_))
 
     remaining = list(pending)
+    later: List[N] = []
+    cone_comps = None
+    if L is None and plan.events:
+        # what the event conditions need comes first, then the cut (the chunk ends before the first frame whose condition holds)
+        cone: Dict[int, N] = {}
+        cone_comps = set()
+        todo = list(plan.events)
+        while todo:
+            x = todo.pop()
+            if x.i in cone or x.kind == "const" or (x.uniform and x.loop is None):
+                continue
+            if x.kind in ("ld", "lout", "lcin") or x.loop is not None:
+                raise Unsupported("event condition reads memory or a loop's result")
+            cone[x.i] = x
+            todo.extend(x.args + x.extra)
+            if x.kind == "st" and x.name in r.st and r.st[x.name] is x:
+                c = comp_of.get(x.i)
+                if c is None:
+                    todo.append(r.outs[x.name])
+                elif id(c) not in cone_comps:
+                    cone_comps.add(id(c))
+                    todo.extend(c.members)
+                    todo.extend(c.inputs)
+        later = [n for n in remaining if n.i not in cone]
+        remaining = [n for n in remaining if n.i in cone]
     guard = 0
-    while remaining or not all(sub_done.values()):
+    while True:
+        if cone_comps is not None and not remaining:
+            items.append(("cut",))
+            cone_comps = None
+            remaining = later
+            continue
+        if not (remaining or not all(sub_done.values())):
+            break
         guard += 1
         if guard > 10 * len(r.nodes) + 100:
             raise AssertionError("scheduler made no progress")
@@ -1401,6 +1492,8 @@ def _schedule(plan: Plan, r: Region, comp_of: Dict[int, Component]):
                 nxt.append(n)
         remaining = nxt
         for s in r.subs:
+            if cone_comps is not None:
+                break
             if not sub_done[s.loop.id] and all(is_done(x) for x in s.ext):
                 if loads_in[s.loop.id] and L is None:
                     flush_sites()
@@ -1409,6 +1502,8 @@ def _schedule(plan: Plan, r: Region, comp_of: Dict[int, Component]):
                 progressed = True
         # scans as soon as their coefficients exist (they are lane-parallel work too)
         for c in comps:
+            if cone_comps is not None and id(c) not in cone_comps:
+                continue
             if not comp_done[id(c)] and c.kind == "scan" and all(is_done(x) for x in c.inputs):
                 items.append(("scan", c))
                 comp_done[id(c)] = True
@@ -1418,7 +1513,8 @@ def _schedule(plan: Plan, r: Region, comp_of: Dict[int, Component]):
         # only switched / serial recurrences can move now: every one of a kind that is ready shares one loop
         ready = []
         for kind in ("spec", "serial"):
-            ready = [c for c in comps if not comp_done[id(c)] and c.kind == kind and all(is_done(x) for x in c.inputs)]
+            ready = [c for c in comps if not comp_done[id(c)] and c.kind == kind and all(is_done(x) for x in c.inputs)
+                     and (cone_comps is None or id(c) in cone_comps)]
             if ready:
                 break
         if not ready:
@@ -1766,7 +1862,9 @@ class _Emit:
         self.has_mem = bool(p.cells or p.stores or p.loads or self.lcell_loops)
         self.has_streams = bool(p.stores)
         self.has_serial = p.has_block or p.has_pending
-        self.has_abort = bool(p.cells or p.stores or p.loads or p.guards or self.lcell_loops)
+        self.has_events = bool(p.events)
+        self.segmented = bool(p.events or p.guards)       # blocks are walked in segments, single frames in between run serially
+        self.has_abort = bool(p.cells or p.stores or p.loads or p.guards or self.lcell_loops or p.events)
         self.early = [s for s in p.stores if s.mode == "early"]
         self.phi_name: Dict[int, str] = {}        # phi / lout node id -> C++ variable
         for L in p.loops:
@@ -1883,8 +1981,10 @@ class _Emit:
             L.append("#define ZT_STAMP(k)")
         if self.has_serial:
             self.emit_serial_fn()
+        if self.segmented:
+            self.emit_frame_fn()
         L.append(f'extern "C" __global__ void __launch_bounds__(64) {km}(ZabBatch b, ZabAudio a) {{')
-        if self.has_serial:
+        if self.has_serial or self.segmented:
             L.append("  ZA_KERNEL_ENTRY();")
         L.append("  const int lane = threadIdx.x;")
         L.append("  const int64_t inst = blockIdx.x;")
@@ -1972,16 +2072,34 @@ class _Emit:
         if tot_s:
             L.append(f"  __shared__ long long zt_site[{tot_s}];     // per address expression of a loop with per-trip cells: a0, stride, previous, lo, hi")
         memo_at = len(L)
-        L.append("  for (int64_t pos = 0; pos < frames; pos += blk) {")
-        L.append("    const int64_t bn = frames - pos < blk ? frames - pos : blk;")
-        L.append("    const int64_t bend = pos + bn;")
-        L.append("    ZT_STAMP(7)")
-        if self.has_serial:
-            self.emit_serial_phase()
+        if self.segmented:
+            # a block is walked in segments: each ends at the block's end or right before a frame an event falls on (or starts
+            # with a frame a guard holds for); that frame runs serially (zt_frame) and the next segment starts behind it, with
+            # the per-block values computed afresh
+            L.append("  int64_t zt_bend = 0, zt_bn = 0, zt_nev = 0;")
+            L.append("  for (int64_t pos = 0; pos < frames; ) {")
+            L.append("    const bool zt_new = pos >= zt_bend;")
+            L.append("    if (zt_new) { zt_bn = frames - pos < blk ? frames - pos : blk; zt_bend = pos + zt_bn; }")
+            L.append("    const int64_t bn = zt_bn;")
+            L.append("    int64_t bend = zt_bend, zt_evf = -1;")
+            L.append("    ZT_STAMP(7)")
+            if self.has_serial:
+                L.append("    if (zt_new)")
+                self.emit_serial_phase()
+        else:
+            L.append("  for (int64_t pos = 0; pos < frames; pos += blk) {")
+            L.append("    const int64_t bn = frames - pos < blk ? frames - pos : blk;")
+            L.append("    const int64_t bend = pos + bn;")
+            L.append("    ZT_STAMP(7)")
+            if self.has_serial:
+                self.emit_serial_phase()
         L.append("    ZT_STAMP(0)")
         self.emit_block_prologue()
         L.append("    ZT_STAMP(1)")
         self.emit_chunk_loop()
+        if self.segmented:
+            L.append("    if (zt_evf < 0) { pos = bend; continue; }")
+            self.emit_serial_frame("    ")
         L.append("  }")
         decl = []
         for lid, (memo, xs) in self.pass_memo.items():
@@ -2018,12 +2136,58 @@ class _Emit:
         secs = list(prog.sections.get("block", [])) if p.has_block else []
         if p.has_pending:
             secs += list(prog.sections.get("slider", []))
+        body = ["    s.samplesblock = (double)bn;", "    s.block_size = (int)bn;"]
+        if p.has_block:
+            body += ["#if ZA_USES_MSG", "    za_msg_begin_block(s);", "#endif", "    za_section_block(s);"]
+        if p.has_pending:
+            body.append("    if (s.pend_change | s.pend_automate | s.pend_automate_end) za_section_slider(s);")
+            body.append("    seen = s.pend_change | s.pend_automate | s.pend_automate_end;")
+            body.append("    s.pend_change = s.pend_automate = s.pend_automate_end = 0;")
+        L.append("// between the blocks: @block and the pending-mask @slider, run by the wavefront with the leaf's section code")
+        self.emit_section_fn("zt_serial", "const int64_t bn", secs, body, [])
+
+    def emit_frame_fn(self):
+        """`zt_frame`: one whole frame of @sample with the leaf's section code -- the frame an event falls on (split_events). The
+        frames before it have left every variable they write in vars[] / mem[] (a leaf with events stores them at the end of every
+        chunk), so the frame runs on that state exactly as the generic kernel's would."""
+        p, L = self.plan, self.L
+        secs = list(self.prog.sections.get("sample", []))
+        body = ["    s.samplesblock = (double)bn;", "    s.block_size = (int)bn;"]
+        body += [f"    s.spl[{ch}] = (double)in_[{ch} * fs + t];" for ch in range(p.nch)]
+        body.append("    za_section_sample(s);")
+        tail = [f"      out_[{ch} * fs + t] = (float)s.spl[{ch}];" for ch in range(p.nch)]
+        L.append("// the frame an event falls on, run by the wavefront with the leaf's section code")
+        self.emit_section_fn("zt_frame", "const int64_t bn, const float* __restrict__ in_, float* __restrict__ out_, const int64_t fs, const int64_t t",
+                             secs, body, tail)
+
+    def emit_serial_frame(self, ind: str):
+        """Frame zt_evf with the section code, then on to the next segment (inside the kernel's loop over pos)."""
+        p, L = self.plan, self.L
+        L.append(f"{ind}// when such frames come thicker than one in 16 this kernel is the wrong tool: the serial code takes the rest")
+        L.append(f"{ind}if (++zt_nev * 16 > zt_evf + 256) {{")
+        self.emit_leave(ind + "  ", "zt_evf")
+        L.append(f"{ind}}}")
+        L.append(f"{ind}__builtin_amdgcn_fence(__ATOMIC_RELEASE, \"workgroup\");")
+        L.append(f"{ind}__builtin_amdgcn_wave_barrier();")
+        L.append(f"{ind}__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"workgroup\");")
+        L.append(f"{ind}(void)zt_frame((const ZabBatch*)__builtin_amdgcn_kernarg_segment_ptr(), inst, lane, bn, in_, out_, a.frame_stride, zt_evf);")
+        L.append(f"{ind}__builtin_amdgcn_fence(__ATOMIC_RELEASE, \"workgroup\");")
+        L.append(f"{ind}__builtin_amdgcn_wave_barrier();")
+        L.append(f"{ind}__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"workgroup\");")
+        L.append(f"{ind}pos = zt_evf + 1;")
+        for n in p.inputs:
+            L.append(f"{ind}x{n.i} = pos + lane < frames ? in_[{int(n.val)} * a.frame_stride + pos + lane] : 0.0f;")
+        L.append(f"{ind}ZT_STAMP(6)")
+        L.append(f"{ind}continue;")
+
+    def emit_section_fn(self, fname: str, params: str, secs, body: List[str], tail: List[str]):
+        p, L = self.plan, self.L
+        prog = self.prog
         rd = sorted(prog.vars[nm] for nm in _read_names(prog, secs) if nm in prog.vars)
         wr = sorted(prog.vars[nm] for nm in (_assigned_names(prog, secs) | _outarg_names(prog, secs)) if nm in prog.vars)
         if os.environ.get("ZA_TPAR_FULL_STATE"):
             rd = wr = list(range(prog.nvars))
-        L.append("// between the blocks: @block and the pending-mask @slider, run by the wavefront with the leaf's section code")
-        L.append("static __device__ __attribute__((noinline)) unsigned long long zt_serial(const ZabBatch* __restrict__ zt_pb, const int64_t inst, const int64_t bn, const int lane) {")
+        L.append(f"static __device__ __attribute__((noinline)) unsigned long long {fname}(const ZabBatch* __restrict__ zt_pb, const int64_t inst, const int lane, {params}) {{")
         L.append("  const ZabBatch& b = *zt_pb;")
         L.append("  unsigned long long seen = 0;")
         L.append("#ifdef ZA_REPLICAS")
@@ -2045,18 +2209,9 @@ class _Emit:
         L.append("#ifdef ZA_REPLICAS")
         L.append("    s.replica = lane != 0 ? 1u : 0u; s.rep_i = (uint32_t)lane; s.rep_n = 64u; s.rep_stride = 1u;")
         L.append("#endif")
-        L.append("    s.samplesblock = (double)bn;")
-        L.append("    s.block_size = (int)bn;")
-        if p.has_block:
-            L.append("#if ZA_USES_MSG")
-            L.append("    za_msg_begin_block(s);")
-            L.append("#endif")
-            L.append("    za_section_block(s);")
-        if p.has_pending:
-            L.append("    if (s.pend_change | s.pend_automate | s.pend_automate_end) za_section_slider(s);")
-            L.append("    seen = s.pend_change | s.pend_automate | s.pend_automate_end;")
-            L.append("    s.pend_change = s.pend_automate = s.pend_automate_end = 0;")
+        L.extend(body)
         L.append("    if (lane == 0) {")
+        L.extend(tail)
         for k0 in range(0, len(wr), 8):
             L.append("      " + " ".join(f"b.vars[{k} * b.var_se + inst * b.var_si] = s.v[{k}];" for k in wr[k0:k0 + 8]))
         L.append("#define ZA_X(k) b.sliders[(k) * b.sl_se + inst * b.sl_si] = s.sl[k];")
@@ -2081,7 +2236,7 @@ class _Emit:
         else:
             L.append("    if (pos == 0 && (b.pend[inst] | b.pend[b.n_pad + inst] | b.pend[2 * (int64_t)b.n_pad + inst]) != 0ull) {")
         L.append("      // (the ZabBatch the function reads is this kernel's own first argument, where it lies in the kernarg segment)")
-        L.append("      zt_pend_seen |= zt_serial((const ZabBatch*)__builtin_amdgcn_kernarg_segment_ptr(), inst, bn, lane);")
+        L.append("      zt_pend_seen |= zt_serial((const ZabBatch*)__builtin_amdgcn_kernarg_segment_ptr(), inst, lane, bn);")
         L.append("      __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"workgroup\");")
         L.append("      __builtin_amdgcn_wave_barrier();")
         L.append("      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"workgroup\");")
@@ -2121,8 +2276,9 @@ class _Emit:
             L.append("    }")
             L.append("    __syncthreads();")
         for gn in p.guards:
-            L.append(f"    if (za_truthy({ref(gn)})) {{   // a rare-event branch the lowering left out (tpar.split_guards) is due: the serial code runs it")
-            self.emit_leave("      ", "pos")
+            L.append(f"    if (za_truthy({ref(gn)})) {{   // a rare-event branch the lowering left out (tpar.split_guards) is due: this frame runs with the section code")
+            L.append("      zt_evf = pos;")
+            self.emit_serial_frame("      ")
             L.append("    }")
         if self.has_mem:
             L.append("    int64_t zt_high = b.mem_high[inst], zt_hc = 0;")
@@ -2140,6 +2296,15 @@ class _Emit:
                 L.append("    }")
         for Lp in self.lcell_loops:
             self.emit_address_pass(Lp)
+        self.has_lbox = bool(p.stores) and any(self.pass_keys(Lp) for Lp in self.lcell_loops)
+        if self.has_lbox:
+            # per-trip cells are read as they stand when the block begins (or live in LDS for its length): a delay-line write
+            # that lands among them would have to be seen by the loop of the very next frame -- not a case for this kernel
+            L.append("    int64_t lmin = INT64_MAX, lmax = -1;     // bounding box of the loops' per-trip cells")
+            for Lp in self.lcell_loops:
+                nk, so = len(self.pass_keys(Lp)), self.site_off[Lp.id]
+                for j in range(nk):
+                    L.append(f"    {{ const int64_t lo = zt_site[{so + 3 * nk + j}], hi = zt_site[{so + 4 * nk + j}]; if (hi >= lo) {{ lmin = lo < lmin ? lo : lmin; lmax = hi > lmax ? hi : lmax; }} }}")
         if self.cell_loops:
             L.append("    {   // per-trip cells into LDS for the length of the block (a loop whose cells do not fit keeps them in memory)")
             L.append("      int zoff = 0;")
@@ -2324,9 +2489,10 @@ class _Emit:
         p, L, ref = self.plan, self.L, self.ref
         cname = self.cname
         L.append("    for (int64_t f0 = pos; f0 < bend; f0 += 64) {")
-        L.append("    const int tn = (int)(bend - f0 < 64 ? bend - f0 : 64);")
-        L.append("    const int last = tn - 1;")
-        L.append("    const bool valid = lane < tn;")
+        q = "" if self.has_events else "const "
+        L.append(f"    {q}int tn = (int)(bend - f0 < 64 ? bend - f0 : 64);")
+        L.append(f"    {q}int last = tn - 1;")
+        L.append(f"    {q}bool valid = lane < tn;")
         for n in p.inputs:
             L.append(f"    const double n{n.i} = (double)x{n.i};")
         L.append("    {   // the next chunk's audio (of the next block, at a block's end)")
@@ -2352,7 +2518,10 @@ class _Emit:
                 L.append(f"      zt_snap[{k}] = {c};")
             L.append("    }")
             L.append("    bool zt_bad = false, zt_badl = false;")
-        L.append("    const bool fin = f0 + 64 >= bend;   // the block's last chunk: its last frame leaves every written variable as the script would")
+        if self.has_events:
+            L.append("    const bool fin = true;   // any chunk may be a segment's last (an event in the next one): each leaves every written variable in memory")
+        else:
+            L.append("    const bool fin = f0 + 64 >= bend;   // the block's last chunk: its last frame leaves every written variable as the script would")
         self.avail = {n.i for n in p.inputs}
         self.raw_issued: set = set()
         self.unit_done: set = set()
@@ -2361,6 +2530,7 @@ class _Emit:
         self.finals = [(name, o) for name, o in p.outs.items() if name != RNG_INDEX and name not in self.hname]
         self.finals += [(f"spl{ch}", p.spl_out[ch]) for ch in range(p.nch) if f"spl{ch}" not in p.outs]
         self.pending: List[tuple] = []
+        self.before_cut = self.has_events
         self.emit_region(p.top, "    ")
         L.append("    ZT_STAMP(2)")
         if self.has_abort:
@@ -2536,6 +2706,8 @@ class _Emit:
             L.append(f"{ind}  zt_bad |= zhi{j} >= mcap;")
             if self.cell_addrs:
                 L.append(f"{ind}  zt_bad |= zlo{j} <= cmax && zhi{j} >= cmin;")
+            if self.has_lbox:
+                L.append(f"{ind}  zt_bad |= zlo{j} <= lmax && zhi{j} >= lmin;")
             L.append(f"{ind}}}")
             return
         L.append(f"{ind}// delay-line write {j}: must advance by one cell per frame (at most one wrap inside the chunk)")
@@ -2548,6 +2720,8 @@ class _Emit:
         cond = f"__popcll(sm{j}) > 1 || s0{j} + sk{j} > mcap || (sk{j} < tn && s1{j} + (tn - sk{j}) > mcap)"
         if self.cell_addrs:
             cond += f" || (s0{j} <= cmax && s0{j} + sk{j} > cmin) || (sk{j} < tn && s1{j} <= cmax && s1{j} + (tn - sk{j}) > cmin)"
+        if self.has_lbox:
+            cond += f" || (s0{j} <= lmax && s0{j} + sk{j} > lmin) || (sk{j} < tn && s1{j} <= lmax && s1{j} + (tn - sk{j}) > lmin)"
         L.append(f"{ind}const bool zsb{j} = {cond};")
         L.append(f"{ind}zt_bad |= {'zsu%d && ' % j if st_.pred is not None else ''}zsb{j};")
 
@@ -2656,6 +2830,16 @@ class _Emit:
                 self.emit_site(it[1], ind)
                 sites_open = True
                 continue
+            if kind == "cut":
+                cond = " || ".join(f"za_truthy({ref(e)})" for e in p.events)
+                L.append(f"{ind}{{   // the first frame an event falls on ends the segment: the frames before it are this chunk")
+                L.append(f"{ind}  const uint64_t m = __ballot(valid && ({cond}));")
+                L.append(f"{ind}  if (m) {{ const int e = (int)__ffsll((long long)m) - 1; zt_evf = f0 + e; bend = zt_evf; tn = e; last = e - 1; valid = lane < tn; }}")
+                L.append(f"{ind}}}")
+                L.append(f"{ind}if (tn == 0) break;")
+                self.before_cut = False
+                self.retire()
+                continue
             if kind == "loop":
                 if top:
                     L.append(f"{ind}ZT_STAMP(2)")
@@ -2710,7 +2894,7 @@ class _Emit:
                     L.append(f"{ind}ZT_STAMP(4)")
             else:
                 raise AssertionError(kind)
-            if top:
+            if top and not self.before_cut:
                 self.retire()
         if sites_open:
             self.emit_site_pairs(ind)
@@ -3525,6 +3709,8 @@ def _simulate(self: Plan, vars0: Dict[str, float], x: np.ndarray, sliders=None, 
     one block (@block, if the script has one, is not run here).
     Returns (y float32 [nch, frames], vars after {name: value}, spl after {k: value}). Raises TparAbort when a chunk breaks
     one of the run-time conditions of the lowering (the kernel hands such a launch to the serial code)."""
+    if self.events:
+        raise NotImplementedError("plans with events run a frame of the script's own section code: device only")
     memv = np.zeros(1 << 16) if mem is None else np.array(mem, dtype=np.float64)
     mcap = len(memv)
     mem_high = [0]
@@ -3601,6 +3787,8 @@ def _simulate(self: Plan, vars0: Dict[str, float], x: np.ndarray, sliders=None, 
             caps[nm][tn:] = cur[nm]
             val[reg.st[nm].i] = caps[nm]
 
+    lbox = [1 << 62, -1]          # bounding box of the loops' per-trip cells (address_pass)
+
     def run_items(reg: Region, carry, f0, tn, sites):
         """One chunk's (or one trip's) schedule. carry: state name -> value before the chunk."""
         for it in reg.items:
@@ -3613,6 +3801,8 @@ def _simulate(self: Plan, vars0: Dict[str, float], x: np.ndarray, sliders=None, 
                     si = {"A": A, "on": on, "lo": int(A[on].min()) if on.any() else 0, "hi": int(A[on].max()) if on.any() else -1}
                     if si["hi"] >= mcap or any(si["lo"] <= a <= si["hi"] for a in cell_addr.values()):
                         raise TparAbort(f0, "a conditional write leaves the arena or runs over a mem[] cell")
+                    if si["lo"] <= lbox[1] and si["hi"] >= lbox[0]:
+                        raise TparAbort(f0, "a conditional write lands among a loop's per-trip cells")
                     sites[st_.j] = si
                     continue
                 live_site = st_.pred is None or bool(_truthy(np.float64(uni(st_.pred, "store condition"))))
@@ -3626,6 +3816,8 @@ def _simulate(self: Plan, vars0: Dict[str, float], x: np.ndarray, sliders=None, 
                         raise TparAbort(f0, "a delay-line write does not advance by one cell per frame (or leaves the arena)")
                     if any(lo <= a <= hi for a in cell_addr.values() for lo, hi in ((A[:tn].min(), A[:tn].max()),)):
                         raise TparAbort(f0, "a delay line runs over a mem[] cell")
+                    if A[:tn].min() <= lbox[1] and A[:tn].max() >= lbox[0]:
+                        raise TparAbort(f0, "a delay line runs over a loop's per-trip cells")
                 if len(sites) == len(self.stores):         # every span known: no two writes may touch one cell
                     spans = {}
                     for s2 in self.stores:
@@ -3833,6 +4025,9 @@ def _simulate(self: Plan, vars0: Dict[str, float], x: np.ndarray, sliders=None, 
             if any(b_ - a_ != st for a_, b_ in zip(s, s[1:])) or max(s) >= mcap:
                 raise TparAbort(0, "a per-trip cell address does not step evenly through the trips (or leaves the arena)")
             desc[key] = (s[0], st, min(s), max(s))
+        for (_, _, lo_, hi_) in desc.values():
+            if hi_ >= lo_:
+                lbox[0], lbox[1] = min(lbox[0], lo_), max(lbox[1], hi_)
         keys = list(desc)
         for i1 in range(len(keys)):
             for i2 in range(i1 + 1, len(keys)):
