@@ -44,6 +44,18 @@ typedef ZaState<ZA_NV, true> ZaSLm;     // the process kernel's second body: mem
 // kept from reordering them; __syncthreads() would also wait for the tile's output stores to reach memory (vmcnt(0)).
 __device__ __forceinline__ void za_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// Leaves with FFT builtins: their transforms are latency-bound (one wavefront per instance walks a chain of dependent memory and
+// LDS round trips), so resident wavefronts are what hides it. Left alone the compiler takes 270 - 290 registers for these
+// kernels -- one wavefront per SIMD; capped at 256 it is two (measured: tools/fft_bench.py).
+#if ZA_USES_FFT && !defined(ZA_WAVES_PER_EU)
+#define ZA_WAVES_PER_EU ZA_FFT_WAVES_PER_EU      /* zart_fft.h */
+#endif
+#if defined(ZA_WAVES_PER_EU) && ZA_WAVES_PER_EU > 0
+#define ZA_OCC __attribute__((amdgpu_waves_per_eu(ZA_WAVES_PER_EU)))
+#else
+#define ZA_OCC
+#endif
+
 #ifndef ZA_KERNEL_ENTRY
 #define ZA_KERNEL_ENTRY() (void)0      /* leaves with FFT builtins reset their LDS twiddle flag here (zart_fft.h) */
 #endif
@@ -304,7 +316,7 @@ __device__ __forceinline__ void za_process_body(const ZabBatch& b, const ZabAudi
   }
 }
 
-extern "C" __global__ void __launch_bounds__(64) ZA_KERNEL(process)(ZabBatch b, ZabAudio a) {
+extern "C" __global__ void __launch_bounds__(64) ZA_OCC ZA_KERNEL(process)(ZabBatch b, ZabAudio a) {
   ZA_KERNEL_ENTRY();
 #if ZA_NCH > 0 && defined(ZA_REPLICAS)
   extern __shared__ double za_dyn_lds[];                 // [arena window: lmem_words x ipw doubles][tile]

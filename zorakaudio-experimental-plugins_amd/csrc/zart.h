@@ -25,7 +25,13 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define ZA_FN __device__ inline __attribute__((always_inline))
+// (FFT leaves are built with -DZA_INLINE_ALL, zajit/build.py: the transform code inlined into its kernels, so that the kernels'
+//  register cap covers it. Never together with outlined user functions, whose whole point is not to be inlined.)
+#if defined(ZA_INLINE_ALL) && !(defined(ZA_OUTLINE_FNS) && ZA_OUTLINE_FNS)
+#define ZA_NOINLINE __device__ inline __attribute__((always_inline))
+#else
 #define ZA_NOINLINE __device__ __attribute__((noinline))
+#endif
 #else
 #define ZA_FN static inline __attribute__((always_inline))
 #define ZA_NOINLINE static __attribute__((noinline))

@@ -136,6 +136,9 @@ ZA_FN bool za_fft_region(S& s, double baseD, int64_t span, int64_t& base, int64_
 #define ZA_F(a) s.fft[(a) * s.fft_stride]
 
 #if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+#ifndef ZA_FFT_WAVES_PER_EU
+#define ZA_FFT_WAVES_PER_EU 2
+#endif
 // twiddles (cos, sin)(2 pi j / ZA_FFT_LDS_POINTS), j < ZA_FFT_LDS_POINTS / 2, staged in LDS by the first cooperative transform of
 // a workgroup. LDS is neither cleared nor private between launches, so every kernel of an FFT leaf resets the flag on
 // entry (ZA_KERNEL_ENTRY in zab_generic.hip.h) instead of trusting whatever an earlier workgroup left behind.
@@ -151,36 +154,83 @@ __device__ __forceinline__ int64_t za_readlane64(int64_t v, int l) {
   return ((int64_t)hi << 32) | (uint32_t)lo;
 }
 // The radix-2 passes of an nlp-point transform whose points sit bit-reversed in `buf` (LDS), butterflies spread over the nact
-// participating lanes. Four independent butterflies per trip: all their LDS reads are issued before the first store, which
-// the compiler cannot do by itself (it must assume the stores alias the next reads).
-__device__ __forceinline__ void za_fft_lds_stages(double* buf, const double* tw, int nlp, int sign, int rank, int nact) {
-  for (int len = 2; len <= nlp; len <<= 1) {
-    const int half = len >> 1, step = ZA_FFT_LDS_POINTS / len;
-    for (int idx0 = rank; idx0 < (nlp >> 1); idx0 += 4 * nact) {
-      double ar[4], ai[4], br[4], bi[4], wr[4], wi[4];
-      int pa[4];
+// participating lanes -- taken R passes at a time: a lane holds the 2^R points that R consecutive passes combine among
+// themselves, runs those passes on them in registers and writes them back once. Every butterfly is the radix-2 one, with the
+// twiddle and the order of operations the one-pass-at-a-time form uses, hence the same bits; what changes is the traffic: LDS
+// is what bounds these transforms (a butterfly moves 80 bytes per pass for 10 flops), and a point now makes one round trip
+// per three passes (46 reads and writes per 12 butterflies instead of 120) behind a third of the barriers.
+template <int R>
+__device__ __forceinline__ void za_fft_lds_pass(double* buf, const double* tw, int nlp, int h0, int sign, int rank, int nact) {
+  constexpr int Q = 1 << R;                      // points per item
+  constexpr int U = R == 3 ? 1 : (R == 2 ? 2 : 4);   // items per trip: all their LDS reads are issued before the first store
+  const int items = nlp >> R;
+  const int hb = 31 - __builtin_clz((unsigned)h0);
+  for (int idx0 = rank; idx0 < items; idx0 += U * nact) {
+    double xr[U][Q], xi[U][Q], wr[U][Q - 1], wi[U][Q - 1];
+    int base[U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int idx = idx0 + u * nact;
-        const int ix = idx < (nlp >> 1) ? idx : 0;
-        const int j = ix & (half - 1), i = ((ix - j) << 1) + j;          // butterfly (i, i + half) of group ix / half
-        pa[u] = idx < (nlp >> 1) ? 2 * i : -1;
-        wr[u] = tw[2 * j * step]; wi[u] = tw[2 * j * step + 1];
-        ar[u] = buf[2 * i]; ai[u] = buf[2 * i + 1];
-        br[u] = buf[2 * (i + half)]; bi[u] = buf[2 * (i + half) + 1];
+    for (int u = 0; u < U; ++u) {
+      const int idx = idx0 + u * nact;
+      const int ix = idx < items ? idx : 0;
+      const int j = ix & (h0 - 1);
+      const int b0 = ((ix >> hb) << (hb + R)) + j;        // points b0 + k * h0, k < Q
+      base[u] = idx < items ? b0 : -1;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int step = ZA_FFT_LDS_POINTS >> (hb + r + 1);       // pass r of this group: len = 2 * h0 << r
+#pragma unroll
+        for (int m = 0; m < (1 << r); ++m) {
+          const int jr = j + m * h0;
+          wr[u][(1 << r) - 1 + m] = tw[2 * jr * step];
+          wi[u][(1 << r) - 1 + m] = tw[2 * jr * step + 1];
+        }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const double w_i = sign < 0 ? -wi[u] : wi[u];
-        const double tr = br[u] * wr[u] - bi[u] * w_i, ti = br[u] * w_i + bi[u] * wr[u];
-        if (pa[u] >= 0) {
-          const int a = pa[u], b = pa[u] + 2 * half;
-          buf[a] = ar[u] + tr; buf[a + 1] = ai[u] + ti;
-          buf[b] = ar[u] - tr; buf[b + 1] = ai[u] - ti;
+      for (int k = 0; k < Q; ++k) {
+        xr[u][k] = buf[2 * (b0 + k * h0)];
+        xi[u][k] = buf[2 * (b0 + k * h0) + 1];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int k = 0; k < Q; ++k) {
+          if (k & (1 << r)) continue;
+          const int c = k | (1 << r), t = (1 << r) - 1 + (k & ((1 << r) - 1));
+          const double w_i = sign < 0 ? -wi[u][t] : wi[u][t];
+          const double tr = xr[u][c] * wr[u][t] - xi[u][c] * w_i, ti = xr[u][c] * w_i + xi[u][c] * wr[u][t];
+          const double ar = xr[u][k], ai = xi[u][k];
+          xr[u][k] = ar + tr; xi[u][k] = ai + ti;
+          xr[u][c] = ar - tr; xi[u][c] = ai - ti;
+        }
+      }
+      if (base[u] >= 0) {
+#pragma unroll
+        for (int k = 0; k < Q; ++k) {
+          buf[2 * (base[u] + k * h0)] = xr[u][k];
+          buf[2 * (base[u] + k * h0) + 1] = xi[u][k];
         }
       }
     }
-    __builtin_amdgcn_wave_barrier();
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ void za_fft_lds_stages(double* buf, const double* tw, int nlp, int sign, int rank, int nact) {
+  int rem = 31 - __builtin_clz((unsigned)nlp), h = 1;
+  while (rem > 0) {
+#ifdef ZA_FFT_RADIX2_PASSES
+    const int R = 1;
+#else
+    const int R = rem % 3 == 0 ? 3 : (rem == 1 ? 1 : 2);      // 10 passes = 2 + 2 + 3 + 3, 11 = 2 + 3 + 3 + 3
+#endif
+    if (R == 3) za_fft_lds_pass<3>(buf, tw, nlp, h, sign, rank, nact);
+    else if (R == 2) za_fft_lds_pass<2>(buf, tw, nlp, h, sign, rank, nact);
+    else za_fft_lds_pass<1>(buf, tw, nlp, h, sign, rank, nact);
+    h <<= R;
+    rem -= R;
   }
 }
 
@@ -189,7 +239,7 @@ __device__ __forceinline__ void za_fft_lds_stages(double* buf, const double* tw,
 // Real transforms (n reals = n / 2 complex points, so n up to 2 * ZA_FFT_COOP_MAX) and convolve_c (n = complex pairs, base2 = its
 // second operand) take the same route; the arithmetic per element is the serial form's, hence the same bits.
 template <class S>
-__device__ __noinline__ bool za_fft_coop(S& s, bool ok, int64_t base, int n, int op, int64_t base2 = 0) {
+ZA_NOINLINE bool za_fft_coop(S& s, bool ok, int64_t base, int n, int op, int64_t base2 = 0) {
   __shared__ double buf[2 * ZA_FFT_LDS_POINTS];
   double* const tw = za_fft_tw;
   const bool is_real = op == ZA_COOP_FFT_REAL || op == ZA_COOP_IFFT_REAL;
@@ -281,20 +331,21 @@ __device__ __noinline__ bool za_fft_coop(S& s, bool ok, int64_t base, int n, int
         continue;
       }
       const int sign = (op == ZA_COOP_FFT || op == ZA_COOP_FFT_NAT) ? -1 : +1;
+      constexpr int ZA_GU = P / 64 < 16 ? (P / 64 < 1 ? 1 : P / 64) : 16;      // a full wavefront fetches a block in one batch of loads
       for (int b = 0; b < B; ++b) {
         // block b of the bit-reversed array: its position m takes natural element k = bitrev_P(m) * B + bitrev_q(b)
         const int rb = (int)za_bitrev((uint32_t)b, q);
-        for (int t0 = rank; t0 < P; t0 += 8 * nact) {
-          double vr[8], vi[8];
+        for (int t0 = rank; t0 < P; t0 += ZA_GU * nact) {
+          double vr[ZA_GU], vi[ZA_GU];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
+          for (int u = 0; u < ZA_GU; ++u) {
             const int t = t0 + u * nact;
             const int k = (t < P ? t : 0) * B + rb;
             const int src = op == ZA_COOP_IFFT ? (int)za_fft_iperm[nl + k] : k;  // ifft: the position that holds bin k
             vr[u] = ZA_G(2 * src); vi[u] = ZA_G(2 * src + 1);
           }
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
+          for (int u = 0; u < ZA_GU; ++u) {
             const int t = t0 + u * nact;
             if (t < P) {
               const uint32_t m = za_bitrev((uint32_t)t, PB);
@@ -311,37 +362,54 @@ __device__ __noinline__ bool za_fft_coop(S& s, bool ok, int64_t base, int n, int
         __builtin_amdgcn_wave_barrier();
       }
       ZA_SLICE_SYNC();
-      // the last q passes (len = 2P [, 4P]) on the B elements j, j + P, ... of the scratch, from registers
-      for (int j = rank; j < P; j += nact) {
-        double er[4], ei[4];
+      // the last q passes (len = 2P [, 4P]) on the B elements j, j + P, ... of the scratch, from registers: four columns per
+      // trip, every load of the trip (16 values and their twiddles) issued before the first store -- one memory latency per
+      // trip, and a lane makes P / 256 trips
+      constexpr int JU = 4;
+      for (int j0 = rank; j0 < P; j0 += JU * nact) {
+        double er[JU][4], ei[JU][4], w1r[JU], w1i[JU], w2r[JU], w2i[JU], w3r[JU], w3i[JU];
+        int dst[JU][4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (k < B) { er[k] = ZA_S(2 * (j + P * k)); ei[k] = ZA_S(2 * (j + P * k) + 1); }
-        auto bfly = [&](int a, int c, int widx) __attribute__((always_inline)) {   // (a, c) <- (a + w c, a - w c), w = W_MAX^widx
-          const double wr = za_fft_cos[widx], wi0 = za_fft_sin[widx];
-          const double w_i = sign < 0 ? -wi0 : wi0;
-          const double tr = er[c] * wr - ei[c] * w_i, ti = er[c] * w_i + ei[c] * wr;
-          const double xr = er[a], xi = ei[a];
-          er[a] = xr + tr; ei[a] = xi + ti;
-          er[c] = xr - tr; ei[c] = xi - ti;
-        };
-        {
-          const int st = ZA_FFT_MAX / (2 * P);                 // len = 2P, half = P: butterflies (j, j + P) [and (j + 2P, j + 3P)]
-          bfly(0, 1, j * st);
-          if (B == 4) bfly(2, 3, j * st);
-        }
-        if (B == 4) {
-          const int st = ZA_FFT_MAX / (4 * P);                 // len = 4P, half = 2P: (j, j + 2P) and (j + P, j + 3P)
-          bfly(0, 2, j * st);
-          bfly(1, 3, (j + P) * st);
-        }
+        for (int u = 0; u < JU; ++u) {
+          const int j = j0 + u * nact < P ? j0 + u * nact : j0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (k < B) {
-            const int pbin = j + P * k;                        // natural index of the result
-            const int dst = op == ZA_COOP_FFT ? (int)za_fft_iperm[nl + pbin] : pbin;   // fft alone: stored in WDL_fft_permute order
-            ZA_G(2 * dst) = er[k]; ZA_G(2 * dst + 1) = ei[k];
+          for (int k = 0; k < 4; ++k)
+            if (k < B) {
+              er[u][k] = ZA_S(2 * (j + P * k)); ei[u][k] = ZA_S(2 * (j + P * k) + 1);
+              const int pbin = j + P * k;                      // natural index of the result
+              dst[u][k] = op == ZA_COOP_FFT ? (int)za_fft_iperm[nl + pbin] : pbin;   // fft alone: stored in WDL_fft_permute order
+            }
+          const int st1 = ZA_FFT_MAX / (2 * P), st2 = ZA_FFT_MAX / (4 * P);
+          w1r[u] = za_fft_cos[j * st1]; w1i[u] = za_fft_sin[j * st1];
+          if (B == 4) {
+            w2r[u] = za_fft_cos[j * st2]; w2i[u] = za_fft_sin[j * st2];
+            w3r[u] = za_fft_cos[(j + P) * st2]; w3i[u] = za_fft_sin[(j + P) * st2];
           }
+        }
+#pragma unroll
+        for (int u = 0; u < JU; ++u) {
+          auto bfly = [&](int a, int c, double wr, double wi0) __attribute__((always_inline)) {   // (a, c) <- (a + w c, a - w c)
+            const double w_i = sign < 0 ? -wi0 : wi0;
+            const double tr = er[u][c] * wr - ei[u][c] * w_i, ti = er[u][c] * w_i + ei[u][c] * wr;
+            const double xr = er[u][a], xi = ei[u][a];
+            er[u][a] = xr + tr; ei[u][a] = xi + ti;
+            er[u][c] = xr - tr; ei[u][c] = xi - ti;
+          };
+          bfly(0, 1, w1r[u], w1i[u]);                          // len = 2P, half = P: butterflies (j, j + P) [and (j + 2P, j + 3P)]
+          if (B == 4) bfly(2, 3, w1r[u], w1i[u]);
+          if (B == 4) {                                        // len = 4P, half = 2P: (j, j + 2P) and (j + P, j + 3P)
+            bfly(0, 2, w2r[u], w2i[u]);
+            bfly(1, 3, w3r[u], w3i[u]);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < JU; ++u) {
+          if (j0 + u * nact < P) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (k < B) { ZA_G(2 * dst[u][k]) = er[u][k]; ZA_G(2 * dst[u][k] + 1) = ei[u][k]; }
+          }
+        }
       }
       ZA_SLICE_SYNC();
 #undef ZA_S

@@ -254,7 +254,11 @@ def build_module(jsfx_path, name: Optional[str] = None, force=False, verbose=Fal
     GEN.mkdir(exist_ok=True)
     src = GEN / f"{prog.name}_module.hip"
     so = LIB / f"libzab_{prog.name}.so"
-    leaf_flags = LEAF_FLAGS.get(prog.name, [])
+    leaf_flags = list(LEAF_FLAGS.get(prog.name, []))
+    if unit.defines.get("ZA_USES_FFT") == "1" and unit.defines.get("ZA_OUTLINE_FNS") != "1" and not os.environ.get("ZA_FFT_CALLS"):
+        # FFT leaves: the transform code inlined into its kernels, so that the kernels' register cap (ZA_OCC: two wavefronts per
+        # SIMD) covers it -- a function that is called keeps its own, larger allocation and the kernel inherits it
+        leaf_flags.append("-DZA_INLINE_ALL")
     text = module_source(unit) + (f"// leaf build flags: {' '.join(leaf_flags)}\n" if leaf_flags else "")
     deps = [CSRC / "zart.h", CSRC / "zab_generic.hip.h", CSRC / "zab_module.h"]
     if "zart_tpar.h" in text:

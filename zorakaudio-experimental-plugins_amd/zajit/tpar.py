@@ -1966,6 +1966,13 @@ class _Emit:
         L.append(f"#define ZT_SPEC_MAX {SPEC_MAX}")
         L.append("#endif")
         L.append(f"#define ZT_SPEC_TOL {SPEC_TOL!r}")
+        L.append("#ifndef ZT_SECTION_FN")
+        L.append("#ifdef ZA_INLINE_ALL")
+        L.append("#define ZT_SECTION_FN __device__ inline __attribute__((always_inline))")
+        L.append("#else")
+        L.append("#define ZT_SECTION_FN __device__ __attribute__((noinline))")
+        L.append("#endif")
+        L.append("#endif")
         L.append("#ifndef ZT_UNI")
         L.append("#define ZT_UNI(x) zt_uniform(x)")
         L.append("#endif")
@@ -1983,7 +1990,7 @@ class _Emit:
             self.emit_serial_fn()
         if self.segmented:
             self.emit_frame_fn()
-        L.append(f'extern "C" __global__ void __launch_bounds__(64) {km}(ZabBatch b, ZabAudio a) {{')
+        L.append(f'extern "C" __global__ void __launch_bounds__(64) ZA_OCC {km}(ZabBatch b, ZabAudio a) {{')
         if self.has_serial or self.segmented:
             L.append("  ZA_KERNEL_ENTRY();")
         L.append("  const int lane = threadIdx.x;")
@@ -2187,7 +2194,7 @@ class _Emit:
         wr = sorted(prog.vars[nm] for nm in (_assigned_names(prog, secs) | _outarg_names(prog, secs)) if nm in prog.vars)
         if os.environ.get("ZA_TPAR_FULL_STATE"):
             rd = wr = list(range(prog.nvars))
-        L.append(f"static __device__ __attribute__((noinline)) unsigned long long {fname}(const ZabBatch* __restrict__ zt_pb, const int64_t inst, const int lane, {params}) {{")
+        L.append(f"static ZT_SECTION_FN unsigned long long {fname}(const ZabBatch* __restrict__ zt_pb, const int64_t inst, const int lane, {params}) {{")
         L.append("  const ZabBatch& b = *zt_pb;")
         L.append("  unsigned long long seen = 0;")
         L.append("#ifdef ZA_REPLICAS")
