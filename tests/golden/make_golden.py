@@ -93,6 +93,9 @@ CASES = [
     ("BedRock", "alt", {0: 2, 1: 100, 2: 80, 3: 10, 4: 90}, 2048, 512),
     ("Alias", "alt", {0: 80, 1: 0, 2: 100, 3: 60, 4: 400, 6: 24, 7: 0, 8: 3, 11: 1}, 2048, 512),
     ("NeuroCV", "alt", {0: 2, 3: 2, 4: 20, 6: 0.2, 7: 5, 8: 3}, 1024, 256),
+    # rare heavy branches (zajit/tpar.py events): a body that reads the frame before / a period that lands on chunk starts
+    ("fx_evtkat", "default", {}, 2000, 500), ("fx_evtkat", "dense", {0: 17, 1: 0.9}, 1500, 512),
+    ("fx_evtkat2", "default", {}, 2000, 500), ("fx_evtkat2", "slow", {0: 333, 1: 0.2}, 1500, 512),
 ]
 
 

@@ -12,7 +12,7 @@ from conftest import AUDIO_EPS, GOLDEN, SCALAR_EPS, assert_state_close, dbfs, go
 pytestmark = pytest.mark.gpu
 
 CASES = sorted(p.stem for p in GOLDEN.glob("*_*.npz")
-               if p.stem.endswith(("_default", "_alt", "_dense")) and not p.stem.startswith("DDT"))
+               if p.stem.endswith(("_default", "_alt", "_dense", "_slow")) and not p.stem.startswith("DDT"))
 
 
 @pytest.mark.parametrize("ipw", ["auto", "64", "4"])

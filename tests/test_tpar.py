@@ -18,7 +18,7 @@ REF_PLUGINS = Path("/root/reference/plugins")
 FIXTURES = ROOT / "tests" / "fixtures"
 TPAR_CATALOG = ["ADS", "ATTACK", "RTT", "SaliencePush", "BedRock", "DPT", "Roomalizer", "EasyExpander", "SOMA"]
 # leaves whose @sample has a rare heavy branch (tpar.split_events): the frame it falls on runs with the serial section code
-TPAR_EVENT_LEAVES = ["PsychoConvolver", "PsychoConvolver+IR", "fx_stft", "fx_stft4k", "fx_stftparts", "fx_convkat", "fx_mapkat", "fx_ringio"]
+TPAR_EVENT_LEAVES = ["PsychoConvolver", "PsychoConvolver+IR", "NeuroCV", "fx_evtkat", "fx_evtkat2", "fx_stft", "fx_stft4k", "fx_stftparts", "fx_convkat", "fx_mapkat", "fx_ringio"]
 TPAR_BLOCK_CATALOG = ["ERBTilt", "SpectralStabilizer", "TSEQ"]        # leaves with @block: the kernel runs it between the blocks
 TPAR_FIXTURES = ["fx_dynkat_default", "fx_dynkat_hot", "fx_randkat_default", "fx_ringkat_default", "fx_ringkat_long",
                  "fx_delaytaps_default", "fx_delaytaps_far"]
@@ -127,6 +127,11 @@ def test_rare_heavy_branches_become_events():
     # nested in a block-constant conditional: the event's condition carries the path's
     plan, msg = _plan_of_text("on ? ( buf[n] = spl0; n += 1; n >= 256 ? ( fft(buf, 256); n = 0; ); ); spl0 = buf[0];")
     assert plan is not None and plan.stats["events"] == 1, msg
+    # a body that reads what the frame before left in a variable the rest of the frame writes first: every chunk stores it
+    plan, msg = _plan_of_text("n += 1; n >= 64 ? ( y = t + 1; fft(buf, 64); n = 0; ); t = spl0 * 2; spl0 = y;")
+    assert plan is not None and plan.event_exposed == ["t"], msg
+    plan, msg = _plan_of_text("n += 1; t = spl0 * 2; n >= 64 ? ( y = t + 1; fft(buf, 64); n = 0; ); spl0 = y;")
+    assert plan is not None and plan.event_exposed == [], msg
     # inside a loop, or with an else arm, or valued: left alone (and then unsupported for what the body holds)
     plan, msg = _plan_of_text("k = 0; loop(2, k >= 1 ? ( fft(buf, 64); ); k += 1; ); spl0 = buf[0];")
     assert plan is None and "fft" in msg, msg

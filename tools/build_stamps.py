@@ -16,5 +16,8 @@ for leaf in sys.argv[1:]:
         src = ROOT / "tests" / "fixtures" / f"{leaf[3:]}.jsfx"
     else:
         leaves = leaves or zb.discover(Path(os.environ.get("ZA_PLUGINS_ROOT", "/root/reference/plugins")))
-        src = leaves[leaf]["entry"]
+        if leaf in leaves:
+            src = leaves[leaf]["entry"]
+        else:                                  # (a leaf the reference ships disabled: plugin.json.bak)
+            src = sorted(Path(os.environ.get("ZA_PLUGINS_ROOT", "/root/reference/plugins")).glob(f"*/{leaf}/src/*.jsfx"))[0]
     print(zb.build_module(src, name=f"{leaf}_stamps", force=True))

@@ -265,7 +265,16 @@ int zab_create(const char* module, const zab_config* cfg, zab_engine** out) {
   if (e->cfg.max_block <= 0) e->cfg.max_block = 512;
   int rc = ZAB_OK;
   hipError_t he;
-  if ((he = hipSetDevice(cfg->device)) != hipSuccess || (he = hipStreamCreate(&e->stream)) != hipSuccess ||
+  // (a message-bus leaf runs one small launch per host block plus a publish kernel: thousands of launches per second of audio,
+  //  each waiting for its turn when other engines keep long kernels in flight on the same device -- a 10 s mixed-catalog run
+  //  was measured spending 94 s in the 1 876 launches of one such engine. Its stream takes the device's highest priority.)
+  auto make_stream = [&]() -> hipError_t {
+    int least = 0, greatest = 0;
+    if (m->uses_msg && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+      return hipStreamCreateWithPriority(&e->stream, hipStreamDefault, greatest);
+    return hipStreamCreate(&e->stream);
+  };
+  if ((he = hipSetDevice(cfg->device)) != hipSuccess || (he = make_stream()) != hipSuccess ||
       (he = create_events(e)) != hipSuccess) {
     rc = fail(ZAB_E_HIP, "HIP stream/event setup failed: %s", hipGetErrorString(he));
     zab_destroy(e);

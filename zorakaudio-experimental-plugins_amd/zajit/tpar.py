@@ -885,6 +885,8 @@ class Region:
 class Plan:
     def __init__(self):
         self.events: List[N] = []
+        self.full_exposed: set = set()
+        self.event_exposed: List[str] = []
         self.g: FrameGraph = None
         self.nch = 0
         self.outs: Dict[str, N] = {}             # variable (or splK) -> node holding its value at the end of a frame
@@ -1003,6 +1005,7 @@ def build_plan(prog: Program, nch: int) -> Plan:
     plan.has_pending = prog.uses("sliderchange", "slider_automate")
     plan.guards = guards
     plan.events = [e for e in g.events if not (e.kind == "const" and e.val == 0.0)]
+    plan.full_exposed = exposed_vars(prog, list(prog.sections["sample"])) if plan.events else set()
     written = list(g.written)
     # variables @sample leaves as they were (x = x) are not state
     for name in list(written):
@@ -1039,6 +1042,11 @@ def build_plan(prog: Program, nch: int) -> Plan:
     loop_by_id = {L.id: L for L in g.loops}
     g.loop_of = loop_by_id
     plan.holdvars = [name for name in written if may_hold(plan.outs[name])]
+    # variables an event's body reads from the frame before although the rest of the frame writes them first: they are no
+    # states of the lowering, yet the section code that runs the event's frame wants them in memory
+    # (the audio channels are set from the input before the section code runs)
+    plan.event_exposed = sorted(nm for nm in plan.full_exposed if nm in plan.outs and nm not in plan.st and nm not in plan.holdvars
+                                and not (is_spl_name(nm) is not None and is_spl_name(nm) < nch))
     for name in plan.holdvars:
         if name in plan.st or name.startswith("mem") or name == RNG_INDEX:
             raise AssertionError(f"{name}: HOLD marker on a state")
@@ -2525,8 +2533,10 @@ class _Emit:
                 L.append(f"      zt_snap[{k}] = {c};")
             L.append("    }")
             L.append("    bool zt_bad = false, zt_badl = false;")
-        if self.has_events:
-            L.append("    const bool fin = true;   // any chunk may be a segment's last (an event in the next one): each leaves every written variable in memory")
+        if self.has_events and p.event_exposed:
+            L.append(f"    bool fin = true;   // every chunk leaves what it wrote in memory: an event's body reads {', '.join(p.event_exposed[:4])} from the frame before")
+        elif self.has_events:
+            L.append("    bool fin = f0 + 64 >= bend;   // the block's last chunk -- or the one an event cuts short (set at the cut)")
         else:
             L.append("    const bool fin = f0 + 64 >= bend;   // the block's last chunk: its last frame leaves every written variable as the script would")
         self.avail = {n.i for n in p.inputs}
@@ -2627,6 +2637,27 @@ class _Emit:
                 L.append(f"      {self.dst(name)} = {ref(o)};")
             L.append("    }")
             self.pending.clear()
+
+    def emit_flush_states(self, ind: str):
+        """The carried states and last-written values as they stand in registers, into vars[] / mem[] (the section code is about
+        to run on them). Variables a frame writes before it reads them are not among them: the section code writes them itself."""
+        p, L = self.plan, self.L
+        cname = self.cname
+        L.append(f"{ind}if (lane == 0) {{")
+        for name, c in cname.items():
+            if name.startswith("memw@") or name == RNG_INDEX:
+                continue
+            if name in p.cells:
+                flag = "memw@" + name[4:]
+                if flag in cname:
+                    L.append(f"{ind}  if ({cname[flag]} != 0.0) {{ {self.dst(name)} = {c}; zt_hc = zt_hc > ca{p.cells[name].i} + 1 ? zt_hc : ca{p.cells[name].i} + 1; }}")
+                continue
+            L.append(f"{ind}  {self.dst(name)} = {c};")
+        for name, h in self.hname.items():
+            L.append(f"{ind}  {self.dst(name)} = {h};")
+        if self.has_mem:
+            L.append(f"{ind}  b.mem_high[inst] = zt_high > zt_hc ? zt_high : zt_hc;")
+        L.append(f"{ind}}}")
 
     def emit_abort_block(self):
         p, L = self.plan, self.L
@@ -2841,9 +2872,12 @@ class _Emit:
                 cond = " || ".join(f"za_truthy({ref(e)})" for e in p.events)
                 L.append(f"{ind}{{   // the first frame an event falls on ends the segment: the frames before it are this chunk")
                 L.append(f"{ind}  const uint64_t m = __ballot(valid && ({cond}));")
-                L.append(f"{ind}  if (m) {{ const int e = (int)__ffsll((long long)m) - 1; zt_evf = f0 + e; bend = zt_evf; tn = e; last = e - 1; valid = lane < tn; }}")
+                L.append(f"{ind}  if (m) {{ const int e = (int)__ffsll((long long)m) - 1; zt_evf = f0 + e; bend = zt_evf; tn = e; last = e - 1; valid = lane < tn; fin = true; }}")
                 L.append(f"{ind}}}")
-                L.append(f"{ind}if (tn == 0) break;")
+                L.append(f"{ind}if (tn == 0) {{   // the event falls on this chunk's first frame: the states as the chunk before left them go to memory")
+                self.emit_flush_states(ind + "  ")
+                L.append(f"{ind}  break;")
+                L.append(f"{ind}}}")
                 self.before_cut = False
                 self.retire()
                 continue
