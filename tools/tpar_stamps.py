@@ -1,7 +1,8 @@
 """In-kernel phase clock of a generated time-parallel kernel: python tools/tpar_stamps.py LEAF [instances] [frames]
 (build the leaf with ZA_TPAR_STAMPS=1 first, e.g. as <LEAF>_stamps: tools/build_stamps.py). Phases: 0 @block / @slider between
 blocks, 1 block prologue (invariants, address passes, staging of per-trip cells), 2 lane-parallel nodes and scans of the chunks,
-3 serial recurrences, 4 switched recurrences, 5 stores / carries / output, 7 loop overhead of the block loop, 8.. uniform loops."""
+3 serial recurrences, 4 switched recurrences, 5 stores / carries / output, 6 the frames events and guards fall on (section code),
+7 loop overhead of the block loop, 8.. uniform loops."""
 import ctypes
 import sys
 from pathlib import Path
@@ -35,7 +36,7 @@ def main():
     tot = v.sum()
     print(f"{leaf} x{n} x{frames}: {ms:.2f} ms, kernel {e.last_kernel_name() if False else ''}")
     names = {0: "@block/@slider", 1: "block prologue", 2: "nodes + scans", 3: "serial recurrences", 4: "switched recurrences",
-             5: "stores/carries/output", 7: "block loop"}
+             5: "stores/carries/output", 6: "event / guard frames", 7: "block loop"}
     for k in range(64):
         if v[k]:
             print(f"  phase {k:2d} {names.get(k, 'uniform loop %d' % (2 * (k - 8))):24s} {100 * v[k] / tot:6.2f} %   {v[k] / n / 100e6 * 1e3:9.3f} ms at 100 MHz")
