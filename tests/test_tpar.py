@@ -142,6 +142,28 @@ def test_rare_heavy_branches_become_events():
     assert plan is None, msg
 
 
+def test_arms_of_block_constant_conditions_run_under_uniform_branches(monkeypatch):
+    """Nodes whose every use is one arm of selects on a single block-constant condition are emitted under a wave-uniform branch
+    (tpar._uniform_guards; on for the leaves where it was measured to pay, ZA_TPAR_BRANCHES=1 forces it)."""
+    from zajit import tpar
+    monkeypatch.setenv("ZA_TPAR_BRANCHES", "1")
+    plan, msg = _plan_of_text("a = spl0 * 2; mode ? ( y = exp(a) * sin(a); ) : ( y = sqrt(abs(a)) + 1; ); z += (y - z) * 0.1; spl0 = z; spl1 = a;")
+    assert plan is not None, msg
+    arms = {}
+    for i, (cn, arm) in plan.node_guard.items():
+        arms.setdefault(arm, []).append(plan.g.nodes[i].op)
+        assert cn.kind == "inv" and cn.name == "mode"
+    assert "exp" in arms[True] and "sin" in arms[True] and "sqrt" in arms[False]
+    text = tpar.emit_hip(plan, plan.g.p)
+    assert "const bool zg" in text and "if (zg" in text and "if (!zg" in text
+    # `a` feeds both arms and an output: always computed; the recurrence's own nodes too
+    always = [n for n in plan.g.nodes if n.kind == "op" and n.op == "*" and n.i not in plan.node_guard]
+    assert always
+    monkeypatch.setenv("ZA_TPAR_BRANCHES", "0")
+    plan0, _ = _plan_of_text("a = spl0 * 2; mode ? ( y = exp(a) * sin(a); ) : ( y = sqrt(abs(a)) + 1; ); z += (y - z) * 0.1; spl0 = z; spl1 = a;")
+    assert plan0.node_guard == {}
+
+
 def test_unsupported_scripts_keep_the_generic_kernel_only():
     from zajit import program, tpar
     for sample, why in (

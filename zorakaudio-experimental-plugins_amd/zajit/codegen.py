@@ -48,7 +48,7 @@ class Unit:
 
 # Leaves whose only cooperative loops are elementwise ("map") loops get replica lanes when that was measured to pay (DESIGN.md
 # section 8.6: Contour 108 -> 82 ms at 384 x 48 000; NeuroCV 109 -> 174 and TextureXY 478 -> 515 do not).
-MAP_REPLICA_LEAVES = {"Contour"}
+MAP_REPLICA_LEAVES = {"Contour", "NeuroCV"}
 
 
 def make_unit(prog: Program) -> Unit:

@@ -885,6 +885,7 @@ class Region:
 class Plan:
     def __init__(self):
         self.events: List[N] = []
+        self.node_guard: Dict[int, tuple] = {}
         self.full_exposed: set = set()
         self.event_exposed: List[str] = []
         self.g: FrameGraph = None
@@ -1318,6 +1319,12 @@ def build_plan(prog: Program, nch: int) -> Plan:
         _schedule(plan, r, comp_of)
     plan.items = top.items
     plan.uses_rand = RNG_INDEX in plan.outs
+    # (measured per leaf, 1024 x 48 000: TSEQ 156 -> 132 ms -- its bands' mode switches leave whole arms idle; BedRock, DPT, ATTACK,
+    #  ERBTilt, PsychoConvolver: no change -- nearly all of their guarded nodes sit on the arm their default settings take -- at
+    #  the price of registers: the branches pin values the straight-line form could sink to their uses, ERBTilt 176 -> 346)
+    want = os.environ.get("ZA_TPAR_BRANCHES")
+    on = prog.name in UNIFORM_BRANCH_LEAVES if want is None else want == "1"
+    plan.node_guard = _uniform_guards(plan, live, all_regions) if on else {}
 
     def count_items(kind, pred=lambda it: True):
         return sum(1 for r in all_regions for it in r.items if it[0] == kind and pred(it))
@@ -1341,6 +1348,77 @@ def build_plan(prog: Program, nch: int) -> Plan:
         "block": int(plan.has_block), "pending": int(plan.has_pending),
     }
     return plan
+
+
+UNIFORM_BRANCH_LEAVES = {"TSEQ"}
+
+
+def _uniform_guards(plan: "Plan", live: Dict[int, N], all_regions) -> Dict[int, tuple]:
+    """If-conversion computes both arms of every conditional. Where the condition is constant over a block (a mode switch, an
+    `enabled` flag, `ir_ready`), the arm not taken is dead weight for the whole block: nodes of the frame whose every use is the
+    same arm of selects on ONE such condition (directly, or through nodes that are themselves only used there) are emitted under
+    a wave-uniform branch on it. Returns node id -> (condition node, arm taken when it is true?). Only plain lane-parallel nodes
+    of the frame take part; anything a recurrence, a loop, a store, an event or an output refers to is computed always."""
+    top = plan.top
+    par = {it[1].i: it[1] for it in top.items if it[0] == "par" and it[1].kind == "op"}
+    always = set()
+    for o in list(plan.outs.values()) + list(plan.spl_out) + list(plan.events) + list(plan.guards) + list(plan.cells.values()):
+        always.add(o.i)
+    for st_ in plan.stores:
+        for x in (st_.addr, st_.value, st_.pred):
+            if x is not None:
+                always.add(x.i)
+    for r in all_regions:
+        for c in r.comps:
+            for x in (list(c.members) + list(getattr(c, "inputs", [])) + list(getattr(c, "ext", []))
+                      + [y for row in (c.A or []) for y in row] + list(c.b or [])
+                      + list(getattr(c, "gdep", [])) + list(getattr(c, "gnodes", [])) + list(getattr(c, "slice", []))
+                      + list(getattr(c, "conds", []))):
+                if isinstance(x, N):
+                    always.add(x.i)
+        if r.loop is not None:
+            for x in r.ext:
+                always.add(x.i)
+    uses: Dict[int, List[tuple]] = {}
+    for n in live.values():
+        for k, a in enumerate(n.args):
+            uses.setdefault(a.i, []).append((n, k))
+        for a in n.extra:
+            uses.setdefault(a.i, []).append((n, -1))
+    memo: Dict[int, Optional[tuple]] = {}
+
+    def guard(n: N) -> Optional[tuple]:
+        if n.i in memo:
+            return memo[n.i]
+        memo[n.i] = None
+        if n.i in always or n.i not in par or n.i not in uses:
+            return None
+        gs = set()
+        for u, k in uses[n.i]:
+            if u.i in par and u.op == "sel" and k in (1, 2) and u.args[0].uniform and u.args[0].loop is None and u.args[0].kind != "const":
+                gs.add((u.args[0].i, k == 1))
+            elif u.i in par and k >= 0:
+                gs.add(guard(u))
+            else:
+                gs.add(None)
+            if len(gs) > 1:
+                return None
+        g_ = next(iter(gs))
+        memo[n.i] = g_
+        return g_
+
+    import sys
+    lim = sys.getrecursionlimit()
+    sys.setrecursionlimit(max(lim, 20000))
+    try:
+        out = {}
+        for i, n in par.items():
+            g_ = guard(n)
+            if g_ is not None:
+                out[i] = (live[g_[0]], g_[1])
+    finally:
+        sys.setrecursionlimit(lim)
+    return out
 
 
 def _sum_terms(n: N) -> List[N]:
@@ -2290,6 +2368,8 @@ class _Emit:
                     L.append(f"      zt_u[{self.uslot[n.i]}] = u{n.i};")
             L.append("    }")
             L.append("    __syncthreads();")
+        for cn in sorted({g_[0].i: g_[0] for g_ in p.node_guard.values()}.values(), key=lambda n: n.i):
+            L.append(f"    const bool zg{cn.i} = za_truthy({ref(cn)});")
         for gn in p.guards:
             L.append(f"    if (za_truthy({ref(gn)})) {{   // a rare-event branch the lowering left out (tpar.split_guards) is due: this frame runs with the section code")
             L.append("      zt_evf = pos;")
@@ -2841,8 +2921,30 @@ class _Emit:
         p, L, ref = self.plan, self.L, self.ref
         top = reg.loop is None
         sites_open = False
+        run: List[N] = []           # consecutive nodes of the frame that hang on one arm of a block-constant condition
+
+        def flush_run():
+            if not run:
+                return
+            cn, arm = p.node_guard[run[0].i]
+            L.append(f"{ind}double " + ", ".join(f"n{n.i} = 0.0" for n in run) + ";")
+            L.append(f"{ind}if ({'' if arm else '!'}zg{cn.i}) {{   // only this arm of the block-constant condition needs them")
+            for n in run:
+                L.append(f"{ind}  n{n.i} = {_expr(n.op, [ref(x) for x in n.args])};")
+            L.append(f"{ind}}}")
+            run.clear()
+            if not self.before_cut:
+                self.retire()
+
         for gid, it in enumerate(reg.items):
             kind = it[0]
+            if top and kind == "par" and it[1].i in p.node_guard:
+                if run and p.node_guard[run[0].i] != p.node_guard[it[1].i]:
+                    flush_run()
+                run.append(it[1])
+                self.avail.add(it[1].i)
+                continue
+            flush_run()
             if kind != "site" and sites_open:
                 self.emit_site_pairs(ind)
                 sites_open = False
@@ -2937,6 +3039,7 @@ class _Emit:
                 raise AssertionError(kind)
             if top and not self.before_cut:
                 self.retire()
+        flush_run()
         if sites_open:
             self.emit_site_pairs(ind)
 
