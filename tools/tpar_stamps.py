@@ -1,4 +1,4 @@
-"""In-kernel phase clock of a generated time-parallel kernel: python tools/tpar_stamps.py LEAF [instances] [frames]
+"""In-kernel phase clock of a generated time-parallel kernel: python tools/tpar_stamps.py LEAF [instances] [frames] [mem_cap] [ir]
 (build the leaf with ZA_TPAR_STAMPS=1 first, e.g. as <LEAF>_stamps: tools/build_stamps.py). Phases: 0 @block / @slider between
 blocks, 1 block prologue (invariants, address passes, staging of per-trip cells), 2 lane-parallel nodes and scans of the chunks,
 3 serial recurrences, 4 switched recurrences, 5 stores / carries / output, 6 the frames events and guards fall on (section code),
@@ -21,6 +21,10 @@ def main():
     meta = zabatch.leaf_meta(leaf)
     nch = int(meta["nch"])
     with zabatch.Engine(leaf, n, max_block=512, mem_cap=int(sys.argv[4]) if len(sys.argv) > 4 else 0) as e:
+        if len(sys.argv) > 5 and sys.argv[5] == "ir":       # an impulse response in file slot 0 (PsychoConvolver): 0.5 s of decaying stereo noise
+            from zajit import noise
+            ir = (noise.white_noise([321], 24000)[0].T * np.exp(-np.arange(24000) / 4000.0)[:, None]).reshape(-1).astype(np.float64)
+            e.file_slot_set(0, ir, channels=2, sample_rate=48000.0)
         e.set_sliders(meta["default_sliders"]); e.prepare()
         nbytes = n * nch * frames * 4
         d_in, d_out = e.device_alloc(nbytes), e.device_alloc(nbytes)

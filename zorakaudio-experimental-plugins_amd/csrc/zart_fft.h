@@ -47,6 +47,7 @@ extern "C" int zab_module_fft_lds_points(void) { return ZA_FFT_LDS_POINTS; }   /
 #endif
 __device__ double za_fft_cos[ZA_FFT_MAX / 2];
 __device__ double za_fft_sin[ZA_FFT_MAX / 2];
+__device__ double za_fft_twc[ZA_FFT_LDS_POINTS];     // (cos, sin)(2 pi j / ZA_FFT_LDS_POINTS), j < ZA_FFT_LDS_POINTS / 2
 __device__ uint16_t za_fft_perm[2 * ZA_FFT_COOP_MAX];     // [n + i] = natural bin stored at position i of an n-point transform
 __device__ uint16_t za_fft_iperm[2 * ZA_FFT_COOP_MAX];    // [n + k] = position that holds natural bin k
 #else
@@ -98,6 +99,10 @@ extern "C" __global__ void za_fft_table_kernel() {
     sincos(6.283185307179586476925286766559 * (double)j / (double)ZA_FFT_MAX, &sn, &cs);
     za_fft_cos[j] = cs;
     za_fft_sin[j] = sn;
+    if (j % (ZA_FFT_MAX / ZA_FFT_LDS_POINTS) == 0) {      // the in-LDS passes' twiddles, (cos, sin) side by side: 8 KB that stay in L1
+      za_fft_twc[2 * (j / (ZA_FFT_MAX / ZA_FFT_LDS_POINTS))] = cs;
+      za_fft_twc[2 * (j / (ZA_FFT_MAX / ZA_FFT_LDS_POINTS)) + 1] = sn;
+    }
   }
   if (j >= 2 && j < 2 * ZA_FFT_COOP_MAX) {      // j = n + i with n the largest power of two <= j (real transforms use sizes from 8)
     uint32_t n = 2;
@@ -139,12 +144,22 @@ ZA_FN bool za_fft_region(S& s, double baseD, int64_t span, int64_t& base, int64_
 #ifndef ZA_FFT_WAVES_PER_EU
 #define ZA_FFT_WAVES_PER_EU 2
 #endif
-// twiddles (cos, sin)(2 pi j / ZA_FFT_LDS_POINTS), j < ZA_FFT_LDS_POINTS / 2, staged in LDS by the first cooperative transform of
-// a workgroup. LDS is neither cleared nor private between launches, so every kernel of an FFT leaf resets the flag on
-// entry (ZA_KERNEL_ENTRY in zab_generic.hip.h) instead of trusting whatever an earlier workgroup left behind.
+// Twiddles of the in-LDS passes, (cos, sin)(2 pi j / ZA_FFT_LDS_POINTS), j < ZA_FFT_LDS_POINTS / 2. Round 3: read from the compact
+// device table za_fft_twc (8 KB, resident in a CU's L1: every wavefront of the CU reads the same table) instead of a copy in each
+// wavefront's LDS -- the copy was a third of a transform's LDS footprint (16 + 8 KB: six wavefronts per CU; 16 KB: two per SIMD,
+// what the register cap allows), and a pass asks for its twiddles together with its points, before it needs either.
+// -DZA_FFT_TW_LDS=1 keeps round 2's LDS copy (staged by the first cooperative transform of a workgroup; LDS is neither cleared nor
+// private between launches, so every kernel of an FFT leaf resets the flag on entry -- ZA_KERNEL_ENTRY in zab_generic.hip.h).
+#ifndef ZA_FFT_TW_LDS
+#define ZA_FFT_TW_LDS 0
+#endif
+#if ZA_FFT_TW_LDS
 __shared__ double za_fft_tw[ZA_FFT_LDS_POINTS];
 __shared__ int za_fft_tw_ready;
 #define ZA_KERNEL_ENTRY() do { za_fft_tw_ready = 0; __builtin_amdgcn_wave_barrier(); } while (0)
+#else
+#define ZA_KERNEL_ENTRY() (void)0
+#endif
 enum { ZA_COOP_FFT = 0, ZA_COOP_IFFT = 1, ZA_COOP_PERMUTE = 2, ZA_COOP_IPERMUTE = 3, ZA_COOP_FFT_REAL = 4, ZA_COOP_IFFT_REAL = 5,
        ZA_COOP_CONVOLVE = 6,
        ZA_COOP_FFT_NAT = 7,      // fft(b, n); fft_permute(b, n)    -> natural order in, natural-order spectrum out
@@ -241,7 +256,11 @@ __device__ __forceinline__ void za_fft_lds_stages(double* buf, const double* tw,
 template <class S>
 ZA_NOINLINE bool za_fft_coop(S& s, bool ok, int64_t base, int n, int op, int64_t base2 = 0) {
   __shared__ double buf[2 * ZA_FFT_LDS_POINTS];
+#if ZA_FFT_TW_LDS
   double* const tw = za_fft_tw;
+#else
+  const double* const tw = za_fft_twc;
+#endif
   const bool is_real = op == ZA_COOP_FFT_REAL || op == ZA_COOP_IFFT_REAL;
   // what runs here: anything that fits the LDS buffer; complex transforms and permutations beyond it run sliced (below);
   // real transforms beyond it take the serial path
@@ -253,6 +272,7 @@ ZA_NOINLINE bool za_fft_coop(S& s, bool ok, int64_t base, int n, int op, int64_t
   const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
   const int rank = __popcll(active & below), nact = __popcll(active);
   const bool is_nat = op == ZA_COOP_FFT_NAT || op == ZA_COOP_IFFT_NAT;
+#if ZA_FFT_TW_LDS
   if (todo && (op == ZA_COOP_FFT || op == ZA_COOP_IFFT || is_real || is_nat) && za_fft_tw_ready != 1) {
     // twiddles of the largest cooperative size, staged once per workgroup launch (the HBM table is 1 us away per read)
     for (int j = rank; j < ZA_FFT_LDS_POINTS / 2; j += nact) {
@@ -263,6 +283,7 @@ ZA_NOINLINE bool za_fft_coop(S& s, bool ok, int64_t base, int n, int op, int64_t
     if (rank == 0) za_fft_tw_ready = 1;
     __builtin_amdgcn_wave_barrier();
   }
+#endif
   while (todo) {
     const int l = __ffsll((long long)todo) - 1;
     todo &= todo - 1;
