@@ -142,6 +142,32 @@ def test_rare_heavy_branches_become_events():
     assert plan is None, msg
 
 
+def test_wrapped_counters_have_a_closed_form(monkeypatch):
+    """pos = (pos + K) % N with K, N constant over a block: the state before frame t of a chunk is (pos + t K) % N -- over
+    non-negative integers, checked per chunk; anything else (a fractional step, a negative start) takes the serial loop."""
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2, 300)).astype(np.float32)
+    for text, cases in (
+            ("ring[pos] = spl0; pos = (pos + step) % len; spl0 = ring[pos] * 0.5; spl1 = pos;",       # a ring position
+             ({"ring": 100.0, "len": 150.0, "step": 1.0, "pos": 0.0}, {"ring": 100.0, "len": 150.0, "step": 1.0, "pos": 149.0})),
+            ("pos = (pos + step) % len; spl0 = spl0 + pos * 0.01; spl1 = pos;",
+             ({"len": 37.0, "step": 5.0, "pos": 36.0},
+              {"len": 64.0, "step": 3.0, "pos": 70.0},            # starts beyond the length: the first frame sees it as it is
+              {"len": 37.0, "step": 1.5, "pos": 2.0},             # a fractional step: the serial loop (za_mod truncates)
+              {"len": 37.0, "step": 2.0, "pos": -5.0}))):         # a negative start: the serial loop
+        monkeypatch.delenv("ZA_TPAR_NO_MODC", raising=False)
+        plan, msg = _plan_of_text(text)
+        assert plan is not None and plan.stats["wrapped_counters"] == 1 and plan.stats["serial_loops"] == 0, msg
+        monkeypatch.setenv("ZA_TPAR_NO_MODC", "1")
+        ref_plan, _ = _plan_of_text(text)
+        assert ref_plan.stats["wrapped_counters"] == 0 and ref_plan.stats["serial_loops"] == 1
+        for v0 in cases:
+            y, va, _ = plan.simulate(dict(v0), x)
+            yr, vr, _ = ref_plan.simulate(dict(v0), x)
+            assert np.array_equal(y, yr) and va["pos"] == vr["pos"], v0
+            assert np.array_equal(plan.mem_after, ref_plan.mem_after)
+
+
 def test_arms_of_block_constant_conditions_run_under_uniform_branches(monkeypatch):
     """Nodes whose every use is one arm of selects on a single block-constant condition are emitted under a wave-uniform branch
     (tpar._uniform_guards; on for the leaves where it was measured to pay, ZA_TPAR_BRANCHES=1 forces it)."""

@@ -865,6 +865,8 @@ class Component:
         self.gdep: List[N] = []                  # nodes of A / b that depend on a placeholder, topological order
         self.slice: List[N] = []                 # nodes needed to evaluate the conditions from the states, topological order
         self.inputs: List[N] = []                # everything outside that the unit reads
+        self.modk: Optional[N] = None            # "modc": y' = (y + modk) % modn
+        self.modn: Optional[N] = None
         self.reg: "Region" = None
 
 
@@ -1335,7 +1337,7 @@ def build_plan(prog: Program, nch: int) -> Plan:
         "spec_loops": count_items("spec"),
         "spec_chains": sum(len(it[1]) for r in all_regions for it in r.items if it[0] == "spec"),
         "spec_switches": sum(len(c.conds) for r in all_regions for it in r.items if it[0] == "spec" for c in it[1]),
-        "serial_loops": count_items("serial"),
+        "serial_loops": count_items("serial"), "wrapped_counters": count_items("modc"),
         "serial_chains": sum(len(it[1]) for r in all_regions for it in r.items if it[0] == "serial"),
         "serial_ops": sum(len([m for m in c.members if m.kind not in ("st", "lcin")]) for r in all_regions for it in r.items
                           if it[0] == "serial" for c in it[1]),
@@ -1471,6 +1473,8 @@ def _schedule(plan: Plan, r: Region, comp_of: Dict[int, Component]):
         c.ext = ext
         if c.kind == "scan":
             c.inputs = [x for row in c.A for x in row] + list(c.b)
+        elif c.kind == "modc":
+            c.inputs = [c.modk, c.modn]
         elif c.kind == "spec":
             own = {x.i for x in c.gdep + c.gnodes + c.slice} | mem
             ins, seen = list(ext), {x.i for x in ext}
@@ -1590,8 +1594,8 @@ def _schedule(plan: Plan, r: Region, comp_of: Dict[int, Component]):
         for c in comps:
             if cone_comps is not None and id(c) not in cone_comps:
                 continue
-            if not comp_done[id(c)] and c.kind == "scan" and all(is_done(x) for x in c.inputs):
-                items.append(("scan", c))
+            if not comp_done[id(c)] and c.kind in ("scan", "modc") and all(is_done(x) for x in c.inputs):
+                items.append((c.kind, c))
                 comp_done[id(c)] = True
                 progressed = True
         if progressed:
@@ -1721,6 +1725,17 @@ def _classify(g: FrameGraph, reg: Region, c: Component, ci: int = 0, live=None):
             rows.append(r)
         return rows, conds, gnodes
 
+    if d == 1 and reg.loop is None and not os.environ.get("ZA_TPAR_NO_MODC"):
+        # a wrapped counter, pos = (pos + K) % N with K and N constant over a block (ring positions): over non-negative integers
+        # the t-th iterate is (pos + t K) % N -- exact, whatever the order; checked per chunk, the serial loop otherwise
+        o, st_ = reg.outs[names[0]], reg.st[names[0]]
+        if o.kind == "op" and o.op == "%" and o.args[1].uniform and o.args[1].loop is None:
+            a = o.args[0]
+            if a.kind == "op" and a.op == "+" and st_ in a.args:
+                k_ = a.args[1] if a.args[0] is st_ else a.args[0]
+                if k_ is not st_ and k_.uniform and k_.loop is None and mem == {st_.i, a.i, o.i}:
+                    c.kind, c.modk, c.modn = "modc", k_, o.args[1]
+                    return
     if d == 1 and _persistent_rounding(g, reg, c, mem):
         return                                    # stays "serial": see _persistent_rounding
     res = attempt(False)
@@ -2954,7 +2969,7 @@ class _Emit:
                 elif kind == "shift":
                     self.avail.add(reg.st[it[1]].i)
                     self.unit_done.add(it[1])
-                elif kind == "scan":
+                elif kind in ("scan", "modc"):
                     for nm in it[1].names:
                         self.avail.add(reg.st[nm].i)
                         self.unit_done.add(nm)
@@ -3018,6 +3033,24 @@ class _Emit:
                 L.append(f"{ind}const double n{reg.st[name].i} = zt_shift1({ref(reg.outs[name])}, {self.carry(reg, name)});   // {name}[t-1]")
             elif kind == "scan":
                 self.emit_scan(reg, it[1], ind)
+            elif kind == "modc":
+                c = it[1]
+                nm, sid = c.names[0], reg.st[c.names[0]].i
+                cv, kk, nn = self.carry(reg, nm), ref(c.modk), ref(c.modn)
+                L.append(f"{ind}// {nm}: a wrapped counter, (y + K) % N over non-negative integers: the state before frame t is (y + t K) % N")
+                L.append(f"{ind}double k{sid};")
+                L.append(f"{ind}if (zt_small_int({cv}) && {cv} >= 0.0 && zt_small_int({kk}) && {kk} >= 0.0 && zt_small_int({nn}) && {nn} >= 1.0 && {nn} < 2147483647.0 && {cv} + 64.0 * {kk} < 2147483647.0) {{")
+                L.append(f"{ind}  k{sid} = lane == 0 ? {cv} : za_mod({cv} + (double)lane * {kk}, {nn});")
+                L.append(f"{ind}}} else {{")
+                mark = len(L)
+                self.serial_loop(reg, [c], ind + "  ")
+                # (the loop declares y / k itself: keep its k as the block-local it is and copy it out)
+                L[mark] = L[mark].replace(f"k{sid} = {cv};", f"zk{sid} = {cv};")
+                for q in range(mark + 1, len(L)):
+                    L[q] = L[q].replace(f"k{sid} = me ? y{sid} : k{sid};", f"zk{sid} = me ? y{sid} : zk{sid};")
+                L.append(f"{ind}  k{sid} = zk{sid};")
+                L.append(f"{ind}}}")
+                L.append(f"{ind}const double n{sid} = k{sid};")
             elif kind == "serial":
                 names = [nm for c in it[1] for nm in c.names]
                 L.append(f"{ind}// serial recurrences sharing one loop: {', '.join(names)}")
@@ -4045,6 +4078,18 @@ def _simulate(self: Plan, vars0: Dict[str, float], x: np.ndarray, sliders=None, 
                 states = _scan_exclusive(A, b, np.array([carry[nm] for nm in comp.names]))
                 for r, nm in enumerate(comp.names):
                     val[reg.st[nm].i] = states[r]
+            elif kind == "modc":
+                comp = it[1]
+                nm = comp.names[0]
+                c0, kk, nn = float(carry[nm]), float(uni(comp.modk, "counter step")), float(uni(comp.modn, "counter length"))
+                small = lambda x_: x_ == math.floor(x_) and abs(x_) < 1.0e12
+                if small(c0) and c0 >= 0 and small(kk) and kk >= 0 and small(nn) and 1 <= nn < 2147483647.0 and c0 + 64 * kk < 2147483647.0:
+                    t = np.arange(WAVE, dtype=np.float64)
+                    st_v = np.mod(c0 + t * kk, nn)
+                    st_v[0] = c0
+                    val[reg.st[nm].i] = st_v
+                else:
+                    sim_serial(reg, comp, carry, tn)
             elif kind == "serial":
                 for comp in it[1]:
                     sim_serial(reg, comp, carry, tn)
