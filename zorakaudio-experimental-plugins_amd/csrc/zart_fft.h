@@ -174,6 +174,17 @@ __device__ __forceinline__ int64_t za_readlane64(int64_t v, int l) {
 // twiddle and the order of operations the one-pass-at-a-time form uses, hence the same bits; what changes is the traffic: LDS
 // is what bounds these transforms (a butterfly moves 80 bytes per pass for 10 flops), and a point now makes one round trip
 // per three passes (46 reads and writes per 12 butterflies instead of 120) behind a third of the barriers.
+// LDS layout of the transform buffer: element i (16 bytes) sits at ZA_B(i) doubles. The bank a wavefront's 16-lane phase hits is
+// decided by the low four bits of the element index; the fused passes stride through the buffer so that, in the first two of
+// them, those bits take only four values per phase (a lane owns 4 consecutive elements / lanes step 16 elements): four-way
+// conflicts on every access, 65 % of the LDS pipeline's active cycles (SQ_LDS_BANK_CONFLICT, profiles/r03_fft_sq.txt). XOR-ing
+// bits 4-5 of the index into bits 0-1 and 2-3 makes the low four bits a bijection of the lanes in every pass's pattern
+// (varying bits {2..5}, {0,1,4,5}, {0..3}) and leaves each 16-element row a permutation of itself.
+#ifndef ZA_FFT_NO_SWIZZLE
+#define ZA_B(i) (2 * ((int)(i) ^ ((((int)(i) >> 4) & 3) * 5)))
+#else
+#define ZA_B(i) (2 * (int)(i))
+#endif
 template <int R>
 __device__ __forceinline__ void za_fft_lds_pass(double* buf, const double* tw, int nlp, int h0, int sign, int rank, int nact) {
   constexpr int Q = 1 << R;                      // points per item
@@ -202,8 +213,8 @@ __device__ __forceinline__ void za_fft_lds_pass(double* buf, const double* tw, i
       }
 #pragma unroll
       for (int k = 0; k < Q; ++k) {
-        xr[u][k] = buf[2 * (b0 + k * h0)];
-        xi[u][k] = buf[2 * (b0 + k * h0) + 1];
+        xr[u][k] = buf[ZA_B((b0 + k * h0))];
+        xi[u][k] = buf[ZA_B((b0 + k * h0)) + 1];
       }
     }
 #pragma unroll
@@ -224,8 +235,8 @@ __device__ __forceinline__ void za_fft_lds_pass(double* buf, const double* tw, i
       if (base[u] >= 0) {
 #pragma unroll
         for (int k = 0; k < Q; ++k) {
-          buf[2 * (base[u] + k * h0)] = xr[u][k];
-          buf[2 * (base[u] + k * h0) + 1] = xi[u][k];
+          buf[ZA_B(base[u] + k * h0)] = xr[u][k];
+          buf[ZA_B(base[u] + k * h0) + 1] = xi[u][k];
         }
       }
     }
@@ -255,7 +266,7 @@ __device__ __forceinline__ void za_fft_lds_stages(double* buf, const double* tw,
 // second operand) take the same route; the arithmetic per element is the serial form's, hence the same bits.
 template <class S>
 ZA_NOINLINE bool za_fft_coop(S& s, bool ok, int64_t base, int n, int op, int64_t base2 = 0) {
-  __shared__ double buf[2 * ZA_FFT_LDS_POINTS];
+  __shared__ double buf[ZA_B(ZA_FFT_LDS_POINTS)];
 #if ZA_FFT_TW_LDS
   double* const tw = za_fft_tw;
 #else
@@ -353,6 +364,109 @@ ZA_NOINLINE bool za_fft_coop(S& s, bool ok, int64_t base, int n, int op, int64_t
       }
       const int sign = (op == ZA_COOP_FFT || op == ZA_COOP_FFT_NAT) ? -1 : +1;
       constexpr int ZA_GU = P / 64 < 16 ? (P / 64 < 1 ? 1 : P / 64) : 16;      // a full wavefront fetches a block in one batch of loads
+#ifndef ZA_FFT_NAT_STRIDED
+      if (is_nat) {
+        // Natural order in, natural order out (the fused pairs: how every leaf calls these sizes). The strided block gathers of the
+        // general path take 16 bytes out of every 64-byte segment of the buffer, once per block: four times the buffer through
+        // HBM (PMC: 3.5 x the algorithmic bytes, profiles/r03_fft_pmc_traffic.json). Here the buffer is read ONCE, coalesced,
+        // and left in the scratch sorted by residue (S_r[t] = x[t B + r]: what block bitrev(r) gathers, now contiguous); the
+        // buffer itself -- free from then on -- takes the block results, and the last passes run in place on it (a lane reads
+        // the four elements it will write). Six 64 KB trips instead of seven and a half, every one of them coalesced.
+        // (measured and rejected: the next block's loads issued before this block's LDS passes, and the chunk copies of the first
+        //  phase double-buffered -- the extra live registers spill under the 256 cap: 297 -> 503 / 558 us)
+        for (int c = 0; c < B; ++c) {
+          for (int i0 = rank; i0 < P; i0 += ZA_GU * nact) {
+            double vr[ZA_GU], vi[ZA_GU];
+#pragma unroll
+            for (int u = 0; u < ZA_GU; ++u) {
+              const int i = i0 + u * nact < P ? i0 + u * nact : i0;
+              vr[u] = ZA_G(2 * (c * P + i)); vi[u] = ZA_G(2 * (c * P + i) + 1);
+            }
+#pragma unroll
+            for (int u = 0; u < ZA_GU; ++u) {
+              const int i = i0 + u * nact;
+              if (i < P) {
+                const int k = c * P + i, r = k & (B - 1), t = k >> q;
+                ZA_S(2 * (r * P + t)) = vr[u]; ZA_S(2 * (r * P + t) + 1) = vi[u];
+              }
+            }
+          }
+        }
+        ZA_SLICE_SYNC();
+        for (int b = 0; b < B; ++b) {
+          const int rb = (int)za_bitrev((uint32_t)b, q);
+          for (int t0 = rank; t0 < P; t0 += ZA_GU * nact) {
+            double vr[ZA_GU], vi[ZA_GU];
+#pragma unroll
+            for (int u = 0; u < ZA_GU; ++u) {
+              const int t = t0 + u * nact < P ? t0 + u * nact : t0;
+              vr[u] = ZA_S(2 * (rb * P + t)); vi[u] = ZA_S(2 * (rb * P + t) + 1);
+            }
+#pragma unroll
+            for (int u = 0; u < ZA_GU; ++u) {
+              const int t = t0 + u * nact;
+              if (t < P) {
+                const uint32_t m = za_bitrev((uint32_t)t, PB);
+                buf[ZA_B(m)] = vr[u]; buf[ZA_B(m) + 1] = vi[u];
+              }
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+          za_fft_lds_stages(buf, tw, P, sign, rank, nact);
+          for (int m = rank; m < P; m += nact) {
+            ZA_G(2 * (P * b + m)) = buf[ZA_B(m)];
+            ZA_G(2 * (P * b + m) + 1) = buf[ZA_B(m) + 1];
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+      
+        ZA_SLICE_SYNC();
+        constexpr int JV = 4;
+        for (int j0 = rank; j0 < P; j0 += JV * nact) {
+          double er[JV][4], ei[JV][4], w1r[JV], w1i[JV], w2r[JV], w2i[JV], w3r[JV], w3i[JV];
+#pragma unroll
+          for (int u = 0; u < JV; ++u) {
+            const int j = j0 + u * nact < P ? j0 + u * nact : j0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (k < B) { er[u][k] = ZA_G(2 * (j + P * k)); ei[u][k] = ZA_G(2 * (j + P * k) + 1); }
+            const int st1 = ZA_FFT_MAX / (2 * P), st2 = ZA_FFT_MAX / (4 * P);
+            w1r[u] = za_fft_cos[j * st1]; w1i[u] = za_fft_sin[j * st1];
+            if (B == 4) {
+              w2r[u] = za_fft_cos[j * st2]; w2i[u] = za_fft_sin[j * st2];
+              w3r[u] = za_fft_cos[(j + P) * st2]; w3i[u] = za_fft_sin[(j + P) * st2];
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < JV; ++u) {
+            auto bfly = [&](int a, int c2, double wr, double wi0) __attribute__((always_inline)) {
+              const double w_i = sign < 0 ? -wi0 : wi0;
+              const double tr = er[u][c2] * wr - ei[u][c2] * w_i, ti = er[u][c2] * w_i + ei[u][c2] * wr;
+              const double xr = er[u][a], xi = ei[u][a];
+              er[u][a] = xr + tr; ei[u][a] = xi + ti;
+              er[u][c2] = xr - tr; ei[u][c2] = xi - ti;
+            };
+            bfly(0, 1, w1r[u], w1i[u]);
+            if (B == 4) bfly(2, 3, w1r[u], w1i[u]);
+            if (B == 4) {
+              bfly(0, 2, w2r[u], w2i[u]);
+              bfly(1, 3, w3r[u], w3i[u]);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < JV; ++u) {
+            if (j0 + u * nact < P) {
+              const int j = j0 + u * nact;
+#pragma unroll
+              for (int k = 0; k < 4; ++k)
+                if (k < B) { ZA_G(2 * (j + P * k)) = er[u][k]; ZA_G(2 * (j + P * k) + 1) = ei[u][k]; }
+            }
+          }
+        }
+        ZA_SLICE_SYNC();
+        continue;
+      }
+#endif
       for (int b = 0; b < B; ++b) {
         // block b of the bit-reversed array: its position m takes natural element k = bitrev_P(m) * B + bitrev_q(b)
         const int rb = (int)za_bitrev((uint32_t)b, q);
@@ -370,15 +484,15 @@ ZA_NOINLINE bool za_fft_coop(S& s, bool ok, int64_t base, int n, int op, int64_t
             const int t = t0 + u * nact;
             if (t < P) {
               const uint32_t m = za_bitrev((uint32_t)t, PB);
-              buf[2 * m] = vr[u]; buf[2 * m + 1] = vi[u];
+              buf[ZA_B(m)] = vr[u]; buf[ZA_B(m) + 1] = vi[u];
             }
           }
         }
         __builtin_amdgcn_wave_barrier();
         za_fft_lds_stages(buf, tw, P, sign, rank, nact);
         for (int m = rank; m < P; m += nact) {
-          ZA_S(2 * (P * b + m)) = buf[2 * m];
-          ZA_S(2 * (P * b + m) + 1) = buf[2 * m + 1];
+          ZA_S(2 * (P * b + m)) = buf[ZA_B(m)];
+          ZA_S(2 * (P * b + m) + 1) = buf[ZA_B(m) + 1];
         }
         __builtin_amdgcn_wave_barrier();
       }
@@ -459,8 +573,8 @@ ZA_NOINLINE bool za_fft_coop(S& s, bool ok, int64_t base, int n, int op, int64_t
           else if (op == ZA_COOP_IFFT) dst = za_bitrev(pm[u], bits);
           else if (op == ZA_COOP_PERMUTE || op == ZA_COOP_IFFT_REAL) dst = pm[u];      // (ifft_real: natural bin order first)
           else dst = (uint32_t)i;
-          buf[2 * dst] = vr[u];
-          buf[2 * dst + 1] = vi[u];
+          buf[ZA_B(dst)] = vr[u];
+          buf[ZA_B(dst) + 1] = vi[u];
         }
       }
     }
@@ -475,20 +589,20 @@ ZA_NOINLINE bool za_fft_coop(S& s, bool ok, int64_t base, int n, int op, int64_t
           const double x0 = buf[0], xn = buf[1];
           buf[0] = x0 + xn; buf[1] = x0 - xn;
         } else {
-          const double ar = buf[2 * k], ai = buf[2 * k + 1], cr = buf[2 * m], ci = buf[2 * m + 1];
+          const double ar = buf[ZA_B(k)], ai = buf[ZA_B(k) + 1], cr = buf[ZA_B(m)], ci = buf[ZA_B(m) + 1];
           {
             const double br = cr, bi = -ci;                                  // conj X[h-k]
             const double er = ar + br, ei = ai + bi, dr = ar - br, di = ai - bi;
             const double c = za_fft_cos[k * step], sn = za_fft_sin[k * step];
-            buf[2 * k] = er + (-sn * dr - c * di);
-            buf[2 * k + 1] = ei + (-sn * di + c * dr);
+            buf[ZA_B(k)] = er + (-sn * dr - c * di);
+            buf[ZA_B(k) + 1] = ei + (-sn * di + c * dr);
           }
           if (m != k) {
             const double br = ar, bi = -ai;                                  // the same formula for bin h - k
             const double er = cr + br, ei = ci + bi, dr = cr - br, di = ci - bi;
             const double c = za_fft_cos[m * step], sn = za_fft_sin[m * step];
-            buf[2 * m] = er + (-sn * dr - c * di);
-            buf[2 * m + 1] = ei + (-sn * di + c * dr);
+            buf[ZA_B(m)] = er + (-sn * dr - c * di);
+            buf[ZA_B(m) + 1] = ei + (-sn * di + c * dr);
           }
         }
       }
@@ -496,9 +610,9 @@ ZA_NOINLINE bool za_fft_coop(S& s, bool ok, int64_t base, int n, int op, int64_t
       for (int i = rank; i < h; i += nact) {
         const int r = (int)za_bitrev((uint32_t)i, bits);
         if (i < r) {
-          const double t0 = buf[2 * i], t1 = buf[2 * i + 1];
-          buf[2 * i] = buf[2 * r]; buf[2 * i + 1] = buf[2 * r + 1];
-          buf[2 * r] = t0; buf[2 * r + 1] = t1;
+          const double t0 = buf[ZA_B(i)], t1 = buf[ZA_B(i) + 1];
+          buf[ZA_B(i)] = buf[ZA_B(r)]; buf[ZA_B(i) + 1] = buf[ZA_B(r) + 1];
+          buf[ZA_B(r)] = t0; buf[ZA_B(r) + 1] = t1;
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -518,7 +632,7 @@ ZA_NOINLINE bool za_fft_coop(S& s, bool ok, int64_t base, int n, int op, int64_t
           im = 2.0 * (buf[0] - buf[1]);
         } else {
           const int m = h - k;
-          const double zr = buf[2 * k], zi = buf[2 * k + 1], yr = buf[2 * m], yi = -buf[2 * m + 1];
+          const double zr = buf[ZA_B(k)], zi = buf[ZA_B(k) + 1], yr = buf[ZA_B(m)], yi = -buf[ZA_B(m) + 1];
           const double er = zr + yr, ei = zi + yi, dr = zr - yr, di = zi - yi;
           const double c = za_fft_cos[k * step], sn = za_fft_sin[k * step];
           re = er + (-sn * dr + c * di);
@@ -543,8 +657,8 @@ ZA_NOINLINE bool za_fft_coop(S& s, bool ok, int64_t base, int n, int op, int64_t
       for (int u = 0; u < 8; ++u) {
         const int i = i0 + u * nact;
         if (i < nl) {
-          ZA_G(2 * i) = buf[2 * src[u]];
-          ZA_G(2 * i + 1) = buf[2 * src[u] + 1];
+          ZA_G(2 * i) = buf[ZA_B(src[u])];
+          ZA_G(2 * i + 1) = buf[ZA_B(src[u]) + 1];
         }
       }
     }
