@@ -46,8 +46,10 @@ class Unit:
         }
 
 
-# Leaves whose only cooperative loops are elementwise ("map") loops get replica lanes when that was measured to pay (DESIGN.md
-# section 8.6: Contour 108 -> 82 ms at 384 x 48 000; NeuroCV 109 -> 174 and TextureXY 478 -> 515 do not).
+# Leaves whose only cooperative loops are elementwise ("map") loops get replica lanes when that was measured to pay: Contour
+# 108 -> 82 ms at 384 x 48 000 on the generic kernel (TextureXY 478 -> 515 does not). NeuroCV's generic kernel loses by it
+# (109 -> 174 ms: its map loops are a small part of every frame), but since round 3 the leaf runs on its time-parallel kernel,
+# where the loops only run in the analysis frame the whole wavefront executes as an event: 78.8 -> 72.4 ms there.
 MAP_REPLICA_LEAVES = {"Contour", "NeuroCV"}
 
 
