@@ -409,6 +409,64 @@ def test_tpar_kernel_tracks_generic_kernel_over_a_long_run_and_across_launches(l
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("leaf", ["fx_evtkat", "fx_evtkat2", "fx_stft", "fx_convkat", "ERBTilt", "TSEQ"])
+@pytest.mark.parametrize("block", [37, 64, 65, 1000])
+def test_odd_block_sizes_and_short_launches(leaf, block):
+    """Blocks that are no multiple of a chunk, shorter than one, or longer than the launch; launches of 1, 63 and 64 frames:
+    segment ends, event frames and block boundaries fall on every lane position. Both kernels get the same launches and blocks
+    (a script with @block sees them), audio within 1e-5, state within 1e-8."""
+    import zabatch
+    from zajit import noise
+    if not zabatch.module_path(leaf).exists():
+        pytest.skip(f"module for {leaf} not built")
+    meta = zabatch.leaf_meta(leaf)
+    n, frames = 3, 2300
+    nch = int(meta["nch"])
+    x = noise.white_noise(range(n), frames, channels=nch)
+    cuts = [0, 1, 64, 127, 128 + 64, 1000, frames]
+    res = {}
+    for label, path in (("fast", zabatch.ZAB_PATH_FAST), ("generic", zabatch.ZAB_PATH_GENERIC)):
+        with zabatch.Engine(leaf, n, path=path, max_block=block) as e:
+            e.set_sliders(meta["default_sliders"]); e.prepare()
+            y = np.concatenate([e.process_host(x[:, :, a:b], block=block) for a, b in zip(cuts[:-1], cuts[1:])], axis=2)
+            res[label] = (y, e.read_vars(), e.var_names())
+            if label == "fast":
+                assert e.used_fast_path()
+    err = np.abs(res["fast"][0].astype(np.float64) - res["generic"][0].astype(np.float64)).max()
+    assert err <= AUDIO_EPS, (leaf, block, err)
+    for i in range(n):
+        assert_state_close(res["fast"][2], res["fast"][1][i], res["generic"][1][i], what=f"{leaf} block {block} vars[{i}]")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("period", [2, 3, 16, 17, 64, 65, 129])
+def test_events_of_every_density(period):
+    """fx_evtkat / fx_evtkat2 with their event every `period` frames: thicker than one frame in sixteen the kernel hands the rest of
+    the launch to the serial tail, at 64 / 65 / 129 the event walks through the lanes of a chunk or sits on its first one."""
+    import zabatch
+    from zajit import noise
+    for leaf in ("fx_evtkat", "fx_evtkat2"):
+        if not zabatch.module_path(leaf).exists():
+            pytest.skip(f"module for {leaf} not built")
+        meta = zabatch.leaf_meta(leaf)
+        n, frames = 3, 3000
+        x = noise.white_noise(range(n), frames)
+        rows = np.tile(np.array(meta["default_sliders"], dtype=np.float64), (n, 1))
+        rows[:, 0] = period
+        rows[1, 0] = period + 1                      # (instances of a batch need not agree on where their events fall)
+        res = {}
+        for label, path in (("fast", zabatch.ZAB_PATH_FAST), ("generic", zabatch.ZAB_PATH_GENERIC)):
+            with zabatch.Engine(leaf, n, path=path) as e:
+                e.set_sliders(rows); e.prepare()
+                y = np.concatenate([e.process_host(x[:, :, :1700], block=500), e.process_host(x[:, :, 1700:], block=500)], axis=2)
+                res[label] = (y, e.read_vars(), e.var_names(), e.read_mem(1000, 8))
+        assert np.abs(res["fast"][0].astype(np.float64) - res["generic"][0]).max() <= AUDIO_EPS, (leaf, period)
+        assert np.abs(res["fast"][3] - res["generic"][3]).max() <= SCALAR_EPS
+        for i in range(n):
+            assert_state_close(res["fast"][2], res["fast"][1][i], res["generic"][1][i], what=f"{leaf} period {period} vars[{i}]")
+
+
+@pytest.mark.gpu
 def test_slider_change_between_launches_runs_at_slider_before_the_tpar_kernel():
     import zabatch
     from zajit import noise
