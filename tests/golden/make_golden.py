@@ -96,6 +96,8 @@ CASES = [
     # rare heavy branches (zajit/tpar.py events): a body that reads the frame before / a period that lands on chunk starts
     ("fx_evtkat", "default", {}, 2000, 500), ("fx_evtkat", "dense", {0: 17, 1: 0.9}, 1500, 512),
     ("fx_evtkat2", "default", {}, 2000, 500), ("fx_evtkat2", "slow", {0: 333, 1: 0.2}, 1500, 512),
+    # a guard (zajit/tpar.py split_guards) that @block raises every third block; and one that never clears (every frame serial)
+    ("fx_guardkat", "default", {}, 2400, 200), ("fx_guardkat", "dense", {0: 0, 1: 0.8}, 700, 128),
 ]
 
 
