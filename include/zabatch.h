@@ -212,6 +212,12 @@ int zab_host_free(void* p);
 /* Launch shape of the lane-per-instance kernels as of the most recent zab_process: instances per wavefront and the
  * number of mem[] words per instance held in LDS for the length of a launch (0: the arena is read in place). */
 int zab_launch_shape(zab_engine* e, int32_t* instances_per_wave, int32_t* lds_mem_words);
+/* A leaf's generated time-parallel kernel hands an instance back to the serial section code when a chunk breaks one of the
+ * lowering's run-time conditions (a delay line that does not advance by one cell per frame, reads that fall into a freshly written
+ * span, events thicker than one frame in sixteen ...): results are the same, time is not. For the most recent zab_process call
+ * (waits for it): how many launches of an instance were finished serially, and how many frames that was. Zero for leaves without
+ * such a kernel. No reference counterpart: the reference has one execution path. */
+int zab_handback_stats(zab_engine* e, uint64_t* instances, uint64_t* frames);
 
 /* ---- one job over several GPUs of a node -------------------------------------------------------------------
  * The reference runs one plugin instance per audio thread; a batch job is N independent instances, so it shards by instance:

@@ -135,6 +135,8 @@ def run_one(zabatch, args, leaf, meta, nch, row, mem_cap):
                 row.update(status="ok", kernel_ms=ms, launches=launches, fast_path=bool(e.used_fast_path()), kernel=e.last_kernel_name(),
                            msamples_per_s=n * nch * args.frames / (ms * 1e-3) / 1e6,
                            realtime_factor=args.frames / 48000.0 / (ms * 1e-3))
+                if row["kind"] == "jsfx" and row["fast_path"]:     # a generated time-parallel kernel: how much of the launch it handed to the serial tail
+                    row["handed_back_instances"], row["handed_back_frames"] = (int(x) for x in e.handback())
                 if not row["fast_path"]:         # generic path: instances per wavefront and the LDS window over mem[] it ran with
                     row["instances_per_wave"], row["lds_mem_words"] = (int(x) for x in e.launch_shape())
                     row["mem_high"] = int(max(e.mem_high()))

@@ -372,7 +372,7 @@ int zab_create(const char* module, const zab_config* cfg, zab_engine** out) {
       (rc = e->alloc(&b.mem_high, (size_t)P)) || (rc = e->alloc(&b.mem_need, (size_t)P)) ||
       (rc = e->alloc(&b.err, (size_t)P)) || (rc = e->alloc(&b.flags, (size_t)P)) ||
       (rc = e->alloc(&b.pend, (size_t)P * 4)) ||      /* change / automate / automate-end, + their OR since the host last looked */ (rc = e->alloc(&b.vis_mask, (size_t)P)) ||
-      (rc = e->alloc(&b.vis_init, (size_t)P)) || (rc = e->alloc(&b.resume, (size_t)P)) ||
+      (rc = e->alloc(&b.vis_init, (size_t)P)) || (rc = e->alloc(&b.resume, (size_t)P + 8)) ||     /* + the two hand-back counters, zab_handback_stats */
       (m->fft_scratch_doubles > 0 && (rc = e->alloc(&b.fft, (size_t)P * m->fft_scratch_doubles))) ||
       (m->uses_gmem && (rc = setup_gmem(e))) ||
       (m->uses_files && ((rc = e->alloc(&e->d_files, 1)) || (rc = e->alloc(&b.fh, (size_t)P * kFileHandleWords)))) ||
@@ -681,6 +681,7 @@ int zab_process(zab_engine* e, const void* in, void* out, int64_t frames, int64_
   if (block > e->cfg.max_block) return fail(ZAB_E_ARG, "zab_process: block %d > max_block %d", block, e->cfg.max_block);
   if (nch > 0 && e->mod->has_sample && (!in || !out)) return fail(ZAB_E_ARG, "zab_process: null audio buffer");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  if (e->b.resume) HIP_TRY(hipMemsetAsync(e->b.resume + e->b.n_pad, 0, 2 * sizeof(int64_t), e->stream));     // hand-back counters of this call
   ZabAudio a{};
   a.frames = frames; a.frame_stride = frame_stride; a.block = block;
   const int64_t bytes = (int64_t)e->b.n_inst * nch * frame_stride * (int64_t)sizeof(float);
@@ -1098,6 +1099,18 @@ int zab_launch_shape(zab_engine* e, int32_t* instances_per_wave, int32_t* lds_me
   if (!e) return fail(ZAB_E_ARG, "zab_launch_shape: null engine");
   if (instances_per_wave) *instances_per_wave = e->b.ipw;
   if (lds_mem_words) *lds_mem_words = e->b.lmem_words;
+  return ZAB_OK;
+}
+int zab_handback_stats(zab_engine* e, uint64_t* instances, uint64_t* frames) {
+  if (!e) return fail(ZAB_E_ARG, "zab_handback_stats: null engine");
+  uint64_t h[2] = {0, 0};
+  if (e->b.resume) {
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipMemcpyAsync(h, e->b.resume + e->b.n_pad, sizeof(h), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+  }
+  if (instances) *instances = h[0];
+  if (frames) *frames = h[1];
   return ZAB_OK;
 }
 const char* zab_last_kernel_name(zab_engine* e) {

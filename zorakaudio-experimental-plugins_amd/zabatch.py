@@ -63,7 +63,7 @@ ABI_SYMBOLS = [
     "zab_var_index", "zab_set_sliders", "zab_get_sliders", "zab_consume_slider_changes", "zab_prepare", "zab_process", "zab_sync", "zab_read_vars",
     "zab_read_mem", "zab_write_mem", "zab_read_mem_high", "zab_device_alloc", "zab_device_free", "zab_device_upload",
     "zab_device_download", "zab_device_noise", "zab_last_timing", "zab_timing_history", "zab_stream",
-    "zab_used_fast_path", "zab_last_kernel_name", "zab_launch_shape", "zab_host_alloc", "zab_host_free", "zab_state_upload", "zab_state_download", "zab_run_section", "zab_gmem_read", "zab_gmem_write", "zab_gmem_seq", "zab_pool_upload", "zab_file_slot_set",
+    "zab_used_fast_path", "zab_last_kernel_name", "zab_launch_shape", "zab_handback_stats", "zab_host_alloc", "zab_host_free", "zab_state_upload", "zab_state_download", "zab_run_section", "zab_gmem_read", "zab_gmem_write", "zab_gmem_seq", "zab_pool_upload", "zab_file_slot_set",
     "zab_group_create", "zab_group_destroy", "zab_group_size", "zab_group_shard", "zab_group_set_sliders", "zab_group_prepare",
     "zab_group_process", "zab_group_sync", "zab_group_reduce",
 ]
@@ -114,6 +114,7 @@ def load_runtime():
     L.zab_last_kernel_name.argtypes = [vp]
     L.zab_last_kernel_name.restype = C.c_char_p
     L.zab_launch_shape.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.zab_handback_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.zab_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
     L.zab_host_free.argtypes = [vp]
     L.zab_state_upload.argtypes = [vp, i32, C.POINTER(zab_host_state)]
@@ -324,6 +325,12 @@ class Engine:
 
     def last_kernel_name(self) -> str:
         return self.L.zab_last_kernel_name(self.h).decode()
+
+    def handback(self):
+        """(instance-launches the time-parallel kernel handed to the serial section code, frames run there) in the last process call."""
+        n, f = C.c_uint64(0), C.c_uint64(0)
+        self._chk(self.L.zab_handback_stats(self.h, C.byref(n), C.byref(f)))
+        return n.value, f.value
 
     def launch_shape(self):
         """(instances per wavefront, mem[] words per instance held in LDS) of the lane-per-instance kernels."""

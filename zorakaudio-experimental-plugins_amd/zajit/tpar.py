@@ -3644,6 +3644,9 @@ class _Emit:
         L.append("  if (inst >= b.n_inst) return;")
         L.append("  const int64_t from = b.resume[inst];")
         L.append("  if (from >= a.frames) return;")
+        L.append("  // (what the host can ask for afterwards, zab_handback_stats: instances handed back in this zab_process call, frames run here)")
+        L.append("  atomicAdd((unsigned long long*)&b.resume[b.n_pad], 1ull);")
+        L.append("  atomicAdd((unsigned long long*)&b.resume[b.n_pad + 1], (unsigned long long)(a.frames - from));")
         L.append("  ZaS s;")
         L.append("  za_state_load(s, b, inst);")
         L.append("  uint64_t pend_seen = 0;")
