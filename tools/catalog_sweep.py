@@ -4,7 +4,8 @@
 
 Per row, beside the device numbers: `cpu_port_msamples_16c` -- the leaf's CPU checker (oracle/port.py, or oracle/faust_ref.c for
 the Faust leaves) on this box's host cores, one instance per thread for --cpu-seconds; `vs_cpu` = device rate / that;
-`hbm_frac` = the audio a launch must move (4 B in + 4 B out per channel and frame) / kernel time / 8 TB/s; `speedup_vs_r02` =
+(a measurement harness like bench.py's `cpu_baseline` leg: the checker is timed beside the device, never in its place; with
+--cpu-seconds 0 nothing under oracle/ is touched) `hbm_frac` = the audio a launch must move (4 B in + 4 B out per channel and frame) / kernel time / 8 TB/s; `speedup_vs_r02` =
 the previous round's kernel time for the same batch / this one.
 
 Leaves whose script reaches a host-only builtin (buffer messages, peer names) are reported as "host-assisted": the engine
