@@ -132,14 +132,50 @@ def test_rare_heavy_branches_become_events():
     assert plan is not None and plan.event_exposed == ["t"], msg
     plan, msg = _plan_of_text("n += 1; t = spl0 * 2; n >= 64 ? ( y = t + 1; fft(buf, 64); n = 0; ); spl0 = y;")
     assert plan is not None and plan.event_exposed == [], msg
-    # inside a loop, or with an else arm, or valued: left alone (and then unsupported for what the body holds)
-    plan, msg = _plan_of_text("k = 0; loop(2, k >= 1 ? ( fft(buf, 64); ); k += 1; ); spl0 = buf[0];")
-    assert plan is None and "fft" in msg, msg
+    # with an else arm: left alone (and then unsupported for what the body holds)
     plan, msg = _plan_of_text("n += 1; n >= 64 ? ( fft(buf, 64); n = 0; ) : ( buf[n] = spl0; );")
     assert plan is None, msg
-    # the condition must not read memory
+
+
+def test_statements_the_lowering_cannot_take_become_events():
+    """Round 4: split_events picks the obvious rare branches up front; beyond that ANY conditional without an else arm, loop or
+    right operand of && / || whose body the walk cannot lower -- wherever @sample reaches it, user functions included -- runs as
+    an event under its own condition (FrameGraph._or_event), and the innermost such statement is the one chosen. Inside a uniform
+    loop the condition must be wave-uniform per trip: it is tested trip by trip before a segment starts (LoopInfo.guards)."""
+    from zajit import tpar
+    # a condition over a mem[] cell (a named state, not a read at a moving address)
     plan, msg = _plan_of_text("buf[9] += 1; buf[9] >= 64 ? ( fft(buf + 64, 64); buf[9] = 0; ); spl0 = buf[70];")
-    assert plan is None, msg
+    assert plan is not None and plan.stats["events"] == 1 and plan.stats["dyn_events"] == 1, msg
+    # inside a function, two levels down
+    plan, msg = _plan_of_text("n += 1; tick(n); spl0 = buf[0];",
+                              init="function work() ( fft(buf, 64); ); function tick(k) ( k >= 64 ? ( work(); n = 0; ); );")
+    assert plan is not None and plan.stats["events"] == 1 and "fft" in plan.dyn_events[0], msg
+    # a loop whose trip count differs from frame to frame: the frames in which it runs at all
+    plan, msg = _plan_of_text("n = floor(abs(spl0) * 8); k = 0; loop(n, k += 1); spl0 = k;")
+    assert plan is not None and plan.stats["events"] == 1 and "count differs" in plan.dyn_events[0], msg
+    plan, msg = _plan_of_text("k = 0; while (k < abs(spl0) * 4) ( k += 1; ); spl1 = k;")
+    assert plan is not None and plan.stats["events"] == 1, msg
+    # the right operand of a short circuit
+    plan, msg = _plan_of_text("n += 1; (n >= 64) && ( fft(buf, 64); n = 0; ); spl0 = buf[0];")
+    assert plan is not None and plan.stats["events"] == 1, msg
+    # found after the walk: a conditional store into a delay line that @sample reads
+    plan, msg = _plan_of_text("abs(spl0) > 0.5 ? ( ring[wp] = spl0; ); spl1 = ring[wp - 5]; wp += 1;", init="ring = 3000; wp = 100;")
+    assert plan is not None and plan.stats["events"] == 1 and "conditional store" in plan.dyn_events[0], msg
+    # inside a uniform loop: a guard of the loop, wave-uniform per trip (here: a cell only the event's body stores to)
+    plan, msg = _plan_of_text("k = 0; loop(4, act[k] > 0 ? ( fft(buf + 64 * k, 64); act[k] = 0; ); k += 1; ); spl0 = buf[0];",
+                              init="act = 500; buf = 1000;")
+    assert plan is not None and plan.stats["events"] == 0 and plan.stats["loop_guards"] == 1, msg
+    with pytest.raises(NotImplementedError):
+        plan.simulate({}, np.zeros((2, 64), dtype=np.float32))
+    text = tpar.emit_hip(plan, plan.g.p)
+    assert "zpg" in text and "zt_frame(" in text
+    # ... where the condition differs from frame to frame the loop itself is the event
+    plan, msg = _plan_of_text("k = 0; loop(nb, abs(spl0) > thr[k] ? ( fft(buf + 64 * k, 64); ); k += 1; ); spl0 = buf[0];",
+                              init="thr = 500; buf = 1000; nb = 4;")
+    assert plan is not None and plan.stats["loops"] == 0 and plan.stats["events"] == 1, msg
+    # a statement that runs in every frame is no event
+    plan, msg = _plan_of_text("k = 0; loop(4, buf[pos + k] = spl0; k += 1; ); pos += 1; spl0 = buf[pos - 9];", init="buf = 1000; pos = 50;")
+    assert plan is None and "inside a loop" in msg, msg
 
 
 def test_wrapped_counters_have_a_closed_form(monkeypatch):
@@ -194,12 +230,8 @@ def test_unsupported_scripts_keep_the_generic_kernel_only():
     from zajit import program, tpar
     for sample, why in (
             ("buf[wp & 63] = spl0; wp += 1; fft(buf, 64); spl0 = buf[3];", "builtin fft"),      # (in every frame: no event to cut out)
-            ("n = floor(abs(spl0) * 8); k = 0; loop(n, k += 1); spl0 = k;", "count differs from frame to frame"),
-            ("k = 0; while (k < abs(spl0) * 4) ( k += 1; ); spl1 = k;", "condition differs from frame to frame"),
             ("acc = 0; k = 0; loop(4, acc = acc * 0.5 + st; k += 1; ); st = acc + spl0; spl0 = st;", "runs through a loop"),
             ("k = 0; loop(4, buf[pos + k] = spl0; k += 1; ); pos += 1; spl0 = buf[pos - 9];", "inside a loop"),
-            ("abs(spl0) > 0.5 ? ( ring[wp] = spl0; ); spl1 = ring[wp - 5]; wp += 1;", "conditional store to a delay line"),
-            ("ring[wp] = spl0; ring[wp] += spl1; wp += 1; spl0 = ring[wp - 7];", "two writes into one delay line"),
             ("k = 0; loop(3, j = 0; loop(2, tab[k * 2 + j] += spl0; j += 1; ); k += 1; );", "nested loop"),
             ("k = 0; loop(3, r = rand(1); k += 1; ); spl0 = r;", "rand() inside a loop")):
         plan, msg = _plan_of_text(sample, init="buf = 1000; ring = 3000; tab = 5000; wp = 100; pos = 50;")
@@ -225,20 +257,66 @@ def test_two_writes_that_touch_one_cell_hand_the_chunk_back():
     assert y[1, 100] == np.float32(np.float64(x[0, 81]) - np.float64(x[0, 98]))
 
 
-def test_delay_lines_that_share_a_buffer_hand_the_launch_back():
-    """Spectral/Alias: its six intdelay() lines all live at mem[0] (the instance variable `buf` is never set). The lowering takes
-    differently named buffers to be different; the run-time check on reads that fall into another write's span catches that they
-    are not, at the first chunk (the leaf therefore keeps the generic kernel: zajit/build.py NO_TPAR)."""
-    from zajit import tpar
+def test_writes_into_one_delay_line_move_in_step():
+    """Round 4. Spectral/Alias: its six intdelay() lines all live at mem[0] (the instance variable `buf` is never set, so it does
+    not tell buffers apart: FrameGraph.never_assigned). Several writes into one delay line per frame are fine while they move
+    in step -- the same cell in the same frame: a read takes the last write in front of it in (frame, program) order, the late
+    stores go out in program order; writes that meet any other way hand the chunk back. Ring positions written with a mask,
+    `pos = (pos + 1) & 2047` under a block-constant condition, are wrapped counters."""
     plan, _ = _plan("Alias")
     assert plan.stats["guards"] == 1 and plan.stats["delay_writes"] == 9 and plan.stats["sparse_writes"] == 3
-    g = load_golden("Alias_default")
-    names = [str(s) for s in g["var_names"]]
-    v0 = {n: (0.0 if np.isnan(v) else float(v)) for n, v in zip(names, g["vars_prepared"])}
-    mem0, _ = _prepared_arena("Alias", g)
+    assert plan.stats["wrapped_counters"] == 6
+    assert len({s.region for s in plan.stores if s.mode == "late"}) == 1
+    for case in ("Alias_default", "Alias_alt"):
+        g = load_golden(case)
+        names = [str(s) for s in g["var_names"]]
+        v0 = {n: (0.0 if np.isnan(v) else float(v)) for n, v in zip(names, g["vars_prepared"])}
+        mem0, high0 = _prepared_arena("Alias", g)
+        y, va, _ = plan.simulate(v0, golden_input(g), sliders=g["sliders"], srate=float(g["srate"]), mem=mem0)
+        assert np.abs(y.astype(np.float64) - g["out"]).max() <= AUDIO_EPS
+        assert_state_close(names, [va.get(n, 0.0) for n in names], g["vars"], what=f"{case} vars")
+        want = np.zeros(len(mem0)); want[g["mem_idx"]] = g["mem_val"]
+        assert np.abs(plan.mem_after - want).max() <= SCALAR_EPS
+        assert max(plan.mem_high_after, high0) == int(g["mem_high"])
+    # read-modify-write of the cell just written, and a second line through the same cells one frame apart (not in step)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((2, 200)).astype(np.float32)
+    plan, msg = _plan_of_text("ring[wp] = spl0; ring[wp] += spl1; wp += 1; spl0 = ring[wp - 7];", init="ring = 3000; wp = 100;")
+    assert plan is not None, msg
+    y, va, _ = plan.simulate({"ring": 3000.0, "wp": 100.0}, x)
+    want = np.zeros(200); want[6:] = (x[0].astype(np.float64) + x[1])[:-6]
+    assert np.array_equal(y[0], want.astype(np.float32)) and va["wp"] == 300.0
+    from zajit import tpar
+    plan, msg = _plan_of_text("ring[wp] = spl0; ring[wp + 1] = spl1; wp += 1; spl0 = ring[wp - 7];", init="ring = 3000; wp = 100;")
     with pytest.raises(tpar.TparAbort) as ei:
-        plan.simulate(v0, golden_input(g)[:, :256], sliders=g["sliders"], srate=float(g["srate"]), mem=mem0)
-    assert ei.value.f0 == 0 and "another buffer" in ei.value.why
+        plan.simulate({"ring": 3000.0, "wp": 100.0}, x)
+    assert "touch one cell" in ei.value.why
+
+
+def test_feedback_through_a_delay_line_cuts_the_chunk():
+    """Round 4: y[t] = x[t] + g y[t - D] through a ring. While D >= 64 no frame of a chunk reads what the chunk writes and the loop
+    closes over memory; a shorter delay ends the chunk before the first frame that would (the next segment starts there);
+    below 16 frames the serial code takes over."""
+    from zajit import tpar
+    text = "y = spl0 + 0.5 * ring[rp]; ring[wp] = y; wp = (wp + 1) & 127; rp = (rp + 1) & 127; spl0 = y; spl1 = rp;"
+    plan, msg = _plan_of_text(text, init="ring = 1000;")
+    assert plan is not None and [sorted(ld.fb) for ld in plan.loads] == [[0]], msg
+    kinds = [it[0] for it in plan.top.items]
+    assert kinds.count("cut") == 1 and "site" not in kinds[:kinds.index("cut")]
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((2, 500)).astype(np.float32)
+    for D, cuts in ((100, 0), (64, 0), (40, 12), (17, 29)):
+        y, va, _ = plan.simulate({"ring": 1000.0, "wp": 5.0, "rp": float((5 - D) & 127)}, x)
+        ref = np.zeros(500)
+        for t in range(500):
+            ref[t] = np.float64(x[0, t]) + 0.5 * (ref[t - D] if t >= D else 0.0)
+        assert np.array_equal(y[0], ref.astype(np.float32)) and plan.fb_cuts == cuts, D
+        assert va["wp"] == float((5 + 500) & 127)
+    with pytest.raises(tpar.TparAbort) as ei:
+        plan.simulate({"ring": 1000.0, "wp": 5.0, "rp": float((5 - 10) & 127)}, x)
+    assert "shorter than 16" in ei.value.why
+    text = tpar.emit_hip(plan, plan.g.p)
+    assert "zt_fbc" in text
 
 
 def test_what_used_to_be_unsupported_now_plans():

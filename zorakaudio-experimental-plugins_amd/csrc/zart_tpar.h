@@ -103,6 +103,8 @@ __device__ __forceinline__ bool zt_sites_ok(int64_t a0, int64_t s0, int64_t lo0,
 
 // an integer small enough that sums and products of a few of them stay exact in a double (loop counters run in strips: i0 + k * step)
 __device__ __forceinline__ bool zt_small_int(double x) { return x == floor(x) && fabs(x) < 1.0e12; }
+// ... that is a power of two (ring lengths written as masks: (pos + 1) & (N - 1))
+__device__ __forceinline__ bool zt_pow2(double x) { const long long v = (long long)x; return v >= 1 && (v & (v - 1)) == 0; }
 
 // LDS doubles for the staged windows of the rings a uniform loop gathers from (zajit/tpar.py RingGroup): 24 KB keeps four
 // wavefronts per CU beside the other tables; a window that does not fit leaves its loop on the gathers from memory

@@ -56,10 +56,6 @@ NO_TPAR: Dict[str, str] = {
     # no audio path at all: the leaf is its @block (msg / gmem bookkeeping), which the lane-per-instance kernel runs with the
     # state in registers from block to block (256 instances x 48 000 frames: 1124 ms against 1570 ms here)
     "3DPannerManager": "@sample is empty: nothing to run time-parallel",
-    # its six intdelay() lines all sit at mem[0] (the instance variable `buf` is never set: Alias.jsfx:100-108), so what the
-    # lowering takes for six buffers is one: every chunk fails the check on reads that fall into another write's span and would
-    # be handed back to the serial code (tests/test_tpar.py pins that)
-    "Alias": "its delay lines share one buffer: every chunk would be handed back",
 }
 LONG_BRANCH_LIMIT = 32
 # leaves whose state the hand-written kernel wants contiguous per instance

@@ -61,13 +61,16 @@ class Unsupported(Exception):
 
 
 class N:
-    __slots__ = ("i", "kind", "op", "args", "val", "name", "uniform", "su", "extra", "loop")
+    __slots__ = ("i", "kind", "op", "args", "val", "name", "uniform", "su", "extra", "loop", "ctx", "fb")
 
     def __init__(self, i, kind, op=None, args=(), val=None, name=None):
         self.i, self.kind, self.op, self.args, self.val, self.name = i, kind, op, tuple(args), val, name
         self.uniform = False
         self.su = False          # wave-uniform, known while walking: built from constants, variables @sample never assigns and
         #                          uniform loop counters
+        self.ctx = ()            # ld: the statements around it that could run as events instead (FrameGraph.ctx)
+        self.fb = frozenset()    # ld in a feedback loop through its delay line: the writes (StoreSite.j) whose values depend on it --
+        #                          never forwarded from, the chunk is cut short instead
         self.extra = ()          # ld: nodes this load must wait for besides its address (the stores it may have to forward from)
         self.loop = None         # innermost uniform loop this node's value changes in (None: once per frame)
 
@@ -107,6 +110,8 @@ class LoopInfo:
         self.cell_out: Dict[str, N] = {}         # -> the value this frame stores (cells the loop never stores to: absent)
         self.cell_flag: Dict[str, N] = {}        # -> "a store to this cell ran in this frame" (the arena's high-water mark)
         self.children: List["LoopInfo"] = []
+        self.guards: List[N] = []                # conditions (wave-uniform per trip) of statements of the body that became events
+        self.ctx: tuple = ()                     # the statements around the loop (itself included) that could run as events instead
 
     def inside(self, other: Optional["LoopInfo"]) -> bool:
         """self is `other` or nested in it (other None: the frame itself)."""
@@ -140,12 +145,28 @@ def _reachable_fns(prog: Program, roots) -> List[str]:
     return seen
 
 
-def _assigned_names(prog: Program, roots, shadow=()) -> set:
-    """Variables assigned by `roots` or a function they can reach (parameters of those functions are their own)."""
+def _event_head(x):
+    """What still runs in every frame of a statement the lowering has turned into an event (FrameGraph.event_ids): its
+    condition / count / left operand. The rest is the event's body, which only the serial section code ever runs."""
+    if isinstance(x, (S.Cond, S.If, S.While)):
+        return x.cond
+    if isinstance(x, S.Loop):
+        return x.count
+    if isinstance(x, S.Binary):
+        return x.l
+    raise AssertionError(type(x))
+
+
+def _assigned_names(prog: Program, roots, shadow=(), skip=frozenset()) -> set:
+    """Variables assigned by `roots` or a function they can reach (parameters of those functions are their own). Statements
+    whose id is in `skip` are events: only their heads count."""
     out = set()
     seen = set()
 
     def walk(x, sh):
+        if id(x) in skip:
+            walk(_event_head(x), sh)
+            return
         if isinstance(x, S.Assign) and isinstance(x.target, S.Var) and x.target.name not in sh:
             out.add(x.target.name)
         if isinstance(x, S.Call) and x.fn in prog.fns and x.fn not in seen:
@@ -245,7 +266,7 @@ def _heavy(prog: Program, x, seen=None) -> bool:
 EVENT = "__event"
 
 
-def split_events(prog: Program, stmts):
+def split_events(prog: Program, stmts, keep=frozenset(), origin=None, cache=None):
     """Statements `C ? ( ... )` (no else) of @sample -- at the top or inside other conditionals, not inside loops or functions --
     whose body is heavy (_heavy) and whose condition is a plain expression: the "every hop: run the FFT" / "buffer full: convolve
     a block" idiom. The lowering replaces each by a marker that keeps the condition; the kernel evaluates the conditions first in
@@ -254,24 +275,41 @@ def split_events(prog: Program, stmts):
     dropped = []
 
     def rw(x, stmt: bool):
+        # (what holds no event keeps its identity: FrameGraph.event_ids names statements by it, from one build of the plan to the next)
         if isinstance(x, S.Seq):
             n = len(x.items)
-            return S.Seq([rw(it, stmt or k + 1 < n) for k, it in enumerate(x.items)], line=x.line, col=x.col)
+            items = [rw(it, stmt or k + 1 < n) for k, it in enumerate(x.items)]
+            if all(a is b for a, b in zip(items, x.items)):
+                return x
+            return S.Seq(items, line=x.line, col=x.col)
         if isinstance(x, (S.Cond, S.If)):
             st = stmt or isinstance(x, S.If)
             if (st and x.then is not None and (x.els is None or isinstance(x.els, S.Num)) and _pure_scalar(prog, x.cond)
-                    and _heavy(prog, x.then)):
+                    and _heavy(prog, x.then) and id(x) not in keep):
                 dropped.append(x)
-                return S.Call(EVENT, [x.cond], line=x.line, col=x.col)
-            return type(x)(x.cond, rw(x.then, st) if x.then is not None else None,
-                           rw(x.els, st) if x.els is not None else None, line=x.line, col=x.col)
+                mark = S.Call(EVENT, [x.cond], line=x.line, col=x.col)
+                if origin is not None:
+                    origin[id(mark)] = x
+                return mark
+            th = rw(x.then, st) if x.then is not None else None
+            el = rw(x.els, st) if x.els is not None else None
+            if th is x.then and el is x.els:
+                return x
+            return type(x)(x.cond, th, el, line=x.line, col=x.col)
         return x
 
+    key = (tuple(id(st) for st in stmts), frozenset(keep))
+    if cache is not None and cache.get("key") == key:
+        if origin is not None:
+            origin.update(cache["origin"])
+        return cache["out"], cache["dropped"]
     out = [rw(st, True) for st in stmts]
+    if cache is not None:
+        cache.update(key=key, out=out, dropped=dropped, origin=dict(origin or {}))
     return out, dropped
 
 
-def exposed_vars(prog: Program, stmts) -> set:
+def exposed_vars(prog: Program, stmts, skip=frozenset()) -> set:
     """Variables whose value from the previous frame some path of the frame can read (a read not preceded, on that path, by a
     write of the same frame). Mirrors FrameGraph's order of evaluation; conservative (a loop body may run zero times, the
     right operand of && / || may not run)."""
@@ -279,6 +317,9 @@ def exposed_vars(prog: Program, stmts) -> set:
     depth = [0]
 
     def ev(x, d: set, sh: frozenset):
+        if id(x) in skip:
+            ev(_event_head(x), d, sh)
+            return
         if isinstance(x, (S.Num, S.Str)):
             return
         if isinstance(x, S.Var):
@@ -339,8 +380,19 @@ def exposed_vars(prog: Program, stmts) -> set:
 # 1. one frame of @sample as a DAG
 # ----------------------------------------------------------------------------------------------------------------------
 class FrameGraph:
-    def __init__(self, prog: Program, nch: int, stmts=None):
+    def __init__(self, prog: Program, nch: int, stmts=None, event_ids=None, no_event=None):
         self.p, self.nch = prog, nch
+        # statements (by id of their syntax node, anywhere @sample reaches) that run as EVENTS: their condition is part of the
+        # frame, their body is not -- the frame one falls on runs with the serial section code. split_events picks the obvious
+        # ones up front; the walk adds every conditional / loop whose body it cannot lower (`_or_event`), and the plan is then
+        # built again with the set known from the start (what @sample assigns, and so what is an invariant, depends on it).
+        self.event_ids: set = set() if event_ids is None else event_ids
+        self.no_event: set = set() if no_event is None else no_event      # ... whose condition proved unusable: never again
+        self.new_events = 0
+        self.reasons: Dict[int, str] = {}         # id of a statement -> why an earlier build of the plan made it an event
+        self.event_why: Dict[int, str] = {}
+        self.event_src: Dict[int, int] = {}      # event condition node -> id of the statement it came from
+        self.ctx: List = []                      # statements being lowered that could run as events instead, outermost first
         self.nodes: List[N] = []
         self.memo: Dict[tuple, N] = {}
         self.env: Dict[str, N] = {}
@@ -352,8 +404,13 @@ class FrameGraph:
         self.stmts = list(prog.sections.get("sample", [])) if stmts is None else list(stmts)
         # variables assigned anywhere in @sample (or a function it can reach): everything else is constant over a block, which
         # lets the walk tell block-constant addresses (mem[] cells used as named state) from moving ones (delay lines)
-        self.wsyn = _assigned_names(prog, self.stmts)
-        self.exposed = set(prog.vars) if os.environ.get("ZA_TPAR_NO_HOLD") else exposed_vars(prog, self.stmts)
+        skip = frozenset(self.event_ids)
+        # variables no section ever assigns (and no builtin can: out-arguments) are 0 for good. A script that keeps a buffer's base
+        # in one (Alias: `instance(buf, pos)` with buf never set) has all such buffers at mem[0]: such names do not tell regions apart
+        everything = [st for sec in prog.sections.values() for st in sec]
+        self.never_assigned = set(prog.vars) - _assigned_names(prog, everything) - _outarg_names(prog, everything) - set(prog.aliases.values())
+        self.wsyn = _assigned_names(prog, self.stmts, skip=skip)
+        self.exposed = set(prog.vars) if os.environ.get("ZA_TPAR_NO_HOLD") else exposed_vars(prog, self.stmts, skip=skip)
         self.pred: Optional[N] = None            # path condition of the statement being walked (None: unconditional)
         self.mem_seq = 0                         # program order of the memory operations of a frame
         self.cells: Dict[str, N] = {}            # "mem@<id>" -> its (block-constant) address node
@@ -509,7 +566,8 @@ class FrameGraph:
             x = todo.pop()
             if x.kind == "op" and x.op == "+":
                 todo.extend(x.args)
-            elif x.su and x.loop is None and not (x.kind == "const" and x.val == 0.0):
+            elif (x.su and x.loop is None and not (x.kind == "const" and x.val == 0.0)
+                  and not (x.kind in ("var", "inv") and x.name in self.never_assigned)):
                 terms.append(x.i)
         return tuple(sorted(terms))
 
@@ -527,6 +585,7 @@ class FrameGraph:
             return self.read(self._cell(a))
         self.mem_seq += 1
         ld = self.mk("ld", args=(a,), val=self.mem_seq)
+        ld.ctx = tuple(self.ctx)
         self.loads.append(ld)
         return ld
 
@@ -541,7 +600,7 @@ class FrameGraph:
         if self.loop_stack:
             raise Unsupported("store to a moving mem[] address inside a loop")
         self.mem_seq += 1
-        self.stores.append(StoreSite(len(self.stores), a, v, self.pred, self.mem_seq, self._region(a)))
+        self.stores.append(StoreSite(len(self.stores), a, v, self.pred, self.mem_seq, self._region(a), tuple(self.ctx)))
 
     def v_Index(self, n):
         return self._load(self._address(n))
@@ -565,13 +624,14 @@ class FrameGraph:
             raise Unsupported("loop() count differs from frame to frame")
         roots = [x for x in (body_ast, cond_ast) if x is not None]
         # (parameters of the enclosing function are locals of this call: their canonical names)
-        carried = sorted({self._canon(nm) for nm in _assigned_names(self.p, roots)})
+        carried = sorted({self._canon(nm) for nm in _assigned_names(self.p, roots, skip=frozenset(self.event_ids))})
         uniform = set(carried)
         parent = self.loop_stack[-1] if self.loop_stack else None
         for _attempt in range(64):
             snap = self._snapshot()
             self.loop_ids += 1
             L = LoopInfo(self.loop_ids, parent)
+            L.ctx = tuple(self.ctx)
             L.count = count
             env0 = self.env
             self.env = dict(env0)
@@ -612,6 +672,9 @@ class FrameGraph:
                 uniform = (uniform | set(extra)) - set(lost)
                 self._restore(snap)
                 continue
+            for gc in L.guards:
+                if not self._trip_uniform(gc, L, {}):
+                    raise Unsupported("event inside a loop with a condition that differs from frame to frame")
             for v in carried:
                 L.next[v] = self.env[v]
             env1 = dict(env0)
@@ -632,18 +695,113 @@ class FrameGraph:
         raise Unsupported("loop analysis did not settle")
 
     def v_Loop(self, n):
-        r0 = self.rand_sites
-        v = self._loop(n.body, n.count, None)
-        if self.rand_sites != r0:
-            raise Unsupported("rand() inside a loop")
-        return v
+        def lower():
+            r0 = self.rand_sites
+            v = self._loop(n.body, n.count, None)
+            if self.rand_sites != r0:
+                raise Unsupported("rand() inside a loop")
+            return v
+
+        # as an event: the frames in which the loop runs at all (za_loopcount(count) >= 1)
+        return self._or_event(n, lower, lambda: self.op(">=", self.ev(n.count), self.ONE), self.ZERO)
 
     def v_While(self, n):
-        r0 = self.rand_sites
-        v = self._loop(n.body, None, n.cond)
-        if self.rand_sites != r0:
-            raise Unsupported("rand() inside a loop")
-        return v
+        def lower():
+            r0 = self.rand_sites
+            v = self._loop(n.body, None, n.cond)
+            if self.rand_sites != r0:
+                raise Unsupported("rand() inside a loop")
+            return v
+
+        return self._or_event(n, lower, lambda: self.ev(n.cond), self.ZERO)
+
+    # -- statements the lowering cannot take become events ------------------------------------------------------------------------
+    def _checkpoint(self):
+        return (self._snapshot(), list(self.events), dict(self.event_src), list(self.scope), self.depth, self.pred,
+                list(self.loop_stack), [list(L.guards) for L in self.loop_stack])
+
+    def _rollback(self, cp):
+        self._restore(cp[0])
+        self.events, self.event_src = list(cp[1]), dict(cp[2])
+        self.scope, self.depth, self.pred = list(cp[3]), cp[4], cp[5]
+        self.loop_stack = list(cp[6])
+        for L, gs in zip(self.loop_stack, cp[7]):
+            L.guards = list(gs)
+
+    def _touches_memory(self, n: N, memo: Dict[int, bool]) -> bool:
+        if n.i in memo:
+            return memo[n.i]
+        memo[n.i] = False
+        r = n.kind in ("ld", "lout", "lcin", "phi") or n.loop is not None or any(self._touches_memory(a, memo) for a in n.args)
+        memo[n.i] = r
+        return r
+
+    def _trip_uniform(self, n: N, L: LoopInfo, memo: Dict[int, bool]) -> bool:
+        """n is the same for every frame of a block in a given trip of L (whose walk is complete: its stored cells are known)."""
+        if n.i in memo:
+            return memo[n.i]
+        memo[n.i] = False
+        if n.kind == "const":
+            r = True
+        elif n.kind in ("var", "inv", "phi"):
+            r = n.su
+        elif n.kind == "lcin":
+            r = n.name not in L.cell_out and self._trip_uniform(self.lcell_addr[n.name], L, memo)
+        elif n.kind == "op":
+            r = n.op != "mtout" and all(self._trip_uniform(a, L, memo) for a in n.args)
+        else:
+            r = False
+        memo[n.i] = r
+        return r
+
+    def _event_at(self, ast, c: N):
+        """The statement `ast` runs as an event under condition c (and the path's): at the top of the frame it joins the
+        conditions every chunk evaluates first; inside a uniform loop it must be wave-uniform per trip and is tested, trip by
+        trip, before a segment starts (LoopInfo.guards)."""
+        full = c if self.pred is None else self.op("land", self.pred, c)
+        if full.kind == "const" and full.val == 0.0:
+            return
+        if _fold(c) not in (None, 0.0) and (self.pred is None or _fold(self.pred) not in (None, 0.0)):
+            raise Unsupported("a statement that runs in every frame is no event")
+        if self.loop_stack:
+            if len(self.loop_stack) > 1:
+                raise Unsupported("event in a nested loop")
+            self.loop_stack[-1].guards.append(full)
+            return
+        if self._touches_memory(full, {}):
+            raise Unsupported("event condition reads memory or a loop's result")
+        self.events.append(full)
+        self.event_src[full.i] = id(ast)
+
+    def _or_event(self, ast, lower, cond, idle: N) -> N:
+        """lower() -- or, where the lowering refuses what `ast` holds (Unsupported), the statement as an event: cond() is
+        evaluated in every frame, the body only by the serial code in the frames whose condition holds; `idle` is the
+        statement's value in all the others."""
+        if id(ast) in self.event_ids:
+            try:
+                self._event_at(ast, cond())
+            except Unsupported as ex:
+                w = self.reasons.get(id(ast))        # (found after an earlier walk: that is the reason to report)
+                raise Unsupported(w.split(": ", 1)[-1]) if isinstance(w, str) else ex
+            return idle
+        if id(ast) in self.no_event or os.environ.get("ZA_TPAR_NO_DYN_EVENTS"):
+            return lower()
+        cp = self._checkpoint()
+        self.ctx.append(ast)
+        try:
+            return lower()
+        except Unsupported as ex:
+            self._rollback(cp)
+            try:
+                self._event_at(ast, cond())          # (no place / condition for an event: the next statement out gets its
+            except Unsupported:                      #  chance, with the reason the body gave)
+                raise ex
+            self.event_ids.add(id(ast))
+            self.event_why[id(ast)] = f"line {getattr(ast, 'line', '?')}: {ex}"
+            self.new_events += 1
+            return idle
+        finally:
+            self.ctx.pop()
 
     def v_FuncDef(self, n):
         raise Unsupported("nested function definition")
@@ -660,29 +818,34 @@ class FrameGraph:
 
     def v_Binary(self, n):
         if n.op in ("&&", "||"):
-            l = self.ev(n.l)
-            env0, pred0 = self.env, self.pred
-            self.env = dict(env0)
-            gate = l if n.op == "&&" else self.op("not", l)          # the right operand runs iff ...
-            self.pred = gate if pred0 is None else self.op("land", pred0, gate)
-            r = self.ev(n.r)
-            self.pred = pred0
-            env_r = self.env
-            if all(env_r.get(k) is v for k, v in env0.items()) and len(env_r) == len(env0):
-                self.env = env0                      # right operand has no effects: both sides evaluated, plain logic
-                return self.op("land" if n.op == "&&" else "lor", l, r)
-            # short circuit with effects on the right: they happen iff the left operand lets the right one run
-            rb = self.op("truth", r)
-            if n.op == "&&":
-                self.env = self._merge(l, env_r, env0, env0)
-                return self.sel(l, rb, self.ZERO)
-            self.env = self._merge(l, env0, env_r, env0)
-            return self.sel(l, self.ONE, rb)
+            # (`a && ( heavy )` / `a || ( heavy )`: the right operand as an event under a / !a; the idle value is the left's verdict)
+            gate = (lambda: self.ev(n.l)) if n.op == "&&" else (lambda: self.op("not", self.ev(n.l)))
+            return self._or_event(n, lambda: self._short_circuit(n), gate, self.ZERO if n.op == "&&" else self.ONE)
         if n.op not in BIN_OPS:
             raise Unsupported(f"binary {n.op}")
         l = self.ev(n.l)
         r = self.ev(n.r)
         return self.op(n.op, l, r)
+
+    def _short_circuit(self, n):
+        l = self.ev(n.l)
+        env0, pred0 = self.env, self.pred
+        self.env = dict(env0)
+        gate = l if n.op == "&&" else self.op("not", l)          # the right operand runs iff ...
+        self.pred = gate if pred0 is None else self.op("land", pred0, gate)
+        r = self.ev(n.r)
+        self.pred = pred0
+        env_r = self.env
+        if all(env_r.get(k) is v for k, v in env0.items()) and len(env_r) == len(env0):
+            self.env = env0                      # right operand has no effects: both sides evaluated, plain logic
+            return self.op("land" if n.op == "&&" else "lor", l, r)
+        # short circuit with effects on the right: they happen iff the left operand lets the right one run
+        rb = self.op("truth", r)
+        if n.op == "&&":
+            self.env = self._merge(l, env_r, env0, env0)
+            return self.sel(l, rb, self.ZERO)
+        self.env = self._merge(l, env0, env_r, env0)
+        return self.sel(l, self.ONE, rb)
 
     def _lookup_incoming(self, key: str, env0) -> N:
         if key in env0:
@@ -719,11 +882,17 @@ class FrameGraph:
         self.env = self._merge(c, env_t, env_e, env0)
         return c, self.sel(c, vt, ve)
 
+    def _cond_stmt(self, n) -> N:
+        if n.then is None or not (n.els is None or isinstance(n.els, S.Num)):
+            return self._branch(n.cond, n.then, n.els)[1]
+        idle = self.ZERO if n.els is None else self.const(n.els.value)
+        return self._or_event(n, lambda: self._branch(n.cond, n.then, n.els)[1], lambda: self.ev(n.cond), idle)
+
     def v_Cond(self, n):
-        return self._branch(n.cond, n.then, n.els)[1]
+        return self._cond_stmt(n)
 
     def v_If(self, n):
-        self._branch(n.cond, n.then, n.els)
+        self._cond_stmt(n)
         return self.ZERO
 
     def v_Seq(self, n):
@@ -781,10 +950,14 @@ class FrameGraph:
             self.depth -= 1
             return v
         if fn == EVENT:
-            if self.loop_stack or self.depth:
-                raise Unsupported("event inside a loop")
-            c = self.ev(n.args[0])
-            self.events.append(c if self.pred is None else self.op("land", self.pred, c))
+            orig = getattr(self, "event_origin", {}).get(id(n))
+            try:
+                self._event_at(n if orig is None else orig, self.ev(n.args[0]))
+            except Unsupported:
+                if orig is None:
+                    raise
+                self.no_event.add(id(orig))          # no event after all: the statement itself is walked next time
+                raise _Replan()
             return self.ZERO
         if fn.startswith("gfx_") or fn in NOOP_CALLS:
             for a in n.args:
@@ -824,8 +997,9 @@ class FrameGraph:
 class StoreSite:
     """One moving-address store of the frame (a delay line's write)."""
 
-    def __init__(self, j, addr, value, pred, seq, region):
+    def __init__(self, j, addr, value, pred, seq, region, ctx=()):
         self.j, self.addr, self.value, self.pred, self.seq, self.region = j, addr, value, pred, seq, region
+        self.ctx = ctx                            # the statements around it that could run as events instead
         # "late":   the chunk's writes land after all of its reads; a read takes the value an earlier frame of the chunk
         #           writes from that frame's lane (store-to-load forwarding),
         # "early":  written before the reads (which then come from memory): buffers that loops gather from,
@@ -867,6 +1041,8 @@ class Component:
         self.inputs: List[N] = []                # everything outside that the unit reads
         self.modk: Optional[N] = None            # "modc": y' = (y + modk) % modn
         self.modn: Optional[N] = None
+        self.modmask = False                     # ... only with the start inside [0, modn): written as a mask, or a step under a condition
+        self.modpow2 = False                     # ... written as (y + modk) & (modn - 1): modn must be a power of two
         self.reg: "Region" = None
 
 
@@ -982,17 +1158,64 @@ def _in_subtree(n: N, loop: Optional[LoopInfo]) -> bool:
     return n.loop is not None and n.loop.inside(loop)
 
 
+class _BadCone(Unsupported):
+    """An event's condition needs, directly or through the recurrences it reads, memory or a loop's result: it cannot be
+    evaluated ahead of the chunk."""
+
+    def __init__(self, event):
+        super().__init__("event condition reads memory or a loop's result")
+        self.event = event
+
+
+class _Blame(Unsupported):
+    """Something found after the walk (a recurrence through a loop, a conditional store into a delay line ...) that the statements
+    around its source -- `ctx`, outermost first -- could take out of the frame by running as events."""
+
+    def __init__(self, why, ctx):
+        super().__init__(why)
+        self.blame_ctx = tuple(ctx)
+
+
+class _Replan(Exception):
+    """The set of statements that run as events changed: build the plan again with it."""
+
+
 def build_plan(prog: Program, nch: int) -> Plan:
     """Raises Unsupported when the leaf cannot take the time-parallel kernel."""
     if not prog.has("sample") or nch <= 0:
         raise Unsupported("no audio @sample")
     if os.environ.get("ZA_TPAR_NO_BLOCK") and prog.has("block"):
         raise Unsupported("@block present")
+    event_ids: set = set()
+    no_event: set = set()
+    why: Dict[int, str] = {}
+    for _round in range(24):
+        try:
+            plan = _build_plan(prog, nch, event_ids, no_event, why)
+        except _Replan:
+            continue
+        except _Blame as bl:
+            ast = next((x for x in reversed(bl.blame_ctx) if id(x) not in event_ids and id(x) not in no_event), None)
+            if ast is None or os.environ.get("ZA_TPAR_NO_DYN_EVENTS"):
+                raise Unsupported(str(bl))
+            event_ids.add(id(ast))
+            why[id(ast)] = f"line {getattr(ast, 'line', '?')}: {bl}"
+            continue
+        plan.dyn_events = sorted(why[i] for i in event_ids if i in why and isinstance(why[i], str))
+        plan.stats["dyn_events"] = len(plan.dyn_events)
+        return plan
+    raise Unsupported("the set of event statements did not settle")
+
+
+def _build_plan(prog: Program, nch: int, event_ids: set, no_event: set, why: Dict[int, str]) -> Plan:
     stmts, guard_asts = (list(prog.sections["sample"]), []) if os.environ.get("ZA_TPAR_NO_GUARDS") else split_guards(prog)
     ev_bodies = []
+    origin: Dict[int, object] = {}
     if not os.environ.get("ZA_TPAR_NO_EVENTS"):
-        stmts, ev_bodies = split_events(prog, stmts)
-    g = FrameGraph(prog, nch, stmts)
+        stmts, ev_bodies = split_events(prog, stmts, keep=frozenset(no_event), origin=origin, cache=why.setdefault("#split", {}))
+    g = FrameGraph(prog, nch, stmts, event_ids, no_event)
+    g.event_origin = origin
+    g.reasons = why
     guards = [g.ev(c) for c in guard_asts]
     if any(not x.su for x in guards) or g.env:
         raise Unsupported("guard condition is not an invariant")
@@ -1000,6 +1223,11 @@ def build_plan(prog: Program, nch: int) -> Plan:
         g.ev(st)
     if g.scope or g.loop_stack:
         raise AssertionError("scope leak")
+    if g.new_events:
+        # what @sample assigns -- and with it which variables are invariants, states, HOLD carriers -- was judged with these
+        # statements' bodies still counted in: once more, with the set known from the start
+        why.update(g.event_why)
+        raise _Replan()
     if g.rand_sites * WAVE > MT_N:
         raise Unsupported("more rand() calls per chunk than one generation of the generator holds")
     plan = Plan()
@@ -1069,18 +1297,17 @@ def build_plan(prog: Program, nch: int) -> Plan:
     for st_ in plan.stores:
         reg = ",".join(map(str, st_.region))
         same = [ld for ld in plan.loads if ld.name == reg]
-        if sum(1 for o in plan.stores if o.region == st_.region) > 1:
-            raise Unsupported("two writes into one delay line per frame")
+        # (several writes into one delay line per frame -- Alias's six lines at mem[0] -- stay "late": a read takes the last write
+        #  in front of it in (frame, program) order; the chunk checks that such writes move in step, emit_site_pairs)
+        shared = sum(1 for o in plan.stores if o.region == st_.region) > 1
         if st_.pred is not None and not st_.pred.su:
-            if same:
-                raise Unsupported("conditional store to a delay line that @sample reads")
+            if same or shared:
+                raise _Blame("conditional store to a delay line that @sample reads", st_.ctx)
             st_.mode = "sparse"
-        elif (any(ld.loop is not None for ld in same) and all(ld.val > st_.seq for ld in same)
+        elif (not shared and any(ld.loop is not None for ld in same) and all(ld.val > st_.seq for ld in same)
               and not reaches_load(st_.addr, rl_memo) and not reaches_load(st_.value, rl_memo)
               and not os.environ.get("ZA_TPAR_NO_EARLY")):
             st_.mode = "early"
-    if plan.stores and g.loops and any(L.cell_out for L in g.loops):
-        raise Unsupported("delay lines together with per-trip cells (a hand-back could not undo the cells' stores)")
     for ld in plan.loads:
         # a load may have to take its value from a store of this chunk: it waits for every store of its own buffer (address
         # and value) and, for the aliasing check, for the addresses of all the others
@@ -1092,8 +1319,6 @@ def build_plan(prog: Program, nch: int) -> Plan:
             if st_.mode == "early" or ",".join(map(str, st_.region)) == ld.name:
                 ex.append(st_.value)
         ld.extra = tuple(ex)
-    if plan.loads and g.loops and any(L.cell_out for L in g.loops):
-        raise Unsupported("gathers together with per-trip cells")
 
     # ---- live nodes -------------------------------------------------------------------------------------------------------------
     live: Dict[int, N] = {}
@@ -1115,9 +1340,29 @@ def build_plan(prog: Program, nch: int) -> Plan:
                     todo.append(L.cell_flag[key])
             L = L.parent
 
+    def guard_cone(L: LoopInfo):
+        """What a loop's guards need from OUTSIDE the loop is computed per block like any invariant; their nodes inside the loop
+        are evaluated by the loop's address pass only (emit_address_pass), not in the trips themselves."""
+        seen, work = set(), list(L.guards)
+        while work:
+            x = work.pop()
+            if x.i in seen or x.kind == "const":
+                continue
+            seen.add(x.i)
+            if not _in_subtree(x, L):
+                todo.append(x)
+                continue
+            if x.kind == "phi":
+                work.extend((L.init[x.name], L.next[x.name]))
+            elif x.kind == "lcin":
+                work.append(g.lcell_addr[x.name])
+            work.extend(x.args)
+
     for L in g.loops:
-        if L.cell_out:
+        if L.cell_out or L.guards:
             loop_live(L)
+        if L.guards:
+            guard_cone(L)
     while todo:
         n = todo.pop()
         if n.i in live:
@@ -1211,7 +1456,9 @@ def build_plan(prog: Program, nch: int) -> Plan:
     # ---- recurrences of every region ---------------------------------------------------------------------------------------------
     comp_of: Dict[int, Component] = {}
     all_regions = [top] + [regions[L.id] for L in loops]
-    for r in all_regions:
+    plan.fb_loads = []
+
+    def region_comps(r: Region):
         nodes = list(r.nodes)
         pos = {n.i: k for k, n in enumerate(nodes)}
         pseudo = {s.loop.id: len(nodes) + k for k, s in enumerate(r.subs)}
@@ -1228,15 +1475,53 @@ def build_plan(prog: Program, nch: int) -> Plan:
             for x in s.ext:
                 if x.i in pos:
                     succ[pos[x.i]].append(pseudo[s.loop.id])
+        out = []
         for comp in _sccs(len(succ), succ):
             cyclic = len(comp) > 1 or comp[0] in succ[comp[0]]
             if not cyclic:
                 continue
             if any(k >= len(nodes) for k in comp):
-                raise Unsupported("a recurrence over the frames runs through a loop")
-            members = sorted((nodes[k] for k in comp), key=lambda n: n.i)
+                inner = [r.subs[k - len(nodes)].loop for k in comp if k >= len(nodes)]
+                raise _Blame("a recurrence over the frames runs through a loop", inner[0].ctx)
+            out.append(sorted((nodes[k] for k in comp), key=lambda n: n.i))
+        return out
+
+    for r in all_regions:
+        members_of = region_comps(r)
+        for _again in range(4):
+            fb = [m for members in members_of for m in members if m.kind == "ld"]
+            if not fb:
+                break
+            # FEEDBACK THROUGH A DELAY LINE: a stored value depends on a read of the same buffer (a feedback echo, a reverb loop).
+            # While the read lands behind the chunk -- the delay is at least the chunk's length -- nothing of the chunk reaches
+            # it and the loop closes over memory only; so such a read is never forwarded to, and the chunk is CUT before the
+            # first frame that would read what one of its own frames writes (the scheduler's "cut", as for events; the frames
+            # behind the cut start the next segment). Its edges from the buffer's stored values go away, and with them the cycle.
+            for ld in fb:
+                if ld.loop is not None or r.loop is not None or os.environ.get("ZA_TPAR_NO_FEEDBACK"):
+                    raise _Blame("feedback through a delay line (a stored value depends on a load of the same buffer)", ld.ctx)
+                # (only the writes whose VALUE lies on the cycle are cut off from the read; another write into the same line --
+                #  `ring[wp] = x; ring[wp] += y` -- is forwarded as ever)
+                cyc = {m.i for members in members_of if ld in members for m in members}
+                fbs = {st_.j for st_ in plan.stores if ",".join(map(str, st_.region)) == ld.name and st_.value.i in cyc}
+                if not fbs:
+                    raise _Blame("feedback through a delay line (a stored value depends on a load of the same buffer)", ld.ctx)
+                ld.fb = frozenset(fbs | set(ld.fb or ()))
+                keep = []
+                for st_ in plan.stores:
+                    keep.append(st_.addr)
+                    if st_.pred is not None:
+                        keep.append(st_.pred)
+                    if st_.mode == "early" or (",".join(map(str, st_.region)) == ld.name and st_.j not in ld.fb):
+                        keep.append(st_.value)
+                ld.extra = tuple(keep)
+                if ld not in plan.fb_loads:
+                    plan.fb_loads.append(ld)
+            members_of = region_comps(r)
+        for members in members_of:
             if any(m.kind == "ld" for m in members):
-                raise Unsupported("feedback through a delay line (a stored value depends on a load of the same buffer)")
+                raise _Blame("feedback through a delay line (a stored value depends on a load of the same buffer)",
+                             next(m for m in members if m.kind == "ld").ctx)
             names = [m.name for m in members if m.kind in ("st", "lcin")]
             order = written if r.loop is None else list(r.loop.cell_out)
             names.sort(key=lambda nm: order.index(nm))
@@ -1245,6 +1530,10 @@ def build_plan(prog: Program, nch: int) -> Plan:
             for m in members:
                 comp_of[m.i] = c
             r.comps.append(c)
+    for ld in plan.fb_loads:
+        sites = [s_ for s_ in plan.stores if s_.j in ld.fb]
+        if any(s_.mode != "late" for s_ in sites):
+            raise _Blame("feedback through a delay line whose write is not an ordinary one", ld.ctx)
 
     # uniform nodes: per block (the frame's) or per trip (a loop's)
     def set_uniform(n: N):
@@ -1273,6 +1562,7 @@ def build_plan(prog: Program, nch: int) -> Plan:
     extra: Dict[int, N] = {}
     todo = [x for c in comps_all if c.kind in ("scan", "spec") for row in c.A for x in row]
     todo += [x for c in comps_all if c.kind in ("scan", "spec") for x in c.b]
+    todo += [x for c in comps_all if c.kind == "modc" for x in (c.modk, c.modn)]
     todo += [a for c in comps_all if c.kind == "spec" for x in c.gdep + c.slice for a in x.args]
     while todo:
         n = todo.pop()
@@ -1318,7 +1608,21 @@ def build_plan(prog: Program, nch: int) -> Plan:
     plan.invariants = [n for n in plan.uniform if n.kind == "inv"]
     plan.inputs = [n for n in top.nodes if n.kind == "in"]
     for r in all_regions:
-        _schedule(plan, r, comp_of)
+        try:
+            _schedule(plan, r, comp_of)
+        except _BadCone as bc:
+            if bc.event.kind == "ld":
+                raise _Blame("feedback through a delay line whose addresses depend on memory", bc.event.ctx)
+            src = g.event_src.get(bc.event.i)
+            if src is not None and src not in event_ids and any(src == id(o) for o in origin.values()):
+                no_event.add(src)               # (one of split_events' picks: the statement itself is walked next time)
+                raise _Replan()
+            if src is None or src not in event_ids:
+                raise
+            # (a statement the walk made an event of: it is none after all; whatever holds it gets its chance)
+            event_ids.discard(src)
+            no_event.add(src)
+            raise _Replan()
     plan.items = top.items
     plan.uses_rand = RNG_INDEX in plan.outs
     # (measured per leaf, 1024 x 48 000: TSEQ 156 -> 132 ms -- its bands' mode switches leave whole arms idle; BedRock, DPT, ATTACK,
@@ -1348,6 +1652,7 @@ def build_plan(prog: Program, nch: int) -> Plan:
         "holds": len(plan.holdvars), "guards": len(guards),
         "early_writes": sum(1 for s in plan.stores if s.mode == "early"), "sparse_writes": sum(1 for s in plan.stores if s.mode == "sparse"),
         "block": int(plan.has_block), "pending": int(plan.has_pending),
+        "loop_guards": sum(len(L.guards) for L in loops),
     }
     return plan
 
@@ -1511,27 +1816,36 @@ def _schedule(plan: Plan, r: Region, comp_of: Dict[int, Component]):
     remaining = list(pending)
     later: List[N] = []
     cone_comps = None
-    if L is None and plan.events:
-        # what the event conditions need comes first, then the cut (the chunk ends before the first frame whose condition holds)
+    if L is None and (plan.events or plan.fb_loads):
+        # what the event conditions need comes first, then the cut (the chunk ends before the first frame whose condition holds);
+        # likewise the addresses of feedback reads and of the writes into their buffers (the chunk ends before the first frame that
+        # would read what an earlier frame of the chunk writes)
         cone: Dict[int, N] = {}
         cone_comps = set()
-        todo = list(plan.events)
+        todo = [(e, e) for e in plan.events]
+        for ld in plan.fb_loads:
+            todo.append((ld.args[0], ld))
+            for st_ in plan.stores:
+                if st_.j in ld.fb:
+                    todo.append((st_.addr, ld))
+                    if st_.pred is not None:
+                        todo.append((st_.pred, ld))
         while todo:
-            x = todo.pop()
+            x, root = todo.pop()
             if x.i in cone or x.kind == "const" or (x.uniform and x.loop is None):
                 continue
             if x.kind in ("ld", "lout", "lcin") or x.loop is not None:
-                raise Unsupported("event condition reads memory or a loop's result")
+                raise _BadCone(root)
             cone[x.i] = x
-            todo.extend(x.args + x.extra)
+            todo.extend((y, root) for y in x.args + x.extra)
             if x.kind == "st" and x.name in r.st and r.st[x.name] is x:
                 c = comp_of.get(x.i)
                 if c is None:
-                    todo.append(r.outs[x.name])
+                    todo.append((r.outs[x.name], root))
                 elif id(c) not in cone_comps:
                     cone_comps.add(id(c))
-                    todo.extend(c.members)
-                    todo.extend(c.inputs)
+                    todo.extend((y, root) for y in c.members)
+                    todo.extend((y, root) for y in c.inputs)
         later = [n for n in remaining if n.i not in cone]
         remaining = [n for n in remaining if n.i in cone]
     guard = 0
@@ -1728,13 +2042,24 @@ def _classify(g: FrameGraph, reg: Region, c: Component, ci: int = 0, live=None):
     if d == 1 and reg.loop is None and not os.environ.get("ZA_TPAR_NO_MODC"):
         # a wrapped counter, pos = (pos + K) % N with K and N constant over a block (ring positions): over non-negative integers
         # the t-th iterate is (pos + t K) % N -- exact, whatever the order; checked per chunk, the serial loop otherwise
-        o, st_ = reg.outs[names[0]], reg.st[names[0]]
-        if o.kind == "op" and o.op == "%" and o.args[1].uniform and o.args[1].loop is None:
+        o0, st_ = reg.outs[names[0]], reg.st[names[0]]
+        o, gate, extra_m = o0, None, set()
+        if (o.kind == "op" and o.op == "sel" and o.args[0].uniform and o.args[0].loop is None and o.args[0].i not in mem
+                and (o.args[1] is st_) != (o.args[2] is st_)):
+            # the step under a block-constant condition (`enabled ? ( ...; pos = (pos + 1) & mask )`): a step of 0 where it is off
+            gate, o, extra_m = (o.args[0], o.args[2] is st_), (o.args[1] if o.args[2] is st_ else o.args[2]), {o0.i}
+        if o.kind == "op" and o.op in ("%", "&") and o.args[1].uniform and o.args[1].loop is None:
             a = o.args[0]
             if a.kind == "op" and a.op == "+" and st_ in a.args:
                 k_ = a.args[1] if a.args[0] is st_ else a.args[0]
-                if k_ is not st_ and k_.uniform and k_.loop is None and mem == {st_.i, a.i, o.i}:
-                    c.kind, c.modk, c.modn = "modc", k_, o.args[1]
+                if k_ is not st_ and k_.uniform and k_.loop is None and mem == {st_.i, a.i, o.i} | extra_m:
+                    # (pos + K) & M with M = 2^k - 1 is (pos + K) % (M + 1) over non-negative integers (checked per chunk)
+                    c.kind, c.modk = "modc", k_
+                    if gate is not None:
+                        c.modk = g.sel(gate[0], k_, g.ZERO) if gate[1] else g.sel(gate[0], g.ZERO, k_)
+                    c.modn = o.args[1] if o.op == "%" else g.op("+", o.args[1], g.ONE)
+                    c.modmask = o.op == "&" or gate is not None       # (the start must lie inside [0, N) then)
+                    c.modpow2 = o.op == "&"
                     return
     if d == 1 and _persistent_rounding(g, reg, c, mem):
         return                                    # stays "serial": see _persistent_rounding
@@ -1792,6 +2117,19 @@ def _const_value(n: N) -> Optional[float]:
             return None
         return {"+": lambda: v[0] + v[1], "-": lambda: v[0] - v[1], "*": lambda: v[0] * v[1], "neg": lambda: -v[0]}[n.op]()
     return None
+
+
+def _fold(n: N) -> Optional[float]:
+    """Value of a node built from constants only, whatever the operators (None: not a constant)."""
+    if n.kind == "const":
+        return float(n.val)
+    if n.kind != "op" or not n.args or n.op in ("mtout", "addr"):
+        return None
+    v = [_fold(a) for a in n.args]
+    if any(x is None for x in v):
+        return None
+    with np.errstate(all="ignore"):
+        return float(_np_op(n.op, [np.float64(x) for x in v]))
 
 
 def _persistent_rounding(g: FrameGraph, reg: Region, c: Component, mem) -> bool:
@@ -1957,15 +2295,18 @@ class _Emit:
         for a in p.cells.values():
             if a not in self.cell_addrs:
                 self.cell_addrs.append(a)
-        self.lcell_loops = [L for L in p.loops if L.cells or L.id in p.rings]
+        self.lcell_loops = [L for L in p.loops if L.cells or L.id in p.rings or L.guards]
         self.ring_lds: Dict[int, str] = {}        # ld node id -> its LDS address, while a loop's staged form is being emitted
         self.ring_u: Dict[int, N] = {}
         self.has_mem = bool(p.cells or p.stores or p.loads or self.lcell_loops)
         self.has_streams = bool(p.stores)
         self.has_serial = p.has_block or p.has_pending
         self.has_events = bool(p.events)
-        self.segmented = bool(p.events or p.guards)       # blocks are walked in segments, single frames in between run serially
-        self.has_abort = bool(p.cells or p.stores or p.loads or p.guards or self.lcell_loops or p.events)
+        self.loop_guards = any(L.guards for L in p.loops)
+        self.has_fb = bool(getattr(p, "fb_loads", []))
+        self.has_cut = bool(p.events) or self.has_fb       # a chunk may end early (tn shrinks at the scheduler's "cut")
+        self.segmented = bool(p.events or p.guards or self.loop_guards or self.has_fb)    # blocks are walked in segments, single frames in between run serially
+        self.has_abort = bool(p.cells or p.stores or p.loads or p.guards or self.lcell_loops or p.events or self.loop_guards)
         self.early = [s for s in p.stores if s.mode == "early"]
         self.phi_name: Dict[int, str] = {}        # phi / lout node id -> C++ variable
         for L in p.loops:
@@ -2131,8 +2472,14 @@ class _Emit:
         if p.rings:
             L.append("  __shared__ double zt_ring[ZT_RING_DOUBLES];     // a chunk's window of the ring a loop gathers from (RingGroup)")
         self.cell_loops = [L_ for L_ in p.loops if L_.cell_out and not os.environ.get("ZA_TPAR_NO_LDS_CELLS")]
+        # a chunk that breaks a run-time condition is handed back as it began: where that can happen in a chunk whose loops have
+        # already moved their cells on (reads / writes at moving addresses are checked as they are met), the cells are copied aside
+        # at the start of every chunk (the second half of zt_cells)
+        self.cell_undo = bool(self.cell_loops) and bool(p.stores or p.loads)
         if self.cell_loops:
-            L.append("  __shared__ double zt_cells[ZT_CELL_DOUBLES];    // the per-trip cells of a block's loops: staged per block, kept here from chunk to chunk")
+            L.append(f"  __shared__ double zt_cells[{'2 * ' if self.cell_undo else ''}ZT_CELL_DOUBLES];    // the per-trip cells of a block's loops: staged per block, kept here from chunk to chunk")
+            if self.cell_undo:
+                L.append("  int zt_cn = 0;     // cells staged (the copy of a chunk's start sits ZT_CELL_DOUBLES further on)")
         if self.has_abort:
             L.append(f"  __shared__ double zt_snap[{max(1, len(self.cname))}];")
         if self.has_mem:
@@ -2190,6 +2537,7 @@ class _Emit:
             L.append("    if (zt_new) { zt_bn = frames - pos < blk ? frames - pos : blk; zt_bend = pos + zt_bn; }")
             L.append("    const int64_t bn = zt_bn;")
             L.append("    int64_t bend = zt_bend, zt_evf = -1;")
+            L.append("    bool zt_fbc = false;     // the segment ended at a feedback read's cut: the next one starts right behind it, no serial frame")
             L.append("    ZT_STAMP(7)")
             if self.has_serial:
                 L.append("    if (zt_new)")
@@ -2206,12 +2554,20 @@ class _Emit:
         L.append("    ZT_STAMP(1)")
         self.emit_chunk_loop()
         if self.segmented:
-            L.append("    if (zt_evf < 0) { pos = bend; continue; }")
+            L.append("    if (zt_evf < 0) {")
+            L.append("      pos = bend;")
+            if self.has_fb:
+                L.append("      if (zt_fbc) {   // (the audio read ahead was that of frame f0 + 64)")
+                for n in p.inputs:
+                    L.append(f"        x{n.i} = pos + lane < frames ? in_[{int(n.val)} * a.frame_stride + pos + lane] : 0.0f;")
+                L.append("      }")
+            L.append("      continue;")
+            L.append("    }")
             self.emit_serial_frame("    ")
         L.append("  }")
         decl = []
         for lid, (memo, xs) in self.pass_memo.items():
-            decl.append(f"  bool zpv{lid} = false; int64_t zph{lid} = 0;     // address pass of loop {lid}: done for these inputs, high-water mark it found")
+            decl.append(f"  bool zpv{lid} = false, zpg{lid} = false; int64_t zph{lid} = 0;     // address pass of loop {lid}: done for these inputs, high-water mark it found, an event of its body is due")
         L[memo_at:memo_at] = decl
         if self.has_serial:
             L.append("  if (lane == 0 && zt_pend_seen) b.pend[3 * (int64_t)b.n_pad + inst] |= zt_pend_seen;")
@@ -2407,6 +2763,17 @@ class _Emit:
         for Lp in self.lcell_loops:
             self.emit_address_pass(Lp)
         self.has_lbox = bool(p.stores) and any(self.pass_keys(Lp) for Lp in self.lcell_loops)
+        self.has_wbox = bool(p.loads) and any(k in Lp.cell_out for Lp in self.lcell_loops for k in self.pass_keys(Lp))
+        if self.has_wbox:
+            # ... and a read at a moving address (a delay line's, a gather's) must stay clear of the cells some loop STORES to: their
+            # values live in registers / LDS while a block runs, memory has what they were when it began
+            L.append("    int64_t wmin = INT64_MAX, wmax = -1;     // bounding box of the per-trip cells that loops store to")
+            for Lp in self.lcell_loops:
+                keys = self.pass_keys(Lp)
+                nk, so = len(keys), self.site_off[Lp.id]
+                for j, k in enumerate(keys):
+                    if k in Lp.cell_out:
+                        L.append(f"    {{ const int64_t lo = zt_site[{so + 3 * nk + j}], hi = zt_site[{so + 4 * nk + j}]; if (hi >= lo) {{ wmin = lo < wmin ? lo : wmin; wmax = hi > wmax ? hi : wmax; }} }}")
         if self.has_lbox:
             # per-trip cells are read as they stand when the block begins (or live in LDS for its length): a delay-line write
             # that lands among them would have to be seen by the loop of the very next frame -- not a case for this kernel
@@ -2426,6 +2793,12 @@ class _Emit:
                 L.append(f"        for (int q = lane; q < {nk} * zln{Lp.id}; q += 64) {{ const int j = q / zln{Lp.id}, k = q - j * zln{Lp.id}; const int64_t A = zt_site[{so} + j] + (int64_t)k * zt_site[{so + nk} + j];")
                 L.append(f"          zt_cells[zlo{Lp.id} + q] = A < mcap ? memp[A * mse] : 0.0; }}")
                 L.append("      }")
+                if self.cell_undo:
+                    L.append(f"      else if (zln{Lp.id} > 0) {{   // (cells that do not fit would be stored to memory trip by trip: no way back from that)")
+                    self.emit_leave("        ", "pos")
+                    L.append("      }")
+            if self.cell_undo:
+                L.append("      zt_cn = zoff;")
             L.append("      __syncthreads();")
             L.append("    }")
         if self.inv_mats:
@@ -2456,7 +2829,7 @@ class _Emit:
         keys = self.pass_keys(Lp)
         rloads = [x for grp in p.rings.get(Lp.id, []) for x in grp.loads]
         need: Dict[int, N] = {}
-        todo = [Lp.cells[k] for k in keys] + ([Lp.cond] if Lp.cond is not None else []) + [u for _, u, _ in rloads]
+        todo = [Lp.cells[k] for k in keys] + ([Lp.cond] if Lp.cond is not None else []) + [u for _, u, _ in rloads] + list(Lp.guards)
         uphis = []
         while todo:
             n = todo.pop()
@@ -2510,6 +2883,8 @@ class _Emit:
             for ld, _, _ in rloads:
                 L.append(f"      zro_lo{ld.i} = 2147483647; zro_hi{ld.i} = -2147483647;")
         L.append("      bool zt_abad = false;")
+        if Lp.guards:
+            L.append(f"      zpg{Lp.id} = false;")
         for v in uphis:
             L.append(f"      double {self.phi_name[Lp.phis[v].i]} = {ref(Lp.init[v])};")
         # per address expression j: first address, stride, previous, lowest, highest -- in LDS (zt_site), every lane the same values
@@ -2536,6 +2911,8 @@ class _Emit:
                 L.append(f"        if (!za_truthy(n{n.i})) break;")
         if Lp.cond is not None and Lp.cond.i not in need:
             L.append(f"        if (!za_truthy({ref(Lp.cond)})) break;")
+        for gc in Lp.guards:
+            L.append(f"        zpg{Lp.id} |= za_truthy({ref(gc)});     // a statement of this trip that runs as an event is due")
         for ld, u, sign in rloads:
             L.append(f"        {{ const double o = {'' if sign > 0 else '-'}{ref(u)}; const int oi = (int)o; zrok{Lp.id} &= (double)oi == o && fabs(o) < 1.0e9;")
             L.append(f"          zro_lo{ld.i} = oi < zro_lo{ld.i} ? oi : zro_lo{ld.i}; zro_hi{ld.i} = oi > zro_hi{ld.i} ? oi : zro_hi{ld.i}; }}")
@@ -2577,6 +2954,11 @@ class _Emit:
         L.append("      }")
         L.append(f"      zt_high = zph{Lp.id} > zt_high ? zph{Lp.id} : zt_high;")
         L.append("    }")
+        if Lp.guards:
+            L.append(f"    if (zpg{Lp.id}) {{   // ... in the segment's first frame: that frame runs with the section code")
+            L.append("      zt_evf = pos;")
+            self.emit_serial_frame("      ")
+            L.append("    }")
 
     def pass_keys(self, Lp: LoopInfo) -> List[str]:
         return [k for k in Lp.cells if (k in Lp.cin and Lp.cin[k].i in self.live_ids()) or k in Lp.cell_out]
@@ -2599,7 +2981,7 @@ class _Emit:
         p, L, ref = self.plan, self.L, self.ref
         cname = self.cname
         L.append("    for (int64_t f0 = pos; f0 < bend; f0 += 64) {")
-        q = "" if self.has_events else "const "
+        q = "" if self.has_cut else "const "
         L.append(f"    {q}int tn = (int)(bend - f0 < 64 ? bend - f0 : 64);")
         L.append(f"    {q}int last = tn - 1;")
         L.append(f"    {q}bool valid = lane < tn;")
@@ -2628,9 +3010,12 @@ class _Emit:
                 L.append(f"      zt_snap[{k}] = {c};")
             L.append("    }")
             L.append("    bool zt_bad = false, zt_badl = false;")
+            if self.cell_undo:
+                L.append("    for (int q = lane; q < zt_cn; q += 64) zt_cells[ZT_CELL_DOUBLES + q] = zt_cells[q];     // the cells as this chunk finds them")
+                L.append("    __syncthreads();")
         if self.has_events and p.event_exposed:
             L.append(f"    bool fin = true;   // every chunk leaves what it wrote in memory: an event's body reads {', '.join(p.event_exposed[:4])} from the frame before")
-        elif self.has_events:
+        elif self.has_cut:
             L.append("    bool fin = f0 + 64 >= bend;   // the block's last chunk -- or the one an event cuts short (set at the cut)")
         else:
             L.append("    const bool fin = f0 + 64 >= bend;   // the block's last chunk: its last frame leaves every written variable as the script would")
@@ -2642,7 +3027,7 @@ class _Emit:
         self.finals = [(name, o) for name, o in p.outs.items() if name != RNG_INDEX and name not in self.hname]
         self.finals += [(f"spl{ch}", p.spl_out[ch]) for ch in range(p.nch) if f"spl{ch}" not in p.outs]
         self.pending: List[tuple] = []
-        self.before_cut = self.has_events
+        self.before_cut = self.has_cut
         self.emit_region(p.top, "    ")
         L.append("    ZT_STAMP(2)")
         if self.has_abort:
@@ -2691,17 +3076,21 @@ class _Emit:
             L.append(f"    zt_mt_end(zt_mt, zt_pos0, (int){cname[RNG_INDEX]}, zt_gmt, b.mt_se, b.mti + inst, lane);")
         if self.cell_loops:
             L.append("    __syncthreads();")
-            for Lp in self.cell_loops:
-                stored = [(self.cell_slot[(Lp.id, k)], k) for k in self.pass_keys(Lp) if k in Lp.cell_out]
-                L.append(f"    if (zlds{Lp.id}) {{   // the block's cells go back to the arena")
-                for j, k in stored:
-                    so, nk = self.site_off[Lp.id], len(self.pass_keys(Lp))
-                    L.append(f"      for (int k = lane; k < zln{Lp.id}; k += 64) memp[(zt_site[{so + j}] + (int64_t)k * zt_site[{so + nk + j}]) * mse] = zt_cells[zlo{Lp.id} + {j} * zln{Lp.id} + k];")
-                L.append("    }")
+            self.emit_cells_writeback("    ")
         if p.has_block and (self.has_mem or True):
             L.append("    __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"workgroup\");     // the block's values are in vars[] / mem[] before @block reads them")
             L.append("    __builtin_amdgcn_wave_barrier();")
             L.append("    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"workgroup\");")
+
+    def emit_cells_writeback(self, ind: str):
+        L = self.L
+        for Lp in self.cell_loops:
+            stored = [(self.cell_slot[(Lp.id, k)], k) for k in self.pass_keys(Lp) if k in Lp.cell_out]
+            L.append(f"{ind}if (zlds{Lp.id}) {{   // the block's cells go back to the arena")
+            for j, k in stored:
+                so, nk = self.site_off[Lp.id], len(self.pass_keys(Lp))
+                L.append(f"{ind}  for (int k = lane; k < zln{Lp.id}; k += 64) memp[(zt_site[{so + j}] + (int64_t)k * zt_site[{so + nk + j}]) * mse] = zt_cells[zlo{Lp.id} + {j} * zln{Lp.id} + k];")
+            L.append(f"{ind}}}")
 
     def ready(self, o: N) -> bool:
         return (o.uniform and o.loop is None) or o.kind in ("const", "hold") or o.i in self.avail
@@ -2762,6 +3151,11 @@ class _Emit:
         L.append("      // the rest of the launch to the serial code (za_launch_fast runs it right behind this kernel)")
         for st_ in reversed(self.early):
             L.append(f"      if (valid && zse{st_.j}) memp[(int64_t){self.ref(st_.addr)} * mse] = zso{st_.j};      // (what this chunk's early stores replaced)")
+        if self.cell_undo:
+            L.append("      __syncthreads();")
+            L.append("      for (int q = lane; q < zt_cn; q += 64) zt_cells[q] = zt_cells[ZT_CELL_DOUBLES + q];")
+            L.append("      __syncthreads();")
+            self.emit_cells_writeback("      ")
         L.append("      if (lane == 0) {")
         for k, name in enumerate(cname):
             if name.startswith("memw@") or name == RNG_INDEX:
@@ -2843,13 +3237,8 @@ class _Emit:
                 L.append(f"{ind}  zt_bad |= zlo{j} <= lmax && zhi{j} >= lmin;")
             L.append(f"{ind}}}")
             return
-        L.append(f"{ind}// delay-line write {j}: must advance by one cell per frame (at most one wrap inside the chunk)")
-        if st_.pred is not None:
-            L.append(f"{ind}const bool zsu{j} = za_truthy({ref(st_.pred)});      // (block-constant condition)")
-        L.append(f"{ind}const double sp{j} = zt_shift1({an}, {an} - 1.0);")
-        L.append(f"{ind}const uint64_t sm{j} = __ballot(valid && lane > 0 && ({an} - sp{j} != 1.0));")
-        L.append(f"{ind}const int sk{j} = sm{j} ? (int)__ffsll((long long)sm{j}) - 1 : tn;")
-        L.append(f"{ind}const int64_t s0{j} = (int64_t)zt_readlane({an}, 0), s1{j} = sk{j} < tn ? (int64_t)zt_readlane({an}, sk{j}) : 0;")
+        self.emit_site_span(st_, ind, "")
+        j = st_.j
         cond = f"__popcll(sm{j}) > 1 || s0{j} + sk{j} > mcap || (sk{j} < tn && s1{j} + (tn - sk{j}) > mcap)"
         if self.cell_addrs:
             cond += f" || (s0{j} <= cmax && s0{j} + sk{j} > cmin) || (sk{j} < tn && s1{j} <= cmax && s1{j} + (tn - sk{j}) > cmin)"
@@ -2858,6 +3247,18 @@ class _Emit:
         L.append(f"{ind}const bool zsb{j} = {cond};")
         L.append(f"{ind}zt_bad |= {'zsu%d && ' % j if st_.pred is not None else ''}zsb{j};")
 
+    def emit_site_span(self, st_: StoreSite, ind: str, sfx: str):
+        """Where a delay-line write goes in this chunk: s0 + [0, sk) and, behind at most one jump (a ring's wrap), s1 + [0, tn - sk)."""
+        L, ref = self.L, self.ref
+        j, an = f"{st_.j}{sfx}", ref(st_.addr)
+        L.append(f"{ind}// delay-line write {st_.j}: must advance by one cell per frame (at most one wrap inside the chunk)")
+        if st_.pred is not None:
+            L.append(f"{ind}const bool zsu{j} = za_truthy({ref(st_.pred)});      // (block-constant condition)")
+        L.append(f"{ind}const double sp{j} = zt_shift1({an}, {an} - 1.0);")
+        L.append(f"{ind}const uint64_t sm{j} = __ballot(valid && lane > 0 && ({an} - sp{j} != 1.0));")
+        L.append(f"{ind}const int sk{j} = sm{j} ? (int)__ffsll((long long)sm{j}) - 1 : tn;")
+        L.append(f"{ind}const int64_t s0{j} = (int64_t)zt_readlane({an}, 0), s1{j} = sk{j} < tn ? (int64_t)zt_readlane({an}, sk{j}) : 0;")
+
     def emit_site_pairs(self, ind: str):
         """No two writes of a chunk may touch one cell (different buffers are an assumption: checked here)."""
         p, L = self.plan, self.L
@@ -2865,7 +3266,13 @@ class _Emit:
         for x, sa in enumerate(dense):
             for sb in dense[x + 1:]:
                 a, b = sa.j, sb.j
-                L.append(f"{ind}zt_bad |= zt_spans_meet(s0{a}, sk{a}, s1{a}, tn - sk{a}, s0{b}, sk{b}, s1{b}, tn - sk{b});")
+                both = " && ".join(f"zsu{x_.j}" for x_ in (sa, sb) if x_.pred is not None)
+                meet = f"zt_spans_meet(s0{a}, sk{a}, s1{a}, tn - sk{a}, s0{b}, sk{b}, s1{b}, tn - sk{b})"
+                if sa.region == sb.region and sa.mode == "late" and sb.mode == "late":
+                    # writes into ONE delay line: fine while they move in step -- the same cell in the same frame, where program
+                    # order decides (the late stores go out in program order; a read takes the last write in front of it)
+                    meet += f" && !(s0{a} == s0{b} && sk{a} == sk{b} && s1{a} == s1{b})"
+                L.append(f"{ind}zt_bad |= {both + ' && ' if both else ''}{meet};")
             for sp_ in (s for s in p.stores if s.mode == "sparse"):
                 a, b = sa.j, sp_.j
                 L.append(f"{ind}zt_bad |= zhi{b} >= zlo{b} && (zt_span_hits(s0{a}, sk{a}, zlo{b}, zhi{b}) || zt_span_hits(s1{a}, tn - sk{a}, zlo{b}, zhi{b}));")
@@ -2905,7 +3312,7 @@ class _Emit:
         """A read at address B against this chunk's writes: other buffers' spans and cells must not be hit; its own buffer's
         late write is forwarded from the writing frame's lane (`v`, only with forward), an early one is already in memory."""
         p, L, ref = self.plan, self.L, self.ref
-        if forward and self.has_late_site(n):
+        if forward and any(s.mode == "late" and ",".join(map(str, s.region)) == n.name and s.j not in n.fb for s in p.stores):
             L.append(f"{ind}int best = -1;")
         for st_ in p.stores:
             j = st_.j
@@ -2924,6 +3331,10 @@ class _Emit:
                 # memory already holds this chunk's values: right for frames at or before this one, wrong for later ones
                 before = "false" if st_.seq < n.val else "true"
                 L.append(f"{ind}  zt_badl |= {on}(tw > lane || (tw == lane && {before})); }}")
+            elif st_.j in n.fb:
+                # (the chunk was cut before the first frame that reads what an earlier one of its frames writes: nothing to see)
+                before = "true" if st_.seq < n.val else "false"
+                L.append(f"{ind}  zt_badl |= {on}(tw >= 0 && (tw < lane || (tw == lane && {before}))); }}")
             else:
                 assert forward
                 before = "true" if st_.seq < n.val else "false"
@@ -2931,6 +3342,8 @@ class _Emit:
                 L.append(f"{ind}  if (__ballot(vis)) {{ const double fw = zt_bperm({ref(st_.value)}, tw); v = vis ? fw : v; best = vis ? tw : best; }} }}")
         if self.cell_addrs:
             L.append(f"{ind}zt_badl |= {B} >= cmin && {B} <= cmax;")
+        if self.has_wbox:
+            L.append(f"{ind}zt_badl |= {B} >= wmin && {B} <= wmax;     // (a per-trip cell some loop stores to: its value lives in LDS)")
 
     def emit_region(self, reg: Region, ind: str):
         p, L, ref = self.plan, self.L, self.ref
@@ -2986,11 +3399,49 @@ class _Emit:
                 sites_open = True
                 continue
             if kind == "cut":
-                cond = " || ".join(f"za_truthy({ref(e)})" for e in p.events)
                 L.append(f"{ind}{{   // the first frame an event falls on ends the segment: the frames before it are this chunk")
-                L.append(f"{ind}  const uint64_t m = __ballot(valid && ({cond}));")
-                L.append(f"{ind}  if (m) {{ const int e = (int)__ffsll((long long)m) - 1; zt_evf = f0 + e; bend = zt_evf; tn = e; last = e - 1; valid = lane < tn; fin = true; }}")
+                if p.events:
+                    cond = " || ".join(f"za_truthy({ref(e)})" for e in p.events)
+                    L.append(f"{ind}  const uint64_t m = __ballot(valid && ({cond}));")
+                else:
+                    L.append(f"{ind}  const uint64_t m = 0;")
+                if self.has_fb:
+                    L.append(f"{ind}  // ... and so does the first frame that would read, from a delay line in a feedback loop, what an earlier frame")
+                    L.append(f"{ind}  // of this chunk writes: the next segment starts AT that frame")
+                    L.append(f"{ind}  bool fbh = false;")
+                    done_sites = set()
+                    for ld in p.fb_loads:
+                        for st_ in p.stores:
+                            if st_.j in ld.fb and st_.j not in done_sites:
+                                done_sites.add(st_.j)
+                                self.emit_site_span(st_, ind + "  ", "c")
+                    for ld in p.fb_loads:
+                        L.append(f"{ind}  {{ const int64_t B = (int64_t){ref(ld.args[0])};")
+                        for st_ in p.stores:
+                            if st_.j not in ld.fb:
+                                continue
+                            j = f"{st_.j}c"
+                            on = f"zsu{j} && " if st_.pred is not None else ""
+                            before = "true" if st_.seq < ld.val else "false"
+                            L.append(f"{ind}    {{ int tw = -1; const int64_t d0 = B - s0{j}, d1 = B - s1{j};")
+                            L.append(f"{ind}      if ((uint64_t)d0 < (uint64_t)sk{j}) tw = (int)d0;")
+                            L.append(f"{ind}      if ((uint64_t)d1 < (uint64_t)(tn - sk{j})) tw = sk{j} + (int)d1;")
+                            L.append(f"{ind}      fbh |= {on}(tw >= 0 && (tw < lane || (tw == lane && {before}))); }}")
+                        L.append(f"{ind}  }}")
+                    L.append(f"{ind}  const uint64_t mf = __ballot(valid && fbh);")
+                else:
+                    L.append(f"{ind}  const uint64_t mf = 0;")
+                L.append(f"{ind}  if (m | mf) {{")
+                L.append(f"{ind}    const int ee = m ? (int)__ffsll((long long)m) - 1 : 64, ef = mf ? (int)__ffsll((long long)mf) - 1 : 64;")
+                L.append(f"{ind}    if (ee <= ef) {{ zt_evf = f0 + ee; bend = zt_evf; tn = ee; }} else {{ zt_fbc = true; bend = f0 + ef; tn = ef; }}")
+                L.append(f"{ind}    last = tn - 1; valid = lane < tn; fin = true;")
+                L.append(f"{ind}  }}")
                 L.append(f"{ind}}}")
+                if self.has_fb:
+                    L.append(f"{ind}if (zt_fbc && tn < 16) {{   // a feedback delay this short is serial work: the section code takes the rest of the launch")
+                    self.emit_flush_states(ind + "  ")
+                    self.emit_leave(ind + "  ", "f0")
+                    L.append(f"{ind}}}")
                 L.append(f"{ind}if (tn == 0) {{   // the event falls on this chunk's first frame: the states as the chunk before left them go to memory")
                 self.emit_flush_states(ind + "  ")
                 L.append(f"{ind}  break;")
@@ -3039,7 +3490,8 @@ class _Emit:
                 cv, kk, nn = self.carry(reg, nm), ref(c.modk), ref(c.modn)
                 L.append(f"{ind}// {nm}: a wrapped counter, (y + K) % N over non-negative integers: the state before frame t is (y + t K) % N")
                 L.append(f"{ind}double k{sid};")
-                L.append(f"{ind}if (zt_small_int({cv}) && {cv} >= 0.0 && zt_small_int({kk}) && {kk} >= 0.0 && zt_small_int({nn}) && {nn} >= 1.0 && {nn} < 2147483647.0 && {cv} + 64.0 * {kk} < 2147483647.0) {{")
+                pw2 = (f" && {cv} < {nn}" + (f" && zt_pow2({nn})" if c.modpow2 else "")) if c.modmask else ""
+                L.append(f"{ind}if (zt_small_int({cv}) && {cv} >= 0.0 && zt_small_int({kk}) && {kk} >= 0.0 && zt_small_int({nn}) && {nn} >= 1.0 && {nn} < 2147483647.0 && {cv} + 64.0 * {kk} < 2147483647.0{pw2}) {{")
                 L.append(f"{ind}  k{sid} = lane == 0 ? {cv} : za_mod({cv} + (double)lane * {kk}, {nn});")
                 L.append(f"{ind}}} else {{")
                 mark = len(L)
@@ -3875,6 +4327,14 @@ def _sites_ok(a0, s0, lo0, hi0, a1, s1, lo1, hi1) -> bool:
     return (a1 - a0) % s0 != 0
 
 
+class _Recut(Exception):
+    """Plan.simulate: the chunk ends before frame e (a feedback read would need a value of its own chunk)."""
+
+    def __init__(self, e):
+        super().__init__(e)
+        self.e = e
+
+
 class _Sim:
     """State of one Plan.simulate call."""
 
@@ -3889,7 +4349,7 @@ def _simulate(self: Plan, vars0: Dict[str, float], x: np.ndarray, sliders=None, 
     one block (@block, if the script has one, is not run here).
     Returns (y float32 [nch, frames], vars after {name: value}, spl after {k: value}). Raises TparAbort when a chunk breaks
     one of the run-time conditions of the lowering (the kernel hands such a launch to the serial code)."""
-    if self.events:
+    if self.events or any(L.guards for L in self.loops):
         raise NotImplementedError("plans with events run a frame of the script's own section code: device only")
     memv = np.zeros(1 << 16) if mem is None else np.array(mem, dtype=np.float64)
     mcap = len(memv)
@@ -3968,6 +4428,7 @@ def _simulate(self: Plan, vars0: Dict[str, float], x: np.ndarray, sliders=None, 
             val[reg.st[nm].i] = caps[nm]
 
     lbox = [1 << 62, -1]          # bounding box of the loops' per-trip cells (address_pass)
+    wbox = [1 << 62, -1]          # ... of those that loops store to
 
     def run_items(reg: Region, carry, f0, tn, sites):
         """One chunk's (or one trip's) schedule. carry: state name -> value before the chunk."""
@@ -4011,7 +4472,11 @@ def _simulate(self: Plan, vars0: Dict[str, float], x: np.ndarray, sliders=None, 
                         for i2 in range(i1 + 1, len(js)):
                             lo1, hi1 = (min(spans[js[i1]]), max(spans[js[i1]])) if spans[js[i1]] else (0, -1)
                             lo2, hi2 = (min(spans[js[i2]]), max(spans[js[i2]])) if spans[js[i2]] else (0, -1)
-                            both_sparse = self.stores[js[i1]].mode == "sparse" and self.stores[js[i2]].mode == "sparse"
+                            sa_, sb_ = self.stores[js[i1]], self.stores[js[i2]]
+                            both_sparse = sa_.mode == "sparse" and sb_.mode == "sparse"
+                            if (sa_.region == sb_.region and sa_.mode == "late" and sb_.mode == "late"
+                                    and np.array_equal(sites[sa_.j]["A"][:tn], sites[sb_.j]["A"][:tn])):
+                                continue                   # writes into one delay line that move in step: program order decides
                             if (hi1 >= lo1 and hi2 >= lo2 and lo1 <= hi2 and lo2 <= hi1) if both_sparse else (spans[js[i1]] & spans[js[i2]]):
                                 raise TparAbort(f0, "two writes of a chunk touch one cell")
                     for s2 in self.stores:                  # early writes go out now
@@ -4046,12 +4511,18 @@ def _simulate(self: Plan, vars0: Dict[str, float], x: np.ndarray, sliders=None, 
                         if np.any(late[:tn]):
                             raise TparAbort(f0, "a gather reads a cell that a later frame of the chunk has already overwritten")
                         continue
+                    if st_.j in n.fb:
+                        if np.any(((tw >= 0) & ((tw < lane) | ((tw == lane) & (st_.seq < n.val))))[:tn]):
+                            raise TparAbort(f0, "a feedback read would need a value of its own chunk (the cut should have ended it)")
+                        continue
                     vis = (tw >= 0) & ((tw < lane) | ((tw == lane) & (st_.seq < n.val))) & (tw >= best)
                     Vv = vec(st_.value)
                     out = np.where(vis, Vv[np.clip(tw, 0, WAVE - 1)], out)
                     best = np.where(vis, tw, best)
                 if any(np.any(B[:tn] == a) for a in cell_addr.values()):
                     raise TparAbort(f0, "a delay-line read hits a mem[] cell")
+                if np.any((B[:tn] >= wbox[0]) & (B[:tn] <= wbox[1])):
+                    raise TparAbort(f0, "a read at a moving address hits a per-trip cell that a loop stores to")
                 val[n.i] = out
             elif kind == "par" and it[1].kind == "lcin":
                 n = it[1]
@@ -4066,6 +4537,31 @@ def _simulate(self: Plan, vars0: Dict[str, float], x: np.ndarray, sliders=None, 
                     return False
             elif kind == "loop":
                 run_loop(it[1], f0, tn, sites)
+            elif kind == "cut":
+                hit = np.zeros(WAVE, dtype=bool)
+                for ld in self.fb_loads:
+                    B = vec(ld.args[0]).astype(np.int64)
+                    for st_ in self.stores:
+                        if st_.j not in ld.fb:
+                            continue
+                        if st_.pred is not None and not _truthy(np.float64(uni(st_.pred, "store condition"))):
+                            continue
+                        A = vec(st_.addr).astype(np.int64)
+                        brk = np.flatnonzero(np.diff(A[:tn]) != 1)
+                        k = int(brk[0]) + 1 if len(brk) else tn
+                        tw = np.full(WAVE, -1)
+                        d0 = B - int(A[0])
+                        tw = np.where((d0 >= 0) & (d0 < k), d0, tw)
+                        if k < tn:
+                            d1 = B - int(A[k])
+                            tw = np.where((d1 >= 0) & (d1 < tn - k), k + d1, tw)
+                        hit |= (tw >= 0) & ((tw < lane) | ((tw == lane) & (st_.seq < ld.val)))
+                hit[tn:] = False
+                if hit.any():
+                    e = int(np.flatnonzero(hit)[0])
+                    if e < 16:
+                        raise TparAbort(f0, "a feedback delay shorter than 16 frames")
+                    raise _Recut(e)
             elif kind == "shift":
                 name = it[1]
                 src = vec(reg.outs[name])
@@ -4086,7 +4582,8 @@ def _simulate(self: Plan, vars0: Dict[str, float], x: np.ndarray, sliders=None, 
                 nm = comp.names[0]
                 c0, kk, nn = float(carry[nm]), float(uni(comp.modk, "counter step")), float(uni(comp.modn, "counter length"))
                 small = lambda x_: x_ == math.floor(x_) and abs(x_) < 1.0e12
-                if small(c0) and c0 >= 0 and small(kk) and kk >= 0 and small(nn) and 1 <= nn < 2147483647.0 and c0 + 64 * kk < 2147483647.0:
+                pw2 = (not comp.modmask) or (c0 < nn and (not comp.modpow2 or (nn >= 1 and (int(nn) & (int(nn) - 1)) == 0)))
+                if small(c0) and c0 >= 0 and small(kk) and kk >= 0 and small(nn) and 1 <= nn < 2147483647.0 and c0 + 64 * kk < 2147483647.0 and pw2:
                     t = np.arange(WAVE, dtype=np.float64)
                     st_v = np.mod(c0 + t * kk, nn)
                     st_v[0] = c0
@@ -4217,9 +4714,11 @@ def _simulate(self: Plan, vars0: Dict[str, float], x: np.ndarray, sliders=None, 
             if any(b_ - a_ != st for a_, b_ in zip(s, s[1:])) or max(s) >= mcap:
                 raise TparAbort(0, "a per-trip cell address does not step evenly through the trips (or leaves the arena)")
             desc[key] = (s[0], st, min(s), max(s))
-        for (_, _, lo_, hi_) in desc.values():
+        for key_, (_, _, lo_, hi_) in desc.items():
             if hi_ >= lo_:
                 lbox[0], lbox[1] = min(lbox[0], lo_), max(lbox[1], hi_)
+                if key_ in Lp.cell_out:
+                    wbox[0], wbox[1] = min(wbox[0], lo_), max(wbox[1], hi_)
         keys = list(desc)
         for i1 in range(len(keys)):
             for i2 in range(i1 + 1, len(keys)):
@@ -4249,8 +4748,11 @@ def _simulate(self: Plan, vars0: Dict[str, float], x: np.ndarray, sliders=None, 
         hcarry = {name: np.float64(inv_value(name)) for name in self.holdvars}
         y = np.zeros_like(x)
         final_vals: Dict[str, float] = {}
-        for f0 in range(0, max(frames, 0), WAVE):
-            tn = min(WAVE, frames - f0)
+        f0, cut_to = 0, None
+        self.fb_cuts = 0
+        while f0 < frames:
+            tn = min(WAVE, frames - f0) if cut_to is None else cut_to
+            cut_to = None
             last = tn - 1
             for n in self.inputs:
                 col = np.zeros(WAVE)
@@ -4259,6 +4761,10 @@ def _simulate(self: Plan, vars0: Dict[str, float], x: np.ndarray, sliders=None, 
             sites: Dict[int, dict] = {}
             try:
                 run_items(top, carry, f0, tn, sites)
+            except _Recut as rc:                        # the same chunk again, ending before the frame that reads its own writes
+                cut_to = rc.e
+                self.fb_cuts += 1
+                continue
             except TparAbort:
                 for st_ in reversed(self.stores):          # what this chunk's early writes replaced
                     if st_.mode == "early" and st_.j in sites and "old" in sites[st_.j]:
@@ -4289,9 +4795,10 @@ def _simulate(self: Plan, vars0: Dict[str, float], x: np.ndarray, sliders=None, 
                     hcarry[name] = np.float64(v[np.flatnonzero(on)[-1]])
             if stream is not None:
                 stream.end_chunk(int(carry[RNG_INDEX]))
-            if f0 + WAVE >= frames:
+            if f0 + tn >= frames:
                 for name, o in list(self.outs.items()) + [(f"spl{ch}", self.spl_out[ch]) for ch in range(self.nch)]:
                     final_vals[name] = float(hcarry[name]) if name in hcarry else float(vec(o)[last])
+            f0 += tn
     vars_after = dict(vars0)
     spl_after = dict(spl_state)
     self.mt_after = stream.state(int(final_vals.get(RNG_INDEX, 0))) if stream is not None else mt
