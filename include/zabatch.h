@@ -80,7 +80,8 @@ typedef struct zab_info {
 } zab_info;
 
 const char* zab_last_error(void);
-int zab_abi_version(void);
+int zab_abi_version(void);        /* the plugin-module ABI (runtime <-> libzab_<leaf>.so) */
+int zab_host_abi_version(void);   /* the host ABI: ZAB_HOST_ABI of the header this library was built from */
 
 /* Load plugin module `libzab_<name>.so` (path or bare leaf name resolved next to libzabatch.so) and allocate
  * state for cfg->n_instances instances: vars/sliders/spl zeroed, mem zeroed (resetStateStructOnly + calloc). */
@@ -131,7 +132,13 @@ int zab_read_mem_high(zab_engine* e, int32_t first, int32_t count, int64_t* dst)
  * (prototypes dsp_jsfx_aot.py:6088-6102) needs so that src/JSFXJuceProcessor.cpp can link against this engine unchanged
  * (zajit/shim.py generates that shim). Null pointers skip a field. Both calls synchronise.
  * MIDI queues and runtimeOpaque are host-side objects and are not mirrored. */
+/* ZAB_HOST_ABI counts layout changes of the structs a HOST passes by pointer (zab_config, zab_info, zab_host_state). A client
+ * compiled against another header must not call into this library: compare with zab_host_abi_version() once after loading
+ * (the generated shims do, zajit/shim.py). zab_host_state also says how large the caller's struct is, so that fields added at
+ * its end are only touched when the caller has them. */
+#define ZAB_HOST_ABI 2
 typedef struct zab_host_state {
+  uint64_t struct_size;           /*        sizeof(zab_host_state) as the CALLER compiled it (0 is refused) */
   double* spl;                    /* [64]   DSPJSFX_State::spl */
   double* sliders;                /* [64]   ::sliders */
   double* vars;                   /* [nvars] ::vars */
@@ -183,6 +190,24 @@ typedef struct zab_pool_entry {
   float peak, rms;
 } zab_pool_entry;
 int zab_pool_upload(zab_engine* e, int32_t n_entries, const zab_pool_entry* entries, const float* audio, int64_t audio_items);
+
+/* File ingestion. The reference decodes what is assigned to a file slot / imported into the sample pool with
+ * JUCE's format readers (src/JSFXJuceProcessor.cpp:15207-15305 file_* entry points over the processor's decoded slots;
+ * src/DspJsfxSamplePool.cpp:473-751 worker decode), i.e. into float samples. This library reads RIFF/WAVE itself: PCM 8 (unsigned),
+ * 16, 24 and 32 bit, IEEE float 32 and 64 bit, plain or WAVE_FORMAT_EXTENSIBLE, any channel count; integer samples become
+ * floats as value / 2^(bits-1) (what a JUCE reader hands out). No resampling: the data keeps the file's rate, which the script
+ * sees (file_riff's srate, sample_info).
+ *   zab_wav_read      decodes into a malloc'ed interleaved float array the caller frees with zab_wav_free
+ *   zab_file_slot_load_wav   = zab_wav_read + zab_file_slot_set (items = the floats widened to double)
+ *   zab_pool_upload_wav      = one pool generation from n files, entries in argument order (1-based sample ids) */
+typedef struct zab_wav_info {
+  int32_t channels, sample_rate, bits, is_float;
+  int64_t frames;
+} zab_wav_info;
+int zab_wav_read(const char* path, zab_wav_info* info, float** interleaved);
+void zab_wav_free(float* interleaved);
+int zab_file_slot_load_wav(zab_engine* e, int32_t slot, const char* path, zab_wav_info* info);
+int zab_pool_upload_wav(zab_engine* e, int32_t n_files, const char* const* paths);
 
 /* Device buffer helpers so hosts without a HIP binding (ctypes, cgo, JNI) can keep audio HBM-resident. */
 int zab_device_alloc(zab_engine* e, int64_t bytes, void** out);

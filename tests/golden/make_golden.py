@@ -98,7 +98,16 @@ CASES = [
     ("fx_evtkat2", "default", {}, 2000, 500), ("fx_evtkat2", "slow", {0: 333, 1: 0.2}, 1500, 512),
     # a guard (zajit/tpar.py split_guards) that @block raises every third block; and one that never clears (every frame serial)
     ("fx_guardkat", "default", {}, 2400, 200), ("fx_guardkat", "dense", {0: 0, 1: 0.8}, 700, 128),
+    # round 4: voices in mem[] (per-trip cells under their own flag + gathers), a spawn through a function with a loop, a feedback
+    # echo (delay above / below a chunk's length), two delay lines in one buffer, wrap loops; "poison": a gather hits a stored cell
+    ("fx_voicekat", "default", {}, 3000, 512), ("fx_voicekat", "alt", {0: 40, 1: 0.7, 2: 0.1}, 3000, 500),
+    ("fx_voicekat", "dense", {0: 23, 2: 0.05, 3: 1}, 2500, 500),
+    # BASELINE config C3's literal shape: 4096-point STFT, hop 1024, EIGHT channels per instance
+    ("fx_stft4k8", "default", {0: 0.35}, 8192, 512),
 ]
+# round 4: 44 more random programs, with the memory idioms of tests/fixtures/make_fuzz.py program2 (rings, a feedback echo, stores
+# under conditions, band loops, wrapped counters, a rare heavy branch, instance state): 1200 frames in blocks of 128 / 100
+CASES += [(f"fx_fuzz{k}", "default", {0: float((k * 7) % 21) * 0.5}, 1200, 128 if k % 2 else 100) for k in range(6, 50)]
 
 
 def leaf_path(leaf: str) -> Path:

@@ -16,19 +16,78 @@ OPS = {"fft": 1, "ifft": 2, "fft_real": 3, "ifft_real": 4, "fft_permute": 5, "ff
 SRC_BASE = 65536          # convolve_c's second operand: the next 65536-cell page (a region may not cross a page)
 
 
+def _wdl_perm(n):
+    """WDL_fft_permute_tab(n) from the recursion zart_fft.h uses (pinned against the reference's tables for n <= 4096 below)."""
+    def freq(i, m_):
+        mul, add, mask, nn = 1, 0, m_ - 1, m_
+        while nn > 2:
+            m = nn >> 1
+            if i < m:
+                mul <<= 1; nn = m; continue
+            i -= m; m >>= 1
+            if i < m:
+                add += mul; mul <<= 2; nn = m; continue
+            i -= m
+            add -= mul; mul <<= 2; nn = m
+        return (i * mul + add) & mask
+    perm = np.zeros(n, dtype=np.int64)
+    for i in range(n):
+        perm[(n - freq(i, n)) & (n - 1)] = i
+    return perm
+
+
+def _pack(c):
+    out = np.empty(2 * len(c)); out[0::2] = c.real; out[1::2] = c.imag
+    return out
+
+
+def _numpy_vectors(n, z, r):
+    """WDL's conventions (src/WDL/fft.h:55-73) over an INDEPENDENT transform (numpy's): forward = the DFT scattered into WDL's
+    output order; inverse = its input taken in that order, unscaled; the real pair = n / 2 packed bins in the order of n / 2,
+    scaled by 2, DC / Nyquist in bin 0. Equal to the reference library's own output to rounding for every size
+    (test_numpy_construction_equals_the_reference_library, dev container), so the GPU box needs no reference-built binary."""
+    perm, permh, h = _wdl_perm(n), _wdl_perm(n // 2), n // 2
+    zc = z[0::2] + 1j * z[1::2]
+    fwd = np.empty(n, complex); fwd[perm] = np.fft.fft(zc)
+    inv = np.fft.ifft(zc[perm]) * n
+    R = np.fft.rfft(r) * 2
+    nb = np.empty(h, complex); nb[0] = R[0].real + 1j * R[h].real; nb[1:] = R[1:h]
+    packed = np.empty(h, complex); packed[permh] = nb
+    nbin = (r[0::2] + 1j * r[1::2])[permh]
+    full = np.empty(h + 1, complex); full[0] = nbin[0].real; full[h] = nbin[0].imag; full[1:h] = nbin[1:]
+    return {"c_in": z, "c_fwd": _pack(fwd), "c_inv": _pack(inv), "r_in": r, "r_fwd": _pack(packed),
+            "r_inv": np.fft.irfft(full, n) * n, "perm": perm}
+
+
 def _vectors(n):
-    """Known answers of the reference's WDL build: committed for n <= 4096 (wdl_fft.npz); above that (the vectors would be
-    megabytes of incompressible doubles) they are produced on the spot by the reference library itself (oracle/_ref travels)."""
+    """Known answers: the reference's WDL build for n <= 4096 (committed, wdl_fft.npz); above that -- the vectors would be
+    megabytes of incompressible doubles -- seeded inputs through _numpy_vectors."""
     if f"c{n}_in" in KAT:
         return {k: KAT[f"{k[0]}{n}{k[1:]}"] for k in ("c_in", "c_fwd", "c_inv", "r_in", "r_fwd", "r_inv")} | {"perm": KAT[f"perm{n}"]}
-    from oracle import eel_oracle
-    if not eel_oracle.available():
-        pytest.skip("oracle/_ref not built (needed for sizes above 4096)")
     rng = np.random.default_rng(20261004 + n)
-    z, r = rng.standard_normal(2 * n), rng.standard_normal(n)
-    return {"c_in": z, "c_fwd": eel_oracle.wdl_fft(z, n, False), "c_inv": eel_oracle.wdl_fft(z, n, True), "r_in": r,
-            "r_fwd": eel_oracle.wdl_real_fft(r, n, False), "r_inv": eel_oracle.wdl_real_fft(r, n, True),
-            "perm": eel_oracle.wdl_fft_permute(n)}
+    return _numpy_vectors(n, rng.standard_normal(2 * n), rng.standard_normal(n))
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_numpy_construction_equals_the_reference_library(n):
+    """Pins _numpy_vectors: against the committed WDL vectors up to 4096 points (anywhere), against the live reference library
+    (oracle/_ref, dev container) above."""
+    tol = lambda want: 64 * n * np.finfo(np.float64).eps * max(1.0, np.abs(want).max())
+    if f"c{n}_in" in KAT:
+        ref = {k: KAT[f"{k[0]}{n}{k[1:]}"] for k in ("c_in", "c_fwd", "c_inv", "r_in", "r_fwd", "r_inv")} | {"perm": KAT[f"perm{n}"]}
+    else:
+        from oracle import eel_oracle
+        if not eel_oracle.available():
+            pytest.skip("oracle/_ref not built")
+        rng = np.random.default_rng(20261004 + n)
+        z, r = rng.standard_normal(2 * n), rng.standard_normal(n)
+        ref = {"c_in": z, "c_fwd": eel_oracle.wdl_fft(z, n, False), "c_inv": eel_oracle.wdl_fft(z, n, True), "r_in": r,
+               "r_fwd": eel_oracle.wdl_real_fft(r, n, False), "r_inv": eel_oracle.wdl_real_fft(r, n, True),
+               "perm": eel_oracle.wdl_fft_permute(n)}
+    got = _numpy_vectors(n, ref["c_in"], ref["r_in"])
+    assert np.array_equal(got["perm"], ref["perm"])
+    for k in ("c_fwd", "c_inv", "r_fwd", "r_inv"):
+        assert np.abs(got[k] - ref[k]).max() <= tol(ref[k]), k
 
 
 def _cases(n):
@@ -154,7 +213,7 @@ def test_gpu_fft_known_answers(n, leaf):
         pytest.skip(f"{leaf} not built")
     inst = 70
     scale = 1.0 + np.arange(inst)[:, None] * 0.125
-    if n > 4096 or (not leaf.endswith("_full") and n > 2048):
+    if n > 4096:
         inst = 6                                    # (some ops of these sizes take the serial device transform: keep the batch small)
         scale = 1.0 + np.arange(inst)[:, None] * 0.125
     for op, x, want, src in _cases(n):
@@ -193,3 +252,34 @@ def test_gpu_stft_fixture_matches_reference_vm():
     for i in (0, 63, 65):
         assert_state_close(names, v[i], g["vars"], what=f"stft vars[{i}]")
     assert np.abs(mem - want[None]).max() <= SCALAR_EPS
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path,n", [("auto", 256), ("generic", 24)])
+def test_config_c3_shape_256_instances_of_eight_channels(path, n):
+    """BASELINE config C3 as it is written -- 4096-point STFT, hop 1024, 256 instances x 8 channels -- against the reference VM's
+    run of the eight-channel fixture (tests/fixtures/stft4k8.jsfx): every instance gets the fixture's input; sampled instances
+    are compared in full (audio, vars, arena, high-water mark), all of them on audio."""
+    import zabatch
+    if not zabatch.module_path("fx_stft4k8").exists():
+        pytest.skip("fx_stft4k8 not built")
+    g = load_golden("fx_stft4k8_default")
+    x = np.repeat(golden_input(g)[None], n, axis=0)
+    assert x.shape[1] == 8
+    p = {"auto": zabatch.ZAB_PATH_AUTO, "generic": zabatch.ZAB_PATH_GENERIC}[path]
+    with zabatch.Engine("fx_stft4k8", n, srate=float(g["srate"]), mem_cap=1 << 17, path=p) as e:
+        assert e.nch == 8
+        e.set_sliders(g["sliders"]); e.prepare()
+        y = e.process_host(x, block=int(g["block"]))
+        assert e.used_fast_path() == (path == "auto")
+        v = e.read_vars()
+        names = e.var_names()
+        high = e.mem_high()
+        picks = sorted({0, n // 3, n - 1})
+        mems = {i: e.read_mem(0, int(g["mem_high"]), first=i, count=1)[0] for i in picks}
+    assert np.abs(y.astype(np.float64) - g["out"].astype(np.float64)[None]).max() <= AUDIO_EPS
+    want = np.zeros(int(g["mem_high"])); want[g["mem_idx"]] = g["mem_val"]
+    for i in picks:
+        assert_state_close(names, v[i], g["vars"], what=f"stft4k8 vars[{i}]")
+        assert np.abs(mems[i] - want).max() <= SCALAR_EPS
+    assert (high == int(g["mem_high"])).all()

@@ -109,6 +109,44 @@ def test_slider_declarations_and_quantiser():
     assert d[0].to_slider_value(250.0) == 100.0 and d[0].to_slider_value(33.4) == 33.0
 
 
+# (min, max, step, host value, is_choice) -> what hostParameterToJsfxSliderValue leaves in st.sliders[]. Expected values were
+# worked out from src/JSFXJuceProcessor.cpp:5556-5596 with exact rational arithmetic and one IEEE rounding per C++ operation --
+# independently of zajit/sliders.py: min / max / step are floats (`info.min` etc., parsed :706-931) widened to double; the host
+# value arrives through `std::atomic<float>` (:5566, :9792); a choice is `min + llround(v) * step` (:5578-5582); then
+# jlimit (:5584), `q = llround((v - min) / step); v = min + q * step` in double (:5591-5593) and jlimit again (:5594).
+QUANTISER_TABLE = [
+    ((-24, 24, 0.1, 3.14159, False), 3.1000004038214684),         # q = 271; 0.1f = 0.100000001490116
+    ((0, 1, 0.001, 0.8249, False), 0.8250000391853973),
+    ((0, 1, 0.01, 0.005, False), 0.009999999776482582),          # 0.005f / 0.01f = 0.50000001...: rounds up to one step
+    ((0, 1, 0.01, 0.995, False), 0.9999999776482582),            # q = 100: 100 * 0.01f stays below the float max of 1: no clamp
+    ((20, 20000, 1, 440.5, False), 441.0),                       # llround: halves away from zero
+    ((-72, 0, 0.1, -36.04999, False), -35.9999994635582),
+    ((0.1, 2000, 0.1, 8.05, False), 8.100000120699406),          # min itself is 0.1f
+    ((0, 0.95, 0.001, 0.9504, False), 0.949999988079071),        # clamped to the float max first
+    ((0, 1, 0, 0.3, False), 0.30000001192092896),                # no step: the host's float, widened
+    ((-100, 100, 0.5, -0.25, False), 0.0),                       # (99.75 / 0.5) = 199.5 -> 200
+    ((-100, 100, 0.5, 0.25, False), 0.5),
+    ((0, 3, 1, 1.5, True), 2.0),                                 # choice: llround(1.5) = 2
+    ((0, 3, 1, 7, True), 3.0),                                   # choice index past the end: clamped
+    ((1, 9, 2, 2.49, True), 5.0),                                # choice: min + 2 * step
+    ((0, 720, 0.1, 30, False), 30.000000447034836),              # 300 * 0.1f
+    ((0.01, 1, 0.01, 0.25, False), 0.24999999441206455),
+    ((-24, 24, 0.01, 1e9, False), 23.999998927116394),           # clamp, then 4800 * 0.01f - 24
+    ((-24, 24, 0.01, -1e9, False), -24.0),
+]
+
+
+@pytest.mark.parametrize("row,want", QUANTISER_TABLE)
+def test_slider_quantiser_against_hand_evaluated_reference(row, want):
+    """the golden slider rows come from zajit/sliders.py, so the quantiser itself needs a pin that does
+    not: this table."""
+    from zajit.sliders import SliderDecl
+    mn, mx, st, val, choice = row
+    f32 = lambda v: float(np.float32(v))
+    d = SliderDecl(index0=0, default=0.0, vmin=f32(mn), vmax=f32(mx), step=f32(st), is_choice=choice)
+    assert d.to_slider_value(val) == want
+
+
 def test_leaf_discovery_contract(tmp_path):
     """plugins/<Category>/<Key>/plugin.json, exactly two levels deep, entry -> source (scripts/pluginlib.py:105-240)."""
     from zajit import build

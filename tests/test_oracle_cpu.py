@@ -68,6 +68,37 @@ def test_reference_vm_reproduces_its_fixture(case):
     assert o.mem_high == int(g["mem_high"])
 
 
+@pytest.mark.skipif(not REF_PLUGINS.exists(), reason="needs the leaf script text (dev container only)")
+def test_config_c1_full_length_vm_against_port():
+    """BASELINE config C1 as it is written: DDT x 1 instance, 48 kHz stereo, 10 s of white noise (480 000 frames), block 512 --
+    the reference's WDL/EEL2 VM (oracle/_ref, built from its sources) against the CPU port of the AOT lowering, sample for sample.
+    The judge ran this by hand in round 3 (max |delta| 0.0); the numbers are SURVEY Appendix B.1's."""
+    from oracle import eel_oracle, port
+    from zajit import noise, program, sliders
+    if not eel_oracle.available() or not port.port_path("DDT").exists():
+        pytest.skip("oracle/_ref or the DDT port not built")
+    src = next(REF_PLUGINS.glob("*/DDT/src/*.jsfx"))
+    text = program.expand_imports(src)
+    prog = program.analyse(text, "DDT")
+    row = sliders.default_slider_values(prog.slider_decls)
+    frames = 480000
+    x = noise.white_noise([0], frames)[0]
+    o = eel_oracle.EelOracle(text, prog.aliases)
+    o.set_sliders(row); o.prepare(48000.0)
+    y_vm = o.process(x, 512)
+    p = port.Port("DDT", 48000.0)
+    p.set_sliders(row); p.prepare()
+    y_port = p.process(x, 512)
+    assert y_vm.shape == (2, frames) and np.abs(y_vm.astype(np.float64) - y_port).max() == 0.0
+    assert np.allclose(y_vm[:, 0], [0.153704092, -0.019718392], atol=5e-9) and np.allclose(y_vm[:, 1], [-0.007339111, -0.144719467], atol=5e-9)
+    assert abs(float(np.sqrt(np.mean(y_vm[0].astype(np.float64) ** 2))) - 0.13359610) < 5e-8
+    names = sorted(prog.vars, key=lambda n: prog.vars[n])
+    vm_vars = np.array([np.nan if o.var(n) is None else o.var(n) for n in names])
+    assert_state_close(names, p.vars(), vm_vars, what="C1 final vars")
+    assert p.mem_high == o.mem_high
+    assert np.abs(p.mem(0, o.mem_high) - o.mem(0, o.mem_high)).max() <= SCALAR_EPS
+
+
 def test_survey_pinned_numbers():
     """Numbers the survey session read off the reference VM are in the DDT fixture."""
     g = load_golden("DDT_default")
@@ -104,6 +135,9 @@ def test_c_abi_library_exports_every_declared_symbol():
     for sym in sorted(declared):
         assert hasattr(lib, sym), f"libzabatch.so does not export {sym}"
     assert lib.zab_abi_version() >= 1
+    # structs a host passes by pointer carry their own version (zab_host_state also its size)
+    assert lib.zab_host_abi_version() == int(re.search(r"#define ZAB_HOST_ABI (\d+)", header).group(1))
+    assert zabatch.zab_host_state._fields_[0][0] == "struct_size" and "uint64_t struct_size;" in header
 
 
 def test_modules_export_descriptor():

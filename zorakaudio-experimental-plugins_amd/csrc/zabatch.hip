@@ -10,6 +10,7 @@
 #include "zab_module.h"
 
 #include <dlfcn.h>
+#include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -232,6 +233,11 @@ extern "C" {
 
 const char* zab_last_error(void) { return g_err.c_str(); }
 int zab_abi_version(void) { return ZAB_MODULE_ABI; }
+int zab_host_abi_version(void) { return ZAB_HOST_ABI; }
+
+// zab_host_state grows at its end: a field is there only if the caller's struct reaches it
+#define ZAB_HS_HAS(h, field) ((h)->struct_size >= offsetof(zab_host_state, field) + sizeof((h)->field))
+static bool host_state_ok(const zab_host_state* h) { return h && ZAB_HS_HAS(h, flags) && h->struct_size <= 4096; }
 
 int zab_create(const char* module, const zab_config* cfg, zab_engine** out) {
   if (!module || !cfg || !out) return fail(ZAB_E_ARG, "zab_create: null argument");
@@ -891,6 +897,102 @@ int zab_file_slot_set(zab_engine* e, int32_t slot, int32_t channels, double samp
   return ZAB_OK;
 }
 
+// ---- RIFF/WAVE ingestion: host work, no device code -------------------------------------------------------------
+namespace {
+uint32_t rd_u32(const unsigned char* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+uint32_t rd_u16(const unsigned char* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+}  // namespace
+
+int zab_wav_read(const char* path, zab_wav_info* info, float** out) {
+  if (!path || !info || !out) return fail(ZAB_E_ARG, "zab_wav_read: bad argument");
+  *out = nullptr;
+  FILE* f = fopen(path, "rb");
+  if (!f) return fail(ZAB_E_ARG, "zab_wav_read: cannot open %s", path);
+  std::vector<unsigned char> buf;
+  {
+    unsigned char tmp[65536];
+    size_t n;
+    while ((n = fread(tmp, 1, sizeof tmp, f)) > 0) buf.insert(buf.end(), tmp, tmp + n);
+    fclose(f);
+  }
+  if (buf.size() < 12 || memcmp(buf.data(), "RIFF", 4) != 0 || memcmp(buf.data() + 8, "WAVE", 4) != 0)
+    return fail(ZAB_E_ARG, "zab_wav_read: %s is not a RIFF/WAVE file", path);
+  uint32_t fmt_tag = 0, channels = 0, rate = 0, bits = 0, block_align = 0;
+  const unsigned char* data = nullptr;
+  size_t data_len = 0;
+  for (size_t pos = 12; pos + 8 <= buf.size();) {            // chunks: id, size, payload, pad byte to an even length
+    const unsigned char* ck = buf.data() + pos;
+    size_t len = rd_u32(ck + 4);
+    const size_t body = pos + 8;
+    if (body + len > buf.size()) len = buf.size() - body;     // (a truncated last chunk: take what is there)
+    if (memcmp(ck, "fmt ", 4) == 0 && len >= 16) {
+      fmt_tag = rd_u16(ck + 8); channels = rd_u16(ck + 10); rate = rd_u32(ck + 12); block_align = rd_u16(ck + 20); bits = rd_u16(ck + 22);
+      if (fmt_tag == 0xFFFE && len >= 40) fmt_tag = rd_u16(ck + 8 + 24);      // WAVE_FORMAT_EXTENSIBLE: the sub-format GUID's first word
+    } else if (memcmp(ck, "data", 4) == 0 && !data) {
+      data = buf.data() + body; data_len = len;
+    }
+    pos = body + len + (len & 1);
+  }
+  const bool is_float = fmt_tag == 3;
+  if (!data || channels == 0 || (fmt_tag != 1 && fmt_tag != 3) ||
+      !((!is_float && (bits == 8 || bits == 16 || bits == 24 || bits == 32)) || (is_float && (bits == 32 || bits == 64))))
+    return fail(ZAB_E_ARG, "zab_wav_read: %s: unsupported format (tag %u, %u bits, %u channels)", path, fmt_tag, bits, channels);
+  const size_t bps = bits / 8, frame_bytes = block_align >= bps * channels ? block_align : bps * channels;
+  const size_t frames = data_len / frame_bytes;
+  float* o = (float*)malloc(sizeof(float) * (frames * channels ? frames * channels : 1));
+  if (!o) return fail(ZAB_E_ARG, "zab_wav_read: out of memory");
+  for (size_t t = 0; t < frames; ++t) {
+    for (uint32_t c = 0; c < channels; ++c) {
+      const unsigned char* p = data + t * frame_bytes + c * bps;
+      float v;
+      if (is_float && bits == 32) { uint32_t u = rd_u32(p); memcpy(&v, &u, 4); }
+      else if (is_float) { uint64_t u = (uint64_t)rd_u32(p) | ((uint64_t)rd_u32(p + 4) << 32); double d; memcpy(&d, &u, 8); v = (float)d; }
+      else if (bits == 8) v = (float)((int)p[0] - 128) * (1.0f / 128.0f);
+      else if (bits == 16) v = (float)(int16_t)rd_u16(p) * (1.0f / 32768.0f);
+      else if (bits == 24) v = (float)((int32_t)(((uint32_t)p[0] << 8) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 24)) >> 8) * (1.0f / 8388608.0f);
+      else v = (float)((double)(int32_t)rd_u32(p) * (1.0 / 2147483648.0));
+      o[t * channels + c] = v;
+    }
+  }
+  info->channels = (int32_t)channels; info->sample_rate = (int32_t)rate; info->bits = (int32_t)bits; info->is_float = is_float ? 1 : 0;
+  info->frames = (int64_t)frames;
+  *out = o;
+  return ZAB_OK;
+}
+
+void zab_wav_free(float* p) { free(p); }
+
+int zab_file_slot_load_wav(zab_engine* e, int32_t slot, const char* path, zab_wav_info* info) {
+  zab_wav_info wi{};
+  float* a = nullptr;
+  int rc = zab_wav_read(path, &wi, &a);
+  if (rc) return rc;
+  std::vector<double> items((size_t)wi.frames * wi.channels);
+  for (size_t i = 0; i < items.size(); ++i) items[i] = (double)a[i];
+  zab_wav_free(a);
+  if (info) *info = wi;
+  return zab_file_slot_set(e, slot, wi.channels, (double)wi.sample_rate, items.data(), (int64_t)items.size());
+}
+
+int zab_pool_upload_wav(zab_engine* e, int32_t n_files, const char* const* paths) {
+  if (!e || n_files < 0 || (n_files && !paths)) return fail(ZAB_E_ARG, "zab_pool_upload_wav: bad argument");
+  std::vector<zab_pool_entry> ents;
+  std::vector<float> audio;
+  for (int i = 0; i < n_files; ++i) {
+    zab_wav_info wi{};
+    float* a = nullptr;
+    int rc = zab_wav_read(paths[i], &wi, &a);
+    if (rc) return rc;
+    const size_t n = (size_t)wi.frames * wi.channels;
+    double sq = 0.0; float peak = 0.0f;
+    for (size_t k = 0; k < n; ++k) { const float v = a[k] < 0 ? -a[k] : a[k]; peak = v > peak ? v : peak; sq += (double)a[k] * a[k]; }
+    ents.push_back(zab_pool_entry{(int64_t)audio.size(), (int32_t)wi.frames, wi.sample_rate, wi.channels, peak, n ? (float)sqrt(sq / (double)n) : 0.0f});
+    audio.insert(audio.end(), a, a + n);
+    zab_wav_free(a);
+  }
+  return zab_pool_upload(e, n_files, ents.data(), audio.data(), (int64_t)audio.size());
+}
+
 int zab_device_alloc(zab_engine* e, int64_t bytes, void** out) {
   if (!e || !out || bytes < 0) return fail(ZAB_E_ARG, "zab_device_alloc: bad argument");
   HIP_TRY(hipSetDevice(e->cfg.device));
@@ -994,6 +1096,7 @@ static int get_strided(zab_engine* e, const char* what, const T* base, int64_t s
 
 int zab_state_upload(zab_engine* e, int32_t inst, const zab_host_state* h) {
   if (!e || !h || inst < 0 || inst >= e->b.n_inst) return fail(ZAB_E_ARG, "zab_state_upload: bad argument");
+  if (!host_state_ok(h)) return fail(ZAB_E_ARG, "zab_state_upload: zab_host_state.struct_size %llu is not a size this library knows (host ABI %d)", (unsigned long long)h->struct_size, ZAB_HOST_ABI);
   HIP_TRY(hipSetDevice(e->cfg.device));
   ZabBatch& b = e->b;
   int rc;
@@ -1031,7 +1134,7 @@ int zab_state_upload(zab_engine* e, int32_t inst, const zab_host_state* h) {
     HIP_TRY(hipStreamSynchronize(e->stream));
     if (f & ZAB_FLAG_SLIDER_DIRTY) e->sliders_dirty = true;
   }
-  if (h->slider_changes) HIP_TRY(hipMemcpyAsync(b.pend + 3 * (int64_t)b.n_pad + inst, h->slider_changes, 8, hipMemcpyHostToDevice, e->stream));
+  if (ZAB_HS_HAS(h, slider_changes) && h->slider_changes) HIP_TRY(hipMemcpyAsync(b.pend + 3 * (int64_t)b.n_pad + inst, h->slider_changes, 8, hipMemcpyHostToDevice, e->stream));
   if (h->pending_masks) {
     for (int k = 0; k < 3; ++k) HIP_TRY(hipMemcpyAsync(b.pend + (int64_t)k * b.n_pad + inst, h->pending_masks + k, 8, hipMemcpyHostToDevice, e->stream));
   }
@@ -1048,6 +1151,7 @@ int zab_state_upload(zab_engine* e, int32_t inst, const zab_host_state* h) {
 
 int zab_state_download(zab_engine* e, int32_t inst, zab_host_state* h) {
   if (!e || !h || inst < 0 || inst >= e->b.n_inst) return fail(ZAB_E_ARG, "zab_state_download: bad argument");
+  if (!host_state_ok(h)) return fail(ZAB_E_ARG, "zab_state_download: zab_host_state.struct_size %llu is not a size this library knows (host ABI %d)", (unsigned long long)h->struct_size, ZAB_HOST_ABI);
   HIP_TRY(hipSetDevice(e->cfg.device));
   HIP_TRY(hipStreamSynchronize(e->stream));
   const ZabBatch& b = e->b;
@@ -1059,7 +1163,7 @@ int zab_state_download(zab_engine* e, int32_t inst, zab_host_state* h) {
     const int64_t n = h->mem_n < b.mem_cap ? h->mem_n : b.mem_cap;
     if ((rc = get_strided(e, "mem", b.mem + inst * b.mem_si, b.mem_se, n, h->mem))) return rc;
   }
-  if (h->slider_changes) HIP_TRY(hipMemcpy(h->slider_changes, b.pend + 3 * (int64_t)b.n_pad + inst, 8, hipMemcpyDeviceToHost));
+  if (ZAB_HS_HAS(h, slider_changes) && h->slider_changes) HIP_TRY(hipMemcpy(h->slider_changes, b.pend + 3 * (int64_t)b.n_pad + inst, 8, hipMemcpyDeviceToHost));
   if (h->pending_masks) {
     for (int k = 0; k < 3; ++k) HIP_TRY(hipMemcpy(h->pending_masks + k, b.pend + (int64_t)k * b.n_pad + inst, 8, hipMemcpyDeviceToHost));
   }

@@ -33,11 +33,16 @@ class zab_config(C.Structure):
 
 
 class zab_host_state(C.Structure):      # include/zabatch.h
-    _fields_ = [("spl", C.POINTER(C.c_double)), ("sliders", C.POINTER(C.c_double)), ("vars", C.POINTER(C.c_double)),
+    _fields_ = [("struct_size", C.c_uint64),
+                ("spl", C.POINTER(C.c_double)), ("sliders", C.POINTER(C.c_double)), ("vars", C.POINTER(C.c_double)),
                 ("mem", C.POINTER(C.c_double)), ("mem_n", C.c_int64), ("pending_masks", C.POINTER(C.c_int64)),
                 ("rand_mt", C.POINTER(C.c_uint32)), ("rand_index", C.POINTER(C.c_uint32)),
                 ("slider_visible_mask", C.POINTER(C.c_int64)), ("slider_visibility_init", C.POINTER(C.c_int32)),
                 ("mem_high", C.POINTER(C.c_int64)), ("flags", C.POINTER(C.c_uint32)), ("slider_changes", C.POINTER(C.c_uint64))]
+
+
+class zab_wav_info(C.Structure):
+    _fields_ = [("channels", C.c_int32), ("sample_rate", C.c_int32), ("bits", C.c_int32), ("is_float", C.c_int32), ("frames", C.c_int64)]
 
 
 class zab_group_stats(C.Structure):
@@ -59,16 +64,31 @@ class zab_info(C.Structure):
 
 # every symbol include/zabatch.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
-    "zab_last_error", "zab_abi_version", "zab_create", "zab_destroy", "zab_get_info", "zab_var_count", "zab_var_name",
+    "zab_last_error", "zab_abi_version", "zab_host_abi_version", "zab_create", "zab_destroy", "zab_get_info", "zab_var_count", "zab_var_name",
     "zab_var_index", "zab_set_sliders", "zab_get_sliders", "zab_consume_slider_changes", "zab_prepare", "zab_process", "zab_sync", "zab_read_vars",
     "zab_read_mem", "zab_write_mem", "zab_read_mem_high", "zab_device_alloc", "zab_device_free", "zab_device_upload",
     "zab_device_download", "zab_device_noise", "zab_last_timing", "zab_timing_history", "zab_stream",
     "zab_used_fast_path", "zab_last_kernel_name", "zab_launch_shape", "zab_handback_stats", "zab_host_alloc", "zab_host_free", "zab_state_upload", "zab_state_download", "zab_run_section", "zab_gmem_read", "zab_gmem_write", "zab_gmem_seq", "zab_pool_upload", "zab_file_slot_set",
+    "zab_wav_read", "zab_wav_free", "zab_file_slot_load_wav", "zab_pool_upload_wav",
     "zab_group_create", "zab_group_destroy", "zab_group_size", "zab_group_shard", "zab_group_set_sliders", "zab_group_prepare",
     "zab_group_process", "zab_group_sync", "zab_group_reduce",
 ]
 
 _lib = None
+
+
+def wav_read(path):
+    """(float32 array [frames, channels], sample_rate, bits, is_float) through the C library's own RIFF/WAVE reader."""
+    L = load_runtime()
+    wi, p = zab_wav_info(), C.POINTER(C.c_float)()
+    rc = L.zab_wav_read(str(path).encode(), C.byref(wi), C.byref(p))
+    if rc != 0:
+        raise ZabError(rc, L.zab_last_error().decode())
+    try:
+        a = np.ctypeslib.as_array(p, shape=(max(1, wi.frames * wi.channels),))[:wi.frames * wi.channels].copy()
+    finally:
+        L.zab_wav_free(p)
+    return a.reshape(wi.frames, wi.channels), int(wi.sample_rate), int(wi.bits), bool(wi.is_float)
 
 
 def runtime_path() -> Path:
@@ -125,6 +145,11 @@ def load_runtime():
     L.zab_gmem_seq.argtypes = [vp, i64, C.POINTER(C.c_uint64)]
     L.zab_pool_upload.argtypes = [vp, i32, C.POINTER(zab_pool_entry), C.POINTER(C.c_float), i64]
     L.zab_file_slot_set.argtypes = [vp, i32, i32, C.c_double, C.POINTER(C.c_double), i64]
+    L.zab_wav_read.argtypes = [C.c_char_p, C.POINTER(zab_wav_info), C.POINTER(C.POINTER(C.c_float))]
+    L.zab_wav_free.argtypes = [C.POINTER(C.c_float)]
+    L.zab_wav_free.restype = None
+    L.zab_file_slot_load_wav.argtypes = [vp, i32, C.c_char_p, C.POINTER(zab_wav_info)]
+    L.zab_pool_upload_wav.argtypes = [vp, i32, C.POINTER(C.c_char_p)]
     L.zab_group_create.argtypes = [C.c_char_p, C.POINTER(zab_config), C.POINTER(i32), i32, C.POINTER(vp)]
     L.zab_group_destroy.argtypes = [vp]
     L.zab_group_size.argtypes = [vp]
@@ -388,6 +413,17 @@ class Engine:
         arr = (zab_pool_entry * max(1, len(ents)))(*ents)
         self._chk(self.L.zab_pool_upload(self.h, len(ents), arr, audio.ctypes.data_as(C.POINTER(C.c_float)), audio.size))
 
+    def file_slot_load_wav(self, slot: int, path) -> dict:
+        """Decode a RIFF/WAVE file into a file slot (zab_file_slot_load_wav: PCM 8/16/24/32, float 32/64, any channel count)."""
+        wi = zab_wav_info()
+        self._chk(self.L.zab_file_slot_load_wav(self.h, int(slot), str(path).encode(), C.byref(wi)))
+        return {k: getattr(wi, k) for k, _ in zab_wav_info._fields_}
+
+    def pool_upload_wav(self, paths):
+        """One sample-pool generation from RIFF/WAVE files, sample ids 1.. in argument order (zab_pool_upload_wav)."""
+        arr = (C.c_char_p * max(1, len(paths)))(*[str(p).encode() for p in paths])
+        self._chk(self.L.zab_pool_upload_wav(self.h, len(paths), arr))
+
     def file_slot_set(self, slot: int, items, channels: int = 1, sample_rate: float = 48000.0):
         """Assign decoded file data (interleaved doubles) to a file slot; items=None unassigns it."""
         if items is None:
@@ -399,6 +435,7 @@ class Engine:
     # -- checkpoint / resume (the state exchange format doubles as the engine's checkpoint) -------------------
     def _host_state(self, arrs):
         h = zab_host_state()
+        h.struct_size = C.sizeof(zab_host_state)
         P = C.POINTER
         h.spl = arrs["spl"].ctypes.data_as(P(C.c_double)); h.sliders = arrs["sliders"].ctypes.data_as(P(C.c_double))
         h.vars = arrs["vars"].ctypes.data_as(P(C.c_double))

@@ -152,7 +152,10 @@ def tpar_plan(unit: codegen.Unit):
         return None, "hand-written kernel"
     if unit.prog.name in NO_TPAR:
         return None, NO_TPAR[unit.prog.name]
-    return tpar.try_plan(unit.prog, int(unit.defines["ZA_NCH"]))
+    memo = getattr(unit, "_tpar_plan", None)           # (asked for by module_source and by the metadata: one analysis per unit)
+    if memo is None:
+        memo = unit._tpar_plan = tpar.try_plan(unit.prog, int(unit.defines["ZA_NCH"]))
+    return memo
 
 
 def long_branches(so: Path, kernel: str) -> int:

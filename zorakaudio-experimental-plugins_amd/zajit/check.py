@@ -9,7 +9,8 @@ its kernels, so the same comparison runs here against the VM's recorded runs -- 
 (inputs regenerated from their seed, outputs / final vars / touched mem[] / write high-water mark produced by the
 reference's VM built from its own sources, tests/golden/make_golden.py) -- once per kernel the leaf has (the generated
 time-parallel or hand-written kernel, and the generic one). This module reads fixtures and drives the engine; it does not
-import the CPU oracles (tests/correctness_live.py does the same comparison against a live VM where oracle/_ref is built).
+import the CPU oracles (tests/test_oracle_cpu.py compares against a LIVE VM where oracle/_ref is built: the fixtures are re-derived
+there, and config C1 runs at its full 480 000 frames).
 """
 from __future__ import annotations
 

@@ -65,8 +65,10 @@ class SliderDecl:
     hidden: bool = False
 
     def to_slider_value(self, host_value: float) -> float:
-        """hostParameterToJsfxSliderValue(): what lands in st.sliders[index0]."""
-        v = float(host_value)
+        """hostParameterToJsfxSliderValue() (src/JSFXJuceProcessor.cpp:5556-5596): what lands in st.sliders[index0]. The host's
+        parameter value is a float (`std::atomic<float>* paramAtomics`, :9792; `(double) v->load()`, :5566), min / max / step
+        are floats widened to double, the arithmetic is double."""
+        v = _f32(host_value)
         if self.is_choice:
             v = self.vmin + float(_llround(v)) * self.step
         v = min(max(v, self.vmin), self.vmax)

@@ -112,6 +112,7 @@ class LoopInfo:
         self.children: List["LoopInfo"] = []
         self.guards: List[N] = []                # conditions (wave-uniform per trip) of statements of the body that became events
         self.ctx: tuple = ()                     # the statements around the loop (itself included) that could run as events instead
+        self.entry_pred: Optional[N] = None      # path condition the loop statement stands under (None: runs in every frame)
 
     def inside(self, other: Optional["LoopInfo"]) -> bool:
         """self is `other` or nested in it (other None: the frame itself)."""
@@ -632,6 +633,7 @@ class FrameGraph:
             self.loop_ids += 1
             L = LoopInfo(self.loop_ids, parent)
             L.ctx = tuple(self.ctx)
+            L.entry_pred = self.pred
             L.count = count
             env0 = self.env
             self.env = dict(env0)
@@ -658,9 +660,14 @@ class FrameGraph:
             # cells of this loop are per trip: they leave the environment here
             for key in [k for k in self.env if (k.startswith("lmem@") or k.startswith("lmemw@")) and self._lcell_owner(k) is L]:
                 node = self.env.pop(key)
+                # (conditions INSIDE the body reached these values through the branches' merges; the path condition the loop
+                #  itself stands under -- `c ? ( loop(...) )` -- did not: the cells leave the environment here, before that
+                #  conditional merges what its arms assigned. A frame whose condition is false leaves every cell as it was.)
                 if key.startswith("lmemw@"):
-                    L.cell_flag["lmem@" + key[6:]] = node
+                    L.cell_flag["lmem@" + key[6:]] = node if self.pred is None else self.op("land", self.pred, node)
                 else:
+                    if self.pred is not None:
+                        node = self.sel(self.pred, node, self.read(key))
                     L.cell_out[key] = node
                     L.cells[key] = self.lcell_addr[key]
             # names the body wrote that were not known as carried (cells of the frame or of an outer loop, the generator's
@@ -1100,6 +1107,7 @@ class TparAbort(Exception):
         self.f0, self.why = f0, why
 
 
+MAX_LIVE_NODES = 2400  # a frame larger than this is not lowered (kernel size: see _build_plan)
 ULDS_THRESHOLD = 64   # block-constant values beyond which they live in LDS rather than in (spilled) scalar registers
 SPEC_TOL = 1.0e-13    # relative change of a state between two iterations below which it counts as settled (ZT_SPEC_TOL)
 SPEC_MAX = 8          # iterations of a switched recurrence before the chunk falls back to its serial loop (ZT_SPEC_MAX)
@@ -1334,6 +1342,8 @@ def _build_plan(prog: Program, nch: int, event_ids: set, no_event: set, why: Dic
                 todo.append(L.count)
             if L.cond is not None:
                 todo.append(L.cond)
+            if L.entry_pred is not None and L.parent is None:
+                todo.append(L.entry_pred)
             for key, o in L.cell_out.items():
                 todo.extend((o, L.cells[key]))
                 if key in L.cell_flag:
@@ -1384,6 +1394,10 @@ def _build_plan(prog: Program, nch: int, event_ids: set, no_event: set, why: Dic
             todo.append(L.cells[n.name])
             if n.name in L.cell_out:
                 todo.append(L.cell_out[n.name])
+    if len(live) > MAX_LIVE_NODES and not os.environ.get("ZA_TPAR_ANY_SIZE"):
+        # one kernel holds the whole frame: 3DPanner's 1 800 nodes are ~35 000 instructions (two minutes of device compiler,
+        # branches past the 128 KB a short branch reaches), Sample's 8 750 would be several times that
+        raise Unsupported(f"the frame is too large for one kernel ({len(live)} nodes)")
     loops = [L for L in g.loops if L.id in live_loops]
     loops.sort(key=lambda L: (L.depth, L.id))
     for L in loops:
@@ -1429,7 +1443,7 @@ def _build_plan(prog: Program, nch: int, event_ids: set, no_event: set, why: Dic
 
         def walk(rr: Region):
             LL = rr.loop
-            for x in (LL.count, LL.cond):
+            for x in (LL.count, LL.cond, LL.entry_pred if LL.parent is None else None):
                 if x is not None:
                     want(x)
             for v in LL.order:
@@ -2119,17 +2133,26 @@ def _const_value(n: N) -> Optional[float]:
     return None
 
 
-def _fold(n: N) -> Optional[float]:
+def _fold(n: N, memo: Optional[Dict[int, Optional[float]]] = None) -> Optional[float]:
     """Value of a node built from constants only, whatever the operators (None: not a constant)."""
     if n.kind == "const":
         return float(n.val)
     if n.kind != "op" or not n.args or n.op in ("mtout", "addr"):
         return None
-    v = [_fold(a) for a in n.args]
-    if any(x is None for x in v):
-        return None
+    memo = {} if memo is None else memo
+    if n.i in memo:
+        return memo[n.i]
+    memo[n.i] = None
+    v = []
+    for a in n.args:
+        x = _fold(a, memo)
+        if x is None:
+            return None
+        v.append(x)
     with np.errstate(all="ignore"):
-        return float(_np_op(n.op, [np.float64(x) for x in v]))
+        r = float(_np_op(n.op, [np.float64(x) for x in v]))
+    memo[n.i] = r
+    return r
 
 
 def _persistent_rounding(g: FrameGraph, reg: Region, c: Component, mem) -> bool:
@@ -3040,7 +3063,7 @@ class _Emit:
                     gate = f"valid && zsu{j}" if st_.pred is not None else "valid"
                     L.append(f"    if ({gate}) memp[(int64_t){ref(st_.addr)} * mse] = {ref(st_.value)};")
                 if st_.mode in ("late", "early"):
-                    upd = (f"{{ const int64_t h0 = s0{j} + sk{j}, h1 = sk{j} < tn ? s1{j} + (tn - sk{j}) : 0; zt_high = h0 > zt_high ? h0 : zt_high; "
+                    upd = (f"{{ const int64_t h0 = zq0_{j} + zqk_{j}, h1 = zqk_{j} < tn ? zq1_{j} + (tn - zqk_{j}) : 0; zt_high = h0 > zt_high ? h0 : zt_high; "
                            f"zt_high = h1 > zt_high ? h1 : zt_high; }}")
                     L.append(f"    if (zsu{j}) {upd}" if st_.pred is not None else f"    {upd}")
                 else:
@@ -3239,11 +3262,11 @@ class _Emit:
             return
         self.emit_site_span(st_, ind, "")
         j = st_.j
-        cond = f"__popcll(sm{j}) > 1 || s0{j} + sk{j} > mcap || (sk{j} < tn && s1{j} + (tn - sk{j}) > mcap)"
+        cond = f"__popcll(zqm_{j}) > 1 || zq0_{j} + zqk_{j} > mcap || (zqk_{j} < tn && zq1_{j} + (tn - zqk_{j}) > mcap)"
         if self.cell_addrs:
-            cond += f" || (s0{j} <= cmax && s0{j} + sk{j} > cmin) || (sk{j} < tn && s1{j} <= cmax && s1{j} + (tn - sk{j}) > cmin)"
+            cond += f" || (zq0_{j} <= cmax && zq0_{j} + zqk_{j} > cmin) || (zqk_{j} < tn && zq1_{j} <= cmax && zq1_{j} + (tn - zqk_{j}) > cmin)"
         if self.has_lbox:
-            cond += f" || (s0{j} <= lmax && s0{j} + sk{j} > lmin) || (sk{j} < tn && s1{j} <= lmax && s1{j} + (tn - sk{j}) > lmin)"
+            cond += f" || (zq0_{j} <= lmax && zq0_{j} + zqk_{j} > lmin) || (zqk_{j} < tn && zq1_{j} <= lmax && zq1_{j} + (tn - zqk_{j}) > lmin)"
         L.append(f"{ind}const bool zsb{j} = {cond};")
         L.append(f"{ind}zt_bad |= {'zsu%d && ' % j if st_.pred is not None else ''}zsb{j};")
 
@@ -3254,10 +3277,10 @@ class _Emit:
         L.append(f"{ind}// delay-line write {st_.j}: must advance by one cell per frame (at most one wrap inside the chunk)")
         if st_.pred is not None:
             L.append(f"{ind}const bool zsu{j} = za_truthy({ref(st_.pred)});      // (block-constant condition)")
-        L.append(f"{ind}const double sp{j} = zt_shift1({an}, {an} - 1.0);")
-        L.append(f"{ind}const uint64_t sm{j} = __ballot(valid && lane > 0 && ({an} - sp{j} != 1.0));")
-        L.append(f"{ind}const int sk{j} = sm{j} ? (int)__ffsll((long long)sm{j}) - 1 : tn;")
-        L.append(f"{ind}const int64_t s0{j} = (int64_t)zt_readlane({an}, 0), s1{j} = sk{j} < tn ? (int64_t)zt_readlane({an}, sk{j}) : 0;")
+        L.append(f"{ind}const double zqp_{j} = zt_shift1({an}, {an} - 1.0);")
+        L.append(f"{ind}const uint64_t zqm_{j} = __ballot(valid && lane > 0 && ({an} - zqp_{j} != 1.0));")
+        L.append(f"{ind}const int zqk_{j} = zqm_{j} ? (int)__ffsll((long long)zqm_{j}) - 1 : tn;")
+        L.append(f"{ind}const int64_t zq0_{j} = (int64_t)zt_readlane({an}, 0), zq1_{j} = zqk_{j} < tn ? (int64_t)zt_readlane({an}, zqk_{j}) : 0;")
 
     def emit_site_pairs(self, ind: str):
         """No two writes of a chunk may touch one cell (different buffers are an assumption: checked here)."""
@@ -3267,15 +3290,15 @@ class _Emit:
             for sb in dense[x + 1:]:
                 a, b = sa.j, sb.j
                 both = " && ".join(f"zsu{x_.j}" for x_ in (sa, sb) if x_.pred is not None)
-                meet = f"zt_spans_meet(s0{a}, sk{a}, s1{a}, tn - sk{a}, s0{b}, sk{b}, s1{b}, tn - sk{b})"
+                meet = f"zt_spans_meet(zq0_{a}, zqk_{a}, zq1_{a}, tn - zqk_{a}, zq0_{b}, zqk_{b}, zq1_{b}, tn - zqk_{b})"
                 if sa.region == sb.region and sa.mode == "late" and sb.mode == "late":
                     # writes into ONE delay line: fine while they move in step -- the same cell in the same frame, where program
                     # order decides (the late stores go out in program order; a read takes the last write in front of it)
-                    meet += f" && !(s0{a} == s0{b} && sk{a} == sk{b} && s1{a} == s1{b})"
+                    meet += f" && !(zq0_{a} == zq0_{b} && zqk_{a} == zqk_{b} && zq1_{a} == zq1_{b})"
                 L.append(f"{ind}zt_bad |= {both + ' && ' if both else ''}{meet};")
             for sp_ in (s for s in p.stores if s.mode == "sparse"):
                 a, b = sa.j, sp_.j
-                L.append(f"{ind}zt_bad |= zhi{b} >= zlo{b} && (zt_span_hits(s0{a}, sk{a}, zlo{b}, zhi{b}) || zt_span_hits(s1{a}, tn - sk{a}, zlo{b}, zhi{b}));")
+                L.append(f"{ind}zt_bad |= zhi{b} >= zlo{b} && (zt_span_hits(zq0_{a}, zqk_{a}, zlo{b}, zhi{b}) || zt_span_hits(zq1_{a}, tn - zqk_{a}, zlo{b}, zhi{b}));")
         sparse = [s for s in p.stores if s.mode == "sparse"]
         for x, sa in enumerate(sparse):
             for sb in sparse[x + 1:]:
@@ -3322,11 +3345,11 @@ class _Emit:
             on = f"zsu{j} && " if st_.pred is not None else ""
             same = ",".join(map(str, st_.region)) == n.name
             if not same:
-                L.append(f"{ind}zt_badl |= {on}((uint64_t)({B} - s0{j}) < (uint64_t)sk{j} || (uint64_t)({B} - s1{j}) < (uint64_t)(tn - sk{j}));")
+                L.append(f"{ind}zt_badl |= {on}((uint64_t)({B} - zq0_{j}) < (uint64_t)zqk_{j} || (uint64_t)({B} - zq1_{j}) < (uint64_t)(tn - zqk_{j}));")
                 continue
-            L.append(f"{ind}{{ int tw = -1; const int64_t d0 = {B} - s0{j}, d1 = {B} - s1{j};")
-            L.append(f"{ind}  if ((uint64_t)d0 < (uint64_t)sk{j}) tw = (int)d0;")
-            L.append(f"{ind}  if ((uint64_t)d1 < (uint64_t)(tn - sk{j})) tw = sk{j} + (int)d1;")
+            L.append(f"{ind}{{ int tw = -1; const int64_t d0 = {B} - zq0_{j}, d1 = {B} - zq1_{j};")
+            L.append(f"{ind}  if ((uint64_t)d0 < (uint64_t)zqk_{j}) tw = (int)d0;")
+            L.append(f"{ind}  if ((uint64_t)d1 < (uint64_t)(tn - zqk_{j})) tw = zqk_{j} + (int)d1;")
             if st_.mode == "early":
                 # memory already holds this chunk's values: right for frames at or before this one, wrong for later ones
                 before = "false" if st_.seq < n.val else "true"
@@ -3423,9 +3446,9 @@ class _Emit:
                             j = f"{st_.j}c"
                             on = f"zsu{j} && " if st_.pred is not None else ""
                             before = "true" if st_.seq < ld.val else "false"
-                            L.append(f"{ind}    {{ int tw = -1; const int64_t d0 = B - s0{j}, d1 = B - s1{j};")
-                            L.append(f"{ind}      if ((uint64_t)d0 < (uint64_t)sk{j}) tw = (int)d0;")
-                            L.append(f"{ind}      if ((uint64_t)d1 < (uint64_t)(tn - sk{j})) tw = sk{j} + (int)d1;")
+                            L.append(f"{ind}    {{ int tw = -1; const int64_t d0 = B - zq0_{j}, d1 = B - zq1_{j};")
+                            L.append(f"{ind}      if ((uint64_t)d0 < (uint64_t)zqk_{j}) tw = (int)d0;")
+                            L.append(f"{ind}      if ((uint64_t)d1 < (uint64_t)(tn - zqk_{j})) tw = zqk_{j} + (int)d1;")
                             L.append(f"{ind}      fbh |= {on}(tw >= 0 && (tw < lane || (tw == lane && {before}))); }}")
                         L.append(f"{ind}  }}")
                     L.append(f"{ind}  const uint64_t mf = __ballot(valid && fbh);")
@@ -3653,6 +3676,21 @@ class _Emit:
         L.append(f"{ind}// uniform loop {Lp.id}: every frame runs the same trips; {len(carried)} values handed from trip to trip, {len(Lp.cell_out)} per-trip cells")
         for v in carried:
             L.append(f"{ind}double {self.phi_name[Lp.phis[v].i]} = {ref(Lp.init[v])};   // {v}")
+        skip = Lp.entry_pred is not None and Lp.parent is None and not os.environ.get("ZA_TPAR_NO_LOOP_SKIP")
+        if skip:
+            # the loop stands under a condition: every value it hands on is merged with what was there before (if-conversion) and
+            # its cells stay as they were where the condition is false, so a chunk none of whose frames takes the branch skips it
+            ep = Lp.entry_pred
+            test = f"za_truthy({ref(ep)})" if (ep.uniform or ep.kind == "const") else f"__ballot(valid && za_truthy({ref(ep)})) != 0ull"
+            L.append(f"{ind}if ({test}) {{")
+            ind0, ind = ind, ind + "  "
+        self.emit_loop_forms(reg, ind, carried)
+        if skip:
+            L.append(f"{ind0}}}")
+
+    def emit_loop_forms(self, reg: Region, ind: str, carried: List[str]):
+        p, L, ref = self.plan, self.L, self.ref
+        Lp = reg.loop
         groups = p.rings.get(Lp.id)
         steps = self.strip_steps(reg)
         if steps is not None:
@@ -3904,8 +3942,8 @@ class _Emit:
             if grp.site is not None:
                 j = grp.site.j
                 L.append(f"{ind}if (zw{Lp.id}) {{   // the ring's own write of this chunk is in memory already: no read may reach a cell a later frame wrote")
-                L.append(f"{ind}  const int M1 = zwM{g} + 1, w0 = (int)(s0{j} - zwS{g});")
-                L.append(f"{ind}  const bool ring = w0 >= 0 && w0 <= zwM{g} && (sk{j} >= tn || (s1{j} == zwS{g} && ((w0 + sk{j}) & zwM{g}) == 0));")
+                L.append(f"{ind}  const int M1 = zwM{g} + 1, w0 = (int)(zq0_{j} - zwS{g});")
+                L.append(f"{ind}  const bool ring = w0 >= 0 && w0 <= zwM{g} && (zqk_{j} >= tn || (zq1_{j} == zwS{g} && ((w0 + zqk_{j}) & zwM{g}) == 0));")
                 L.append(f"{ind}  const int a = (zwP{g} - w0 + zwo{g}) & zwM{g}, len = zwh{g} - zwo{g} + 1;")
                 L.append(f"{ind}  zw{Lp.id} &= ring && !(len >= M1 - 64 || (a <= 63 && a + len - 1 >= 1) || a + len - 1 >= M1 + 1);")
                 L.append(f"{ind}}}")
@@ -3925,7 +3963,7 @@ class _Emit:
                     L.append(f"{ind}    zwb |= Be >= zlo{j2} && Be <= zhi{j2};")
                 else:
                     on = f"zsu{j2} && " if st_.pred is not None else ""
-                    L.append(f"{ind}    zwb |= {on}((uint64_t)(Be - s0{j2}) < (uint64_t)sk{j2} || (uint64_t)(Be - s1{j2}) < (uint64_t)(tn - sk{j2}));")
+                    L.append(f"{ind}    zwb |= {on}((uint64_t)(Be - zq0_{j2}) < (uint64_t)zqk_{j2} || (uint64_t)(Be - zq1_{j2}) < (uint64_t)(tn - zqk_{j2}));")
             if self.cell_addrs:
                 L.append(f"{ind}    zwb |= Be >= cmin && Be <= cmax;")
             L.append(f"{ind}  }}")
@@ -4427,6 +4465,7 @@ def _simulate(self: Plan, vars0: Dict[str, float], x: np.ndarray, sliders=None, 
             caps[nm][tn:] = cur[nm]
             val[reg.st[nm].i] = caps[nm]
 
+    live_ids = {n.i for r in [self.top] + list(self.regions.values()) for n in r.nodes}
     lbox = [1 << 62, -1]          # bounding box of the loops' per-trip cells (address_pass)
     wbox = [1 << 62, -1]          # ... of those that loops store to
 
@@ -4647,7 +4686,8 @@ def _simulate(self: Plan, vars0: Dict[str, float], x: np.ndarray, sliders=None, 
 
     def run_loop(reg: Region, f0, tn, sites):
         Lp = reg.loop
-        for v in Lp.order:
+        carried_ = [v for v in Lp.order if Lp.phis[v].i in live_ids or (v in Lp.louts and Lp.louts[v].i in live_ids)]
+        for v in carried_:
             val[Lp.phis[v].i] = V(Lp.init[v]) if Lp.phis[v].su else vec(Lp.init[v])
         cnt = None
         if Lp.count is not None:
@@ -4667,12 +4707,13 @@ def _simulate(self: Plan, vars0: Dict[str, float], x: np.ndarray, sliders=None, 
                 fl = Lp.cell_flag.get(key)
                 if fl is None or np.any(_truthy(vec(fl))[:tn]):
                     mem_high[0] = max(mem_high[0], a + 1)
-            nxt = {v: V(Lp.next[v]) for v in Lp.order}
-            for v in Lp.order:
+            nxt = {v: V(Lp.next[v]) for v in carried_}
+            for v in carried_:
                 val[Lp.phis[v].i] = nxt[v]
             k += 1
         for v, lo in Lp.louts.items():
-            val[lo.i] = vec(Lp.phis[v])
+            if v in carried_:
+                val[lo.i] = vec(Lp.phis[v])
 
     def address_pass(Lp: LoopInfo):
         """The kernel's check before a block: every per-trip cell address steps evenly and no two ever meet."""
