@@ -149,7 +149,7 @@ def reference_vm_baseline(seconds_budget: float = 4.0):
         vm.process(x, BLOCK)
         reps += 1
     vm_rate = reps * frames * 2 / (time.perf_counter() - t0) / 1e6
-    out = {"value": vm_rate, "unit": "Msamples/s", "cores": 1, "kind": "reference",
+    out = {"value": vm_rate, "unit": "Msamples/s", "cores": 1, "kind": "reference VM on a repo-authored script of the leaf's class, not the leaf itself",
            "sample": f"WDL/EEL2 portable VM (oracle/_ref, gcc -O2) on tests/fixtures/delaytaps.jsfx defaults, {frames}-frame passes "
                      f"for ~{seconds_budget:.0f} s, block {BLOCK}, one core"}
     if port.port_path("fx_delaytaps").exists():
@@ -370,16 +370,22 @@ def main() -> int:
         total_samples = job.units      # SUM over ranks
         k_ms = float(np.mean(kernel_ms))
         achieved = alg / (k_ms * 1e-3) / 1e9
+        # HBM traffic of the dominant kernel: PMC counters need the profiler around the process, so they cannot be read inside
+        # this run; tools/pmc_pass.sh runs THIS command under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes)
+        # and leaves profiles/pmc_<kernel>_<instances>x<frames>.json, which is picked up here by kernel name and batch shape
+        # (profiles/pmc_traffic.json: the default configuration's, kept under its old name too)
         traffic, traffic_source = None, None
-        pmc = ROOT / "profiles" / "pmc_traffic.json"
-        if pmc.exists():
+        kname = kernel_name
+        for pmc in (ROOT / "profiles" / f"pmc_{kname}_{n_inst}x{frames}.json", ROOT / "profiles" / "pmc_traffic.json"):
+            if traffic is not None or not pmc.exists():
+                continue
             try:
                 rec = json.loads(pmc.read_text())
                 if (rec.get("leaf", "DDT") == leaf and rec.get("instances") == n_inst and rec.get("frames") == frames
-                        and rec.get("fast") == used_fast):
+                        and rec.get("fast") == used_fast and rec.get("kernel", kname) == kname):
                     traffic = rec.get("hbm_bytes_per_launch")
-                    traffic_source = ("profiles/pmc_traffic.json: committed rocprofv3 --pmc passes of this command "
-                                      "(FETCH_SIZE / WRITE_SIZE, separate runs), not measured in this run")
+                    traffic_source = (f"profiles/{pmc.name}: committed rocprofv3 --pmc passes of this command "
+                                      "(FETCH_SIZE / WRITE_SIZE, separate runs; tools/pmc_pass.sh), not measured in this run")
             except Exception:
                 traffic = None
         null_db = lambda a: None if null_n == 0 else (float(20.0 * math.log10(a)) if a > 0 else -400.0)

@@ -85,6 +85,7 @@ def test_modtilt_zero_tilt_is_identity_and_blocks_do_not_matter():
 
 
 VARIANTS = [("ClickBeGoneSG", "generic"), ("ClickBeGoneSG", "wave1"), ("ClickBeGoneSG", "wave4"),
+            ("ClickBeGoneSG", "wave2"), ("ClickBeGoneSG", "wave8"), ("ClickBeGoneSG", "wave16"),     # round 4: the G sweep's widths
             ("ModTilt", "generic"), ("ModTilt", "wave"), ("GTS", "generic"), ("VAR", "generic"), ("VAR", "wave"), ("RED", "generic"), ("RED", "wave"),
             ("ClickBeGoneSG", "generic64"), ("ModTilt", "generic64"), ("RED", "generic64")]   # 64 instances per wavefront
 
@@ -153,6 +154,30 @@ def test_gpu_matches_restatement(leaf, variant, monkeypatch):
         err = np.abs(y[i].astype(np.float64) - want).max()
         assert err <= tol, (leaf, i, err)
         assert np.abs(st[i] - r.state()).max() <= tol, (leaf, i)
+
+
+@pytest.mark.gpu
+def test_config_c5_per_gpu_batch_1024_instances_x_48000_frames():
+    """BASELINE config C5's batch per GPU as it is timed -- ClickBeGoneSG x 1024 instances, one second of audio -- on the wave
+    kernel, sampled instances against the restatement bit for bit (the 1024-per-GPU batch was only ever
+    timed). Every instance has its own noise and its own settings; the launch is cut once so that state crosses a launch."""
+    import zabatch
+    fr = _ref()
+    n, frames = 1024, 48000
+    x = _input("ClickBeGoneSG", list(range(7000, 7000 + n)), frames)
+    x[:, :, 30000:] *= 0.03
+    rows = np.zeros((n, 64)); rows[:, :5] = FAUST["ClickBeGoneSG"]
+    rows[:, 0] = np.linspace(0, 100, n); rows[:, 1] = np.linspace(100, 0, n); rows[:, 3] = np.arange(n) % 3; rows[:, 4] = (np.arange(n) // 3) % 2
+    with zabatch.Engine("ClickBeGoneSG", n, path=zabatch.ZAB_PATH_FAST) as e:
+        e.set_sliders(rows); e.prepare()
+        y = np.concatenate([e.process_host(x[:, :, :20001], block=512), e.process_host(x[:, :, 20001:], block=512)], axis=2)
+        assert e.used_fast_path() and e.last_kernel_name().startswith("zf_cbg_wave")
+        st = e.read_vars()
+    for i in (0, 1, 63, 64, 511, 777, 1022, 1023):
+        r = fr.FaustRef("ClickBeGoneSG", 48000)
+        want = r.compute(x[i], rows[i, :8].astype(np.float32))
+        assert np.array_equal(y[i], want.astype(np.float32)), i
+        assert np.abs(st[i] - r.state()).max() == 0.0, i
 
 
 def _build_host(key, tmp_path):

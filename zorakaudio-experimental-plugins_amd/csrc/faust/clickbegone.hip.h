@@ -119,6 +119,25 @@ struct ZfClickBeGone {
     base = env * c.base_a + st[S_BASE] * c.one_m_base_a;
     st[S_BASE] = base;
   }
+  // detect_scaled() split where its own feed-forward part is, for the wave kernel (same IEEE operations, so the same bits):
+  //   env_step   the HPFs and the envelope: env = max(env * rel, |hpL|, |hpR|) as ONE three-way maximum (max is exact and
+  //              associative: v_max3_f32 with |.| modifiers gives the bits of max(env * rel, max(|hpL|, |hpR|)));
+  //   (the product env * base_a of every frame is formed frame-parallel by the caller)
+  //   base_step  base = eb + base * (1 - base_a).
+  ZF_FN static float env_step(float* st, const Ctl& c, float vL, float vR) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 v = {vL, vR}, hp0 = {st[S_HPL], st[S_HPR]}, a2 = {c.a, c.a};
+    const f2 hp = v + a2 * hp0;
+    st[S_HPL] = hp.x; st[S_HPR] = hp.y;
+    const float env = __builtin_fmaxf(__builtin_fmaxf(st[S_ENV] * c.env_rel, fabsf(hp.x)), fabsf(hp.y));
+    st[S_ENV] = env;
+    return env;
+  }
+  ZF_FN static float base_step(float* st, const Ctl& c, float env_times_base_a) {
+    const float base = env_times_base_a + st[S_BASE] * c.one_m_base_a;
+    st[S_BASE] = base;
+    return base;
+  }
   ZF_FN static float trigger(const Ctl& c, float env, float base, float e_norm) {                // :77,95 (feed-forward)
     const float ratio = env / (base + 1e-12f);
     return (float)((int)(ratio > c.ratio_thr) * (int)(e_norm > c.err_thr));

@@ -94,24 +94,33 @@ __global__ void __launch_bounds__(64) zf_cbg_wave(ZabBatch b, ZabAudio a) {
       us[g][1][lane] = c.a * (aR(0) - aR(1));
     }
     zf_wave_sync();
-    // ---- C: recursion 1, lane = instance -------------------------------------------------------------------------------
+    // ---- C: recursion 1, lane = instance. Its feed-forward part -- the product env * base_a inside the baseline's update --
+    // is taken out of the serial chain (round 4): C1 runs the HPFs and the envelope over the chunk (4 dependent VALU
+    // operations per frame: packed multiply, packed add, multiply, three-way maximum), C2 forms env * base_a with one lane
+    // per frame, C3 runs the baseline's two remaining operations per frame. Same IEEE operations on the same operands.
     if (lane < ng) {
       if (tn == 64) {                                                 // full chunk: straight-line code, LDS reads up front
         float ul[64], ur[64];
 #pragma unroll
         for (int n = 0; n < 64; ++n) { ul[n] = us[lane][0][n]; ur[n] = us[lane][1][n]; }
 #pragma unroll
-        for (int n = 0; n < 64; ++n) {
-          float env, base;
-          L::detect_scaled(st, myc, ul[n], ur[n], env, base);
-          eb[lane][0][n] = env; eb[lane][1][n] = base;
-        }
+        for (int n = 0; n < 64; ++n) eb[lane][0][n] = L::env_step(st, myc, ul[n], ur[n]);
       } else {
-        for (int n = 0; n < tn; ++n) {
-          float env, base;
-          L::detect_scaled(st, myc, us[lane][0][n], us[lane][1][n], env, base);
-          eb[lane][0][n] = env; eb[lane][1][n] = base;
-        }
+        for (int n = 0; n < tn; ++n) eb[lane][0][n] = L::env_step(st, myc, us[lane][0][n], us[lane][1][n]);
+      }
+    }
+    zf_wave_sync();
+    for (int g = 0; g < ng; ++g) eb[g][1][lane] = eb[g][0][lane] * ctls[g].base_a;         // C2
+    zf_wave_sync();
+    if (lane < ng) {                                                                        // C3
+      if (tn == 64) {
+        float ev[64];
+#pragma unroll
+        for (int n = 0; n < 64; ++n) ev[n] = eb[lane][1][n];
+#pragma unroll
+        for (int n = 0; n < 64; ++n) eb[lane][1][n] = L::base_step(st, myc, ev[n]);
+      } else {
+        for (int n = 0; n < tn; ++n) eb[lane][1][n] = L::base_step(st, myc, eb[lane][1][n]);
       }
     }
     zf_wave_sync();
@@ -170,7 +179,7 @@ __global__ void __launch_bounds__(64) zf_cbg_wave(ZabBatch b, ZabAudio a) {
 static int zf_cbg_pick_g(int n_inst) {
   // measured on MI355X (48 000 frames): N=1024: G=1 3.6 ms, G=4 8.3 ms; N=4096: 8.6 / 8.7 ms; N=16384: G=4 21 ms
   int g = n_inst <= 4096 ? 1 : 4;
-  if (const char* e = getenv("ZAB_CBG_G")) { const int v = atoi(e); if (v == 1 || v == 4) g = v; }
+  if (const char* e = getenv("ZAB_CBG_G")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) g = v; }
   return g;
 }
 static int32_t zf_cbg_applies(const ZabBatch*, const ZabAudio* a) { return a->frames > 0 ? 1 : 0; }
@@ -178,6 +187,9 @@ static hipError_t zf_cbg_launch(const ZabBatch* b, const ZabAudio* a, hipStream_
   const int g = zf_cbg_pick_g(b->n_inst);
   const dim3 grid((b->n_inst + g - 1) / g), block(64);
   if (g == 1) hipLaunchKernelGGL(zf_cbg_wave<1>, grid, block, 0, st, *b, *a);
-  else hipLaunchKernelGGL(zf_cbg_wave<4>, grid, block, 0, st, *b, *a);
+  else if (g == 2) hipLaunchKernelGGL(zf_cbg_wave<2>, grid, block, 0, st, *b, *a);
+  else if (g == 4) hipLaunchKernelGGL(zf_cbg_wave<4>, grid, block, 0, st, *b, *a);
+  else if (g == 8) hipLaunchKernelGGL(zf_cbg_wave<8>, grid, block, 0, st, *b, *a);
+  else hipLaunchKernelGGL(zf_cbg_wave<16>, grid, block, 0, st, *b, *a);
   return hipGetLastError();
 }

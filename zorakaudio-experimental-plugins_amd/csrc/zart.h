@@ -36,6 +36,15 @@
 #define ZA_FN static inline __attribute__((always_inline))
 #define ZA_NOINLINE static __attribute__((noinline))
 #endif
+// The section functions za_section_{init,slider,block,sample}. A script with a very large variable table (ZA_BIG_STATE: Texture's
+// 1087, Sample's 4058) runs from a state object in memory whatever is done, so inlining its sections into every
+// kernel that runs them -- process, the time-parallel kernel's @block / event-frame functions, its serial tail, prepare, slider --
+// buys nothing and costs the device compiler the same several-hundred-kilobyte body three to five times: they are real calls there.
+#if defined(ZA_BIG_STATE) && ZA_BIG_STATE && defined(__HIPCC__) && !defined(ZA_INLINE_ALL)
+#define ZA_SECTION_FN __device__ __attribute__((noinline))
+#else
+#define ZA_SECTION_FN ZA_FN
+#endif
 #if defined(ZA_OUTLINE_FNS) && ZA_OUTLINE_FNS
 #define ZA_UFN ZA_NOINLINE     // user functions of a very large script: real calls (zajit/codegen.py)
 #else

@@ -44,20 +44,17 @@ HIP_FLAGS += os.environ.get("ZA_EXTRA_HIP_FLAGS", "").split()      # experiments
 # leaves with a hand-written kernel: name -> header under csrc/kernels/
 FAST_KERNELS = {"DDT": "kernels/ddt_ring2.hip.h"}
 FAST_KERNEL_DEPS = {"DDT": ["kernels/ddt_fast.hip.h"]}     # headers the hand-written kernel file includes
-# Per-leaf code-shape choices measured on MI355X (tools/catalog_sweep.py, 1024 instances). zart.h's arena
-# load is branch-free by default (better or equal on 20 leaves, up to 14 %); these four delay-line / FIR style scripts run
-# faster with the bounds check as a branch around the load (Roomalizer 1.76x, TSEQ 1.07x, DOT 1.05x, DPT 1.03x).
+# Build variants of the repo's own test fixtures (no catalog leaf is named here: what used to be per-leaf choices -- the arena
+# load's bounds check as a branch for four delay-line scripts, replica lanes for two scripts' elementwise loops, uniform branches
+# for one script's mode switches -- are now rules over what the translator finds in a script: zajit/codegen.py make_unit,
+# zajit/tpar/plan.py _wants_uniform_guards; DESIGN.md section 4.1 has the measurements the rules came from).
 LEAF_FLAGS = {"fx_dynkat_s1": ["-DZT_SPEC_MAX=1"],       # test variant: switched recurrences mostly fall back to their serial loop
               # FFT builtins with the whole 4096-point transform in LDS (zart_fft.h: ZA_FFT_LDS_POINTS; default 1024 + slicing)
-              "fx_fftkat_full": ["-DZA_FFT_LDS_POINTS=4096"], "fx_fftbench_full": ["-DZA_FFT_LDS_POINTS=4096"],
-              "Roomalizer": ["-DZA_LD_BRANCH"], "TSEQ": ["-DZA_LD_BRANCH"], "DOT": ["-DZA_LD_BRANCH"], "DPT": ["-DZA_LD_BRANCH"]}
-# leaves that could take a time-parallel kernel but keep the generic one, with the reason (measured)
-NO_TPAR: Dict[str, str] = {
-    # no audio path at all: the leaf is its @block (msg / gmem bookkeeping), which the lane-per-instance kernel runs with the
-    # state in registers from block to block (256 instances x 48 000 frames: 1124 ms against 1570 ms here)
-    "3DPannerManager": "@sample is empty: nothing to run time-parallel",
-}
-LONG_BRANCH_LIMIT = 32
+              "fx_fftkat_full": ["-DZA_FFT_LDS_POINTS=4096"], "fx_fftbench_full": ["-DZA_FFT_LDS_POINTS=4096"]}
+# leaves that could take a time-parallel kernel but keep the generic one, with the reason (none at present: a leaf whose @sample
+# does nothing is recognised by the lowering itself)
+NO_TPAR: Dict[str, str] = {}
+LONG_BRANCH_LIMIT = int(os.environ.get("ZA_LONG_BRANCH_LIMIT", "32"))
 # leaves whose state the hand-written kernel wants contiguous per instance
 INSTANCE_MAJOR = {"DDT"}
 

@@ -46,16 +46,19 @@ class Unit:
         }
 
 
-# Leaves whose only cooperative loops are elementwise ("map") loops get replica lanes when that was measured to pay: Contour
-# 108 -> 82 ms at 384 x 48 000 on the generic kernel (TextureXY 478 -> 515 does not). NeuroCV's generic kernel loses by it
-# (109 -> 174 ms: its map loops are a small part of every frame), but since round 3 the leaf runs on its time-parallel kernel,
-# where the loops only run in the analysis frame the whole wavefront executes as an event: 78.8 -> 72.4 ms there.
-MAP_REPLICA_LEAVES = {"Contour", "NeuroCV"}
+# Scripts whose only shareable loops are elementwise ("map") loops get replica lanes exactly when they have a time-parallel kernel:
+# there the wavefront IS the instance, so the section code it runs between the frames (@block, event frames) shares such loops
+# over 64 lanes that would otherwise idle (measured: NeuroCV 78.8 -> 72.4 ms, Contour's generic kernel 108 -> 82 ms), while on
+# the lane-per-instance kernel alone thin wavefronts for map loops did not pay (NeuroCV 109 -> 174 ms, TextureXY 478 -> 515 ms).
 
 
 def make_unit(prog: Program) -> Unit:
     em = Emitter(prog)
     code = em.emit()
+    from . import tpar
+    import os
+    nch_ = max(0, min(64, int(prog.io["process"])))
+    tp_plan = (None, "disabled (ZA_NO_TPAR)") if os.environ.get("ZA_NO_TPAR") else tpar.try_plan(prog, nch_)
     used_spl = list(range(64)) if em.dyn_spl else sorted(em.used_spl)
     used_sl = list(range(64)) if em.dyn_sl else sorted(em.used_sl)
     # aliased sliders are written back to vars by the host sequence, so they must be resident too
@@ -86,13 +89,17 @@ def make_unit(prog: Program) -> Unit:
         "ZA_USES_MSG": "1" if "msg" in em.features else "0",
         "ZA_USES_FFT": "1" if "fft" in em.features else "0",
         # has accumulation loops shared by replica lanes (emit.py) -- or only elementwise loops, where that was measured to pay
-        "ZA_USES_COOP": "1" if ("coop" in em.features or ("coopmap" in em.features and prog.name in MAP_REPLICA_LEAVES)) else "0",
+        "ZA_USES_COOP": "1" if ("coop" in em.features or ("coopmap" in em.features and tp_plan[0] is not None)) else "0",
         # leaves whose mem[] is touched only by zart.h's load/store/memset/memcpy can keep its low part in LDS (zart.h)
         "ZA_USES_LMEM": "1" if "mem" in em.features and not em.features & {"fft", "gmem", "pool", "file", "msg"} else "0",
         # very large scripts (Sample: 754 specialised functions, 1 MB of expressions) cannot be flattened into one kernel body
         # by the device compiler in reasonable time or memory: their user functions become real calls
         "ZA_OUTLINE_FNS": "1" if len(prog.fns) > 256 else "0",
+        # a variable table this large lives in memory anyway: its section functions are real calls (csrc/zart.h ZA_SECTION_FN)
+        "ZA_BIG_STATE": "1" if prog.nvars > 1000 else "0",
         "ZA_MEMTOP": f"{float(prog.memtop)!r}",
     }
-    return Unit(prog=prog, code=code, defines=defines, features=sorted(em.features), used_spl=used_spl,
+    unit = Unit(prog=prog, code=code, defines=defines, features=sorted(em.features), used_spl=used_spl,
                 used_sl=used_sl, strings=list(em.strings))
+    unit._tpar_plan = tp_plan          # (zajit/build.py tpar_plan: one analysis per unit)
+    return unit

@@ -1000,7 +1000,7 @@ class Emitter:
     def section(self, sec: str) -> str:
         self.cur_sec = sec
         body = " ".join(self.stmt(st) for st in self.p.sections.get(sec, []))
-        return f"template <class S> ZA_FN void za_section_{sec}(S& s) {{ {body} }}"
+        return f"template <class S> ZA_SECTION_FN void za_section_{sec}(S& s) {{ {body} }}"
 
     def emit(self) -> str:
         order = self._fn_order()
