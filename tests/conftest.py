@@ -33,8 +33,10 @@ def dbfs(x: float) -> float:
     return float(20.0 * np.log10(max(x, 1e-300)))
 
 
-def assert_state_close(names, got, want, eps=SCALAR_EPS, what="vars", skip=()):
-    """Reference comparator semantics (src/JSFXCorrectnessCheck.h:40-49): NaN==NaN, inf by equality, else abs <= eps."""
+def assert_state_close(names, got, want, eps=SCALAR_EPS, what="vars", skip=(), rel=False):
+    """Reference comparator semantics (src/JSFXCorrectnessCheck.h:40-49): NaN==NaN, inf by equality, else abs <= eps.
+    rel=True (comparisons between two of THIS repo's kernels, not against the reference VM): eps scales with the magnitude above
+    1 -- a re-associated sum differs by an ulp, which on a variable of 3e11 (Texture's knee_t with its span at the floor) is 3e-5."""
     bad = []
     # EEL2 variable names are case-insensitive, the AOT compiler's are not (SURVEY 8 a-2 addendum): a script that uses both `PI`
     # and `pi` (Spectral/Texture) has ONE variable in the reference VM and two in the compiled path, so those names cannot be
@@ -53,7 +55,7 @@ def assert_state_close(names, got, want, eps=SCALAR_EPS, what="vars", skip=()):
         if np.isnan(a) or np.isinf(a) or np.isinf(b):
             ok = (np.isnan(a) and np.isnan(b)) or a == b
         else:
-            ok = abs(a - b) <= eps
+            ok = abs(a - b) <= eps * (max(1.0, abs(a), abs(b)) if rel else 1.0)
         if not ok:
             bad.append((n, a, b))
     assert not bad, f"{what} mismatch (first 8 of {len(bad)}): {bad[:8]}"

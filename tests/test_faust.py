@@ -86,6 +86,7 @@ def test_modtilt_zero_tilt_is_identity_and_blocks_do_not_matter():
 
 VARIANTS = [("ClickBeGoneSG", "generic"), ("ClickBeGoneSG", "wave1"), ("ClickBeGoneSG", "wave4"),
             ("ClickBeGoneSG", "wave2"), ("ClickBeGoneSG", "wave8"), ("ClickBeGoneSG", "wave16"),     # round 4: the G sweep's widths
+            ("ClickBeGoneSG", "quad"),                                                              # ... and four wavefronts for four instances
             ("ModTilt", "generic"), ("ModTilt", "wave"), ("GTS", "generic"), ("VAR", "generic"), ("VAR", "wave"), ("RED", "generic"), ("RED", "wave"),
             ("ClickBeGoneSG", "generic64"), ("ModTilt", "generic64"), ("RED", "generic64")]   # 64 instances per wavefront
 
@@ -119,9 +120,15 @@ def test_gpu_matches_restatement(leaf, variant, monkeypatch):
     monkeypatch.delenv("ZAB_IPW", raising=False)
     if variant == "generic64":
         monkeypatch.setenv("ZAB_IPW", "64")
+    monkeypatch.delenv("ZAB_CBG_KERNEL", raising=False)
     if variant.startswith("wave"):
         if variant[4:]:
             monkeypatch.setenv("ZAB_CBG_G", variant[4:])
+        if leaf == "ClickBeGoneSG":
+            monkeypatch.setenv("ZAB_CBG_KERNEL", "wave")
+        path = zabatch.ZAB_PATH_FAST
+    if variant == "quad":
+        monkeypatch.setenv("ZAB_CBG_KERNEL", "quad")
         path = zabatch.ZAB_PATH_FAST
     n, frames = 70, 3000                                  # two workgroups, ragged tile tail
     x = _input(leaf, list(range(40, 40 + n)), frames)
@@ -141,7 +148,7 @@ def test_gpu_matches_restatement(leaf, variant, monkeypatch):
     with zabatch.Engine(leaf, n, path=path) as e:
         e.set_sliders(rows); e.prepare()
         y1 = e.process_host(x[:, :, :1700], block=512)
-        assert e.used_fast_path() == variant.startswith("wave")
+        assert e.used_fast_path() == (variant.startswith("wave") or variant == "quad")
         y2 = e.process_host(x[:, :, 1700:], block=512)    # state carried across launches
         st = e.read_vars()
     y = np.concatenate([y1, y2], axis=2)
@@ -157,13 +164,15 @@ def test_gpu_matches_restatement(leaf, variant, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_config_c5_per_gpu_batch_1024_instances_x_48000_frames():
+@pytest.mark.parametrize("kernel", ["wave", "quad"])
+def test_config_c5_per_gpu_batch_1024_instances_x_48000_frames(kernel, monkeypatch):
     """BASELINE config C5's batch per GPU as it is timed -- ClickBeGoneSG x 1024 instances, one second of audio -- on the wave
     kernel, sampled instances against the restatement bit for bit (the 1024-per-GPU batch was only ever
     timed). Every instance has its own noise and its own settings; the launch is cut once so that state crosses a launch."""
     import zabatch
     fr = _ref()
-    n, frames = 1024, 48000
+    monkeypatch.setenv("ZAB_CBG_KERNEL", kernel)
+    n, frames = (1024 if kernel == "wave" else 1022), 48000      # (a workgroup of the four-wave kernel with two live instances)
     x = _input("ClickBeGoneSG", list(range(7000, 7000 + n)), frames)
     x[:, :, 30000:] *= 0.03
     rows = np.zeros((n, 64)); rows[:, :5] = FAUST["ClickBeGoneSG"]
@@ -173,7 +182,7 @@ def test_config_c5_per_gpu_batch_1024_instances_x_48000_frames():
         y = np.concatenate([e.process_host(x[:, :, :20001], block=512), e.process_host(x[:, :, 20001:], block=512)], axis=2)
         assert e.used_fast_path() and e.last_kernel_name().startswith("zf_cbg_wave")
         st = e.read_vars()
-    for i in (0, 1, 63, 64, 511, 777, 1022, 1023):
+    for i in (0, 1, 63, 64, 511, 777, n - 2, n - 1):
         r = fr.FaustRef("ClickBeGoneSG", 48000)
         want = r.compute(x[i], rows[i, :8].astype(np.float32))
         assert np.array_equal(y[i], want.astype(np.float32)), i

@@ -176,14 +176,27 @@ __global__ void __launch_bounds__(64) zf_cbg_wave(ZabBatch b, ZabAudio a) {
   }
 }
 
+#include "clickbegone_quad.hip.h"
+
 static int zf_cbg_pick_g(int n_inst) {
-  // measured on MI355X (48 000 frames): N=1024: G=1 3.6 ms, G=4 8.3 ms; N=4096: 8.6 / 8.7 ms; N=16384: G=4 21 ms
-  int g = n_inst <= 4096 ? 1 : 4;
+  // measured on MI355X (48 000 frames, round 4: gpurun_out/s2_cbg_g_sweep.txt -> profiles/r04_cbg_g_sweep.txt), G = 1 / 2 / 4 / 8 / 16:
+  //   N = 1024: 2.90 / 4.24 / 6.09 / 10.1 / 24.3 ms;  N = 4096: 6.38 / 5.60 / 6.57 / 10.7 / 24.3;  N = 8192: 12.1 / 10.4 / 7.98 / 10.8 / 25.2
+  int g = n_inst <= 2560 ? 1 : (n_inst <= 6144 ? 2 : 4);
   if (const char* e = getenv("ZAB_CBG_G")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) g = v; }
   return g;
 }
 static int32_t zf_cbg_applies(const ZabBatch*, const ZabAudio* a) { return a->frames > 0 ? 1 : 0; }
+static bool zf_cbg_use_quad(int n_inst) {
+  bool quad = false;                        // (ZAB_CBG_KERNEL = quad | wave pins it)
+  if (const char* e = getenv("ZAB_CBG_KERNEL")) quad = e[0] == 'q';
+  (void)n_inst;
+  return quad;
+}
 static hipError_t zf_cbg_launch(const ZabBatch* b, const ZabAudio* a, hipStream_t st) {
+  if (zf_cbg_use_quad(b->n_inst)) {
+    hipLaunchKernelGGL(zf_cbg_wave_quad, dim3((b->n_inst + 3) / 4), dim3(256), 0, st, *b, *a);
+    return hipGetLastError();
+  }
   const int g = zf_cbg_pick_g(b->n_inst);
   const dim3 grid((b->n_inst + g - 1) / g), block(64);
   if (g == 1) hipLaunchKernelGGL(zf_cbg_wave<1>, grid, block, 0, st, *b, *a);

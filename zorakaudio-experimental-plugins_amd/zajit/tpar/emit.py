@@ -540,7 +540,11 @@ class _Emit:
                     L.append(f"    const int64_t ca{a.i} = (int64_t){ref(a)};")
             if self.cell_addrs:
                 ca = self.cell_addrs
-                clash = " || ".join([f"ca{a.i} >= mcap" for a in ca] + [f"ca{a.i} == ca{b_.i}" for i_, a in enumerate(ca) for b_ in ca[i_ + 1:]])
+                # (cells the frame only READS may share an address -- x[0] and x[n - 1] with n = 1 -- and may lie past the arena,
+                #  where a read yields 0: only a cell that is stored to must be alone and inside)
+                wr = {p.cells[nm].i for nm in p.cells if nm in p.outs}
+                clash = " || ".join([f"ca{a.i} >= mcap" for a in ca if a.i in wr]
+                                    + [f"ca{a.i} == ca{b_.i}" for i_, a in enumerate(ca) for b_ in ca[i_ + 1:] if a.i in wr or b_.i in wr]) or "false"
                 L.append(f"    int64_t cmin = ca{ca[0].i}, cmax = ca{ca[0].i};")
                 for a in ca[1:]:
                     L.append(f"    cmin = ca{a.i} < cmin ? ca{a.i} : cmin; cmax = ca{a.i} > cmax ? ca{a.i} : cmax;")

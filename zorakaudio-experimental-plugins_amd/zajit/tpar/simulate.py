@@ -71,8 +71,9 @@ def _simulate(self: Plan, vars0: Dict[str, float], x: np.ndarray, sliders=None, 
     one block (@block, if the script has one, is not run here).
     Returns (y float32 [nch, frames], vars after {name: value}, spl after {k: value}). Raises TparAbort when a chunk breaks
     one of the run-time conditions of the lowering (the kernel hands such a launch to the serial code)."""
-    if self.events or any(L.guards for L in self.loops):
-        raise NotImplementedError("plans with events run a frame of the script's own section code: device only")
+    # Plans with events (or guards inside loops) run the frame an event falls on with the script's own section code -- device only.
+    # The restatement still covers them as long as no event is due: the conditions are evaluated where the kernel evaluates
+    # them, and the first one that holds ends the simulation with NotImplementedError.
     import sys
     _pkg = sys.modules[__package__]                # (the package's tunables as they stand now: tests set them on the package)
     SPEC_MAX, SPEC_TOL = _pkg.SPEC_MAX, _pkg.SPEC_TOL
@@ -265,6 +266,9 @@ def _simulate(self: Plan, vars0: Dict[str, float], x: np.ndarray, sliders=None, 
             elif kind == "loop":
                 run_loop(it[1], f0, tn, sites)
             elif kind == "cut":
+                for ev_ in self.events:
+                    if np.any(_truthy(vec(ev_))[:tn]):
+                        raise NotImplementedError(f"an event is due in the chunk at frame {f0}: that frame runs the script's own section code (device only)")
                 hit = np.zeros(WAVE, dtype=bool)
                 for ld in self.fb_loads:
                     B = vec(ld.args[0]).astype(np.int64)
@@ -410,7 +414,9 @@ def _simulate(self: Plan, vars0: Dict[str, float], x: np.ndarray, sliders=None, 
         for v in Lp.order:
             if Lp.phis[v].su:
                 val[Lp.phis[v].i] = V(Lp.init[v])
-        seqs: Dict[str, List[int]] = {key: [] for key in Lp.cells}
+        # (the cells the trips use: one only a guard reads is loaded by the guard's own evaluation, like in the kernel's pass)
+        pass_cells = {key: a for key, a in Lp.cells.items() if (key in Lp.cin and Lp.cin[key].i in live_ids) or key in Lp.cell_out}
+        seqs: Dict[str, List[int]] = {key: [] for key in pass_cells}
         cnt = None
         if Lp.count is not None:
             c = uni(Lp.count, "loop count")
@@ -428,7 +434,27 @@ def _simulate(self: Plan, vars0: Dict[str, float], x: np.ndarray, sliders=None, 
                     break
             if stop or (Lp.cond is not None and not _in_subtree(Lp.cond, Lp) and not _truthy(np.float64(uni(Lp.cond, "cond")))):
                 break
-            for key, a in Lp.cells.items():
+            gmemo: Dict[int, np.float64] = {}
+
+            def gv(n: N):                       # a guard's nodes inside the loop: evaluated here only (as in the kernel's pass)
+                if n.kind == "const":
+                    return np.float64(n.val)
+                if not _in_subtree(n, Lp) or n.kind == "phi":
+                    return np.float64(uni(n, "guard operand"))
+                if n.i in gmemo:
+                    return gmemo[n.i]
+                if n.kind == "lcin":
+                    a_ = int(gv(self.g.lcell_addr[n.name]))
+                    r_ = np.float64(memv[a_] if 0 <= a_ < mcap else 0.0)
+                else:
+                    r_ = np.float64(_np_op(n.op, [gv(a_) for a_ in n.args]))
+                gmemo[n.i] = r_
+                return r_
+
+            for gc in Lp.guards:
+                if _truthy(gv(gc)):
+                    raise NotImplementedError(f"a statement of loop {Lp.id} that runs as an event is due (trip {k}): device only")
+            for key, a in pass_cells.items():
                 seqs[key].append(int(uni(a, "cell address")))
             nxt = {v: V(Lp.next[v]) for v in Lp.order if Lp.phis[v].su}
             for v, x_ in nxt.items():
@@ -468,10 +494,12 @@ def _simulate(self: Plan, vars0: Dict[str, float], x: np.ndarray, sliders=None, 
             if _truthy(np.float64(V(gn))):
                 raise TparAbort(0, "a rare-event branch the lowering left out is due")
         cell_addr = {name: int(V(a)) for name, a in self.cells.items()}
-        if len(set(cell_addr.values())) != len(cell_addr) or any(a >= len(memv) for a in cell_addr.values()):
-            raise TparAbort(0, "mem[] cells alias each other or lie past the arena")
+        wr_cells = {nm: a for nm, a in cell_addr.items() if nm in self.outs}
+        if (any(a >= len(memv) for a in wr_cells.values())
+                or any(a == a2 for nm, a in wr_cells.items() for nm2, a2 in cell_addr.items() if nm2 != nm)):
+            raise TparAbort(0, "a mem[] cell that is stored to aliases another or lies past the arena")
         for Lp in self.loops:
-            if Lp.cells:
+            if Lp.cells or Lp.guards:
                 address_pass(Lp)
         carry = {name: np.float64(inv_value(name)) for name in self.st}
         hcarry = {name: np.float64(inv_value(name)) for name in self.holdvars}
