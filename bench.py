@@ -204,6 +204,7 @@ def main() -> int:
     ap.add_argument("--null-instances", type=int, default=4, help="instances per rank checked against the CPU checker")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-null-test", action="store_true")
+    ap.add_argument("--mem-cap", type=int, default=0, help="mem[] cells per instance (0: the leaf's default arena of 65536; Alias needs 524288)")
     ap.add_argument("--group", action="store_true",
                     help="ONE process over the C library's zab_group_* (a host thread + stream per GPU, RCCL for the end-of-run "
                          "statistics) instead of one torchrun rank per GPU; same shards, same JSON line")
@@ -260,7 +261,8 @@ def main() -> int:
     if args.group:
         # the whole job in this process: zab_group_create shards n_total instances over the devices exactly as sharding.plan
         # does over ranks (contiguous ranges); shard 0's engine stands where rank 0's engine stands below
-        grp = zabatch.Group(leaf, n_total, devices=list(range(world)), srate=SRATE, max_block=BLOCK, path=path, first_instance_id=1)
+        grp = zabatch.Group(leaf, n_total, devices=list(range(world)), srate=SRATE, max_block=BLOCK, path=path, first_instance_id=1,
+                            **({"mem_cap": args.mem_cap} if args.mem_cap else {}))
         grp.set_sliders(meta["default_sliders"])
         grp.prepare()
         eng = grp.shards[0][2]
@@ -274,7 +276,8 @@ def main() -> int:
         grp.sync()
         d_in, d_out = g_in[0], g_out[0]
     else:
-        eng = zabatch.Engine(leaf, n_inst, srate=SRATE, max_block=BLOCK, device=local_rank, path=path, first_instance_id=1 + lo)
+        eng = zabatch.Engine(leaf, n_inst, srate=SRATE, max_block=BLOCK, device=local_rank, path=path, first_instance_id=1 + lo,
+                             mem_cap=args.mem_cap)
         nch = eng.nch
         eng.set_sliders(meta["default_sliders"])
         eng.prepare()

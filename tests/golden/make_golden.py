@@ -104,6 +104,8 @@ CASES = [
     ("fx_voicekat", "dense", {0: 23, 2: 0.05, 3: 1}, 2500, 500),
     # BASELINE config C3's literal shape: 4096-point STFT, hop 1024, EIGHT channels per instance
     ("fx_stft4k8", "default", {0: 0.35}, 8192, 512),
+    # coupled state machines (three and four states, a wrap written with floor): zt_scanN, numeric guesses
+    ("fx_statekat", "default", {}, 6000, 512), ("fx_statekat", "alt", {0: 0.35, 1: 7, 2: 0.02}, 5000, 500),
 ]
 # round 4: 44 more random programs, with the memory idioms of tests/fixtures/make_fuzz.py program2 (rings, a feedback echo, stores
 # under conditions, band loops, wrapped counters, a rare heavy branch, instance state): 1200 frames in blocks of 128 / 100

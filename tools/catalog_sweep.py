@@ -35,6 +35,7 @@ def main() -> int:
     ap.add_argument("--out", default="")
     ap.add_argument("--only", default="", help="comma-separated leaf names (default: every built leaf)")
     ap.add_argument("--cpu-seconds", type=float, default=2.0, help="budget of the CPU checker per leaf (0: skip)")
+    ap.add_argument("--arena-gb", type=int, default=192, help="HBM the mem[] arenas of one leaf's batch may take (rounds 1-3: 48)")
     args = ap.parse_args()
     lib = ROOT / "zorakaudio-experimental-plugins_amd" / "lib"
     leaves = sorted(p.stem for p in lib.glob("*.json") if not p.stem.startswith("fx_"))
@@ -51,7 +52,9 @@ def main() -> int:
         m = re.search(r"needed >= (\d+)", row.get("status", ""))
         if m:                                  # fixed arena too small for this leaf: size it from the device's report
             cap = 1 << (int(m.group(1)) + 64).bit_length()
-            row["instances"] = max(1, min(args.instances, (48 << 30) // (cap * 8)))
+            # (arenas of tens of millions of cells: as many instances as two thirds of the card's 288 GB hold -- a wavefront's run
+            #  time does not depend on how many others run until the chip is full, so a small batch only understates the kernel)
+            row["instances"] = max(1, min(args.instances, (args.arena_gb << 30) // (cap * 8)))
             row["mem_cap"] = cap
             run_one(zabatch, args, leaf, meta, nch, row, cap)
         if row.get("kernel_ms"):

@@ -187,9 +187,10 @@ static int zf_cbg_pick_g(int n_inst) {
 }
 static int32_t zf_cbg_applies(const ZabBatch*, const ZabAudio* a) { return a->frames > 0 ? 1 : 0; }
 static bool zf_cbg_use_quad(int n_inst) {
-  bool quad = false;                        // (ZAB_CBG_KERNEL = quad | wave pins it)
+  // measured (48 000 frames; profiles/r04_cbg_quad_vs_wave.txt): N = 1024: 2.22 ms against 2.89 (wave, G = 1); 4096: 5.02 against 5.58
+  // (G = 2); 8192: 9.90 against 7.97 (G = 4) -- four instances per serial instruction stream pay while the chip has SIMDs to spare
+  bool quad = n_inst <= 4608;               // (ZAB_CBG_KERNEL = quad | wave pins it)
   if (const char* e = getenv("ZAB_CBG_KERNEL")) quad = e[0] == 'q';
-  (void)n_inst;
   return quad;
 }
 static hipError_t zf_cbg_launch(const ZabBatch* b, const ZabAudio* a, hipStream_t st) {

@@ -195,6 +195,49 @@ __device__ __forceinline__ double zt_scan1_sum(double b, double y_in, int lane) 
 }
 
 // ---- two coupled states: y[t] = A[t] y[t-1] + b[t], A = [a00 a01; a10 a11] ---------------------------------------------
+// D coupled states (round 4: three -- a gate, its smoother and the smoother's previous value; a play position, its direction and
+// an "active" latch): the maps y -> A y + b of the 64 frames composed by the same six DPP steps, D x D + D values per lane.
+template <int D> struct ZtMapN { double a[D][D]; double b[D]; };
+template <int D, int CTRL, int ROWS> __device__ __forceinline__ void zt_scanN_step(ZtMapN<D>& m) {
+  ZtMapN<D> s, r;
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) s.a[i][j] = zt_dpp<CTRL, ROWS>(m.a[i][j], i == j ? 1.0 : 0.0);     // (no source lane: the identity map)
+    s.b[i] = zt_dpp<CTRL, ROWS>(m.b[i], 0.0);
+  }
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      double acc = m.a[i][0] * s.a[0][j];
+#pragma unroll
+      for (int k = 1; k < D; ++k) acc = __builtin_fma(m.a[i][k], s.a[k][j], acc);
+      r.a[i][j] = acc;
+    }
+    double acc = m.b[i];
+#pragma unroll
+    for (int k = D - 1; k >= 0; --k) acc = __builtin_fma(m.a[i][k], s.b[k], acc);
+    r.b[i] = acc;
+  }
+  m = r;
+}
+template <int D> __device__ __forceinline__ void zt_scanN(ZtMapN<D>& m) {
+  zt_scanN_step<D, ZT_ROW_SHR(1), 0xF>(m);
+  zt_scanN_step<D, ZT_ROW_SHR(2), 0xF>(m);
+  zt_scanN_step<D, ZT_ROW_SHR(4), 0xF>(m);
+  zt_scanN_step<D, ZT_ROW_SHR(8), 0xF>(m);
+  zt_scanN_step<D, ZT_ROW_BCAST15, 0xA>(m);
+  zt_scanN_step<D, ZT_ROW_BCAST31, 0xC>(m);
+}
+// the states such a scan implies at the END of each frame, given the carried-in state c[]
+template <int D> __device__ __forceinline__ double zt_mapN_apply(const ZtMapN<D>& m, int i, const double* c) {
+  double acc = m.b[i];
+#pragma unroll
+  for (int k = D - 1; k >= 0; --k) acc = __builtin_fma(m.a[i][k], c[k], acc);
+  return acc;
+}
+
 struct ZtMap2 { double a00, a01, a10, a11, b0, b1; };
 #define ZT_SCAN2_STEP(CTRL, ROWS)                                                             \
   {                                                                                           \

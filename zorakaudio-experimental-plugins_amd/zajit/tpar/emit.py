@@ -1351,6 +1351,15 @@ class _Emit:
             L.append(f"{ind}  zt_scan2_inv(sb{s0}, sb{s1}, am, zt_m + {k} * ZT_MAT_TABLE_DOUBLES, zo, {cn(n0)}, {cn(n1)}, lane); }}")
             L.append(f"{ind}const double n{s0} = zt_shift1(sb{s0}, {cn(n0)});")
             L.append(f"{ind}const double n{s1} = zt_shift1(sb{s1}, {cn(n1)});")
+        elif len(c.names) > 2:
+            d = len(c.names)
+            sid = [reg.st[nm].i for nm in c.names]
+            rows = ", ".join("{" + ", ".join(ref(c.A[r][k]) for k in range(d)) + "}" for r in range(d))
+            L.append(f"{ind}ZtMapN<{d}> sm{sid[0]} = {{{{{rows}}}, {{{', '.join(ref(c.b[r]) for r in range(d))}}}}};   // {', '.join(c.names)}: {d} coupled affine states")
+            L.append(f"{ind}zt_scanN<{d}>(sm{sid[0]});")
+            L.append(f"{ind}const double sc{sid[0]}[{d}] = {{{', '.join(cn(nm) for nm in c.names)}}};")
+            for r, nm in enumerate(c.names):
+                L.append(f"{ind}const double n{sid[r]} = zt_shift1(zt_mapN_apply<{d}>(sm{sid[0]}, {r}, sc{sid[0]}), {cn(nm)});")
         else:
             n0, n1 = c.names
             s0, s1 = reg.st[n0].i, reg.st[n1].i
@@ -1372,13 +1381,13 @@ class _Emit:
         for c in comps:
             for k, gn in enumerate(c.gnodes):
                 gname[gn.i] = f"g{gn.name}_{k}"
-                L.append(f"{ind}bool {gname[gn.i]};")
+                L.append(f"{ind}{'double' if gn.op == 'num' else 'bool'} {gname[gn.i]};")
 
         def xref(x: N, loc: Dict[int, str]) -> str:
             if x.i in loc:
                 return loc[x.i]
             if x.kind == "guess":
-                return f"({gname[x.i]} ? 1.0 : 0.0)"
+                return gname[x.i] if x.op == "num" else f"({gname[x.i]} ? 1.0 : 0.0)"
             return ref(x)
 
         def slice_eval(c: Component, ind2: str, out_prefix: str):
@@ -1387,7 +1396,10 @@ class _Emit:
                 loc[m.i] = f"v{m.i}"
                 L.append(f"{ind2}const double v{m.i} = {_expr(m.op, [xref(x, loc) for x in m.args])};")
             for k, (cnd, gn) in enumerate(zip(c.conds, c.gnodes)):
-                L.append(f"{ind2}{out_prefix}{gname[gn.i]} = za_truthy({xref(cnd, loc)});")
+                if gn.op == "num":
+                    L.append(f"{ind2}{out_prefix.replace('bool', 'double')}{gname[gn.i]} = {xref(cnd, loc)};")
+                else:
+                    L.append(f"{ind2}{out_prefix}{gname[gn.i]} = za_truthy({xref(cnd, loc)});")
 
         L.append(f"{ind}{{   // first pattern: the states taken to stay at their carried values")
         for c in comps:
@@ -1406,6 +1418,15 @@ class _Emit:
                 L.append(f"{ind}  double sa{s} = {xref(c.A[0][0], loc)}, sb{s} = {xref(c.b[0], loc)};")
                 L.append(f"{ind}  zt_scan1(sa{s}, sb{s});")
                 L.append(f"{ind}  s{s} = zt_shift1(__builtin_fma(sa{s}, {cn(nm)}, sb{s}), {cn(nm)});")
+            elif len(c.names) > 2:
+                d = len(c.names)
+                sid = [reg.st[nm].i for nm in c.names]
+                rows = ", ".join("{" + ", ".join(xref(c.A[r][k], loc) for k in range(d)) + "}" for r in range(d))
+                L.append(f"{ind}  ZtMapN<{d}> sm{sid[0]} = {{{{{rows}}}, {{{', '.join(xref(c.b[r], loc) for r in range(d))}}}}};")
+                L.append(f"{ind}  zt_scanN<{d}>(sm{sid[0]});")
+                L.append(f"{ind}  const double sc{sid[0]}[{d}] = {{{', '.join(cn(nm) for nm in c.names)}}};")
+                for r, nm in enumerate(c.names):
+                    L.append(f"{ind}  s{sid[r]} = zt_shift1(zt_mapN_apply<{d}>(sm{sid[0]}, {r}, sc{sid[0]}), {cn(nm)});")
             else:
                 n0, n1 = c.names
                 s0, s1 = reg.st[n0].i, reg.st[n1].i

@@ -183,6 +183,23 @@ def _pure_scalar(prog: Program, x) -> bool:
     return False
 
 
+GUARD_MIN_BODY = 48      # syntax nodes (through the functions it calls) from which a guard's body is worth keeping out of the frame
+
+
+def _ast_size(prog: Program, x, seen=None, cap: int = 100000) -> int:
+    """Syntax nodes of x, through the user functions it calls (each counted once)."""
+    seen = set() if seen is None else seen
+    n, todo = 0, [x]
+    while todo and n < cap:
+        y = todo.pop()
+        n += 1
+        if isinstance(y, S.Call) and y.fn in prog.fns and y.fn not in seen:
+            seen.add(y.fn)
+            todo.append(prog.fns[y.fn].body)
+        todo.extend(S.children(y))
+    return n
+
+
 def split_guards(prog: Program):
     """Top-level statements of @sample of the form `G ? ( ... )` where G reads only variables that nothing else in @sample
     writes and the body assigns one of them -- the "rebuild when the sample rate changed / a table is dirty" idiom: running the
@@ -192,10 +209,14 @@ def split_guards(prog: Program):
     items = list(prog.sections.get("sample", []))
     if len(items) == 1 and isinstance(items[0], S.Seq):
         items = list(items[0].items)
+    # (a LIGHT body -- a handful of assignments, `block_event_arm ? ( latch the block's MIDI flags; block_event_arm = 0 )`, which
+    #  @block re-arms every block -- is cheaper as an ordinary conditional of the frame than as a serial frame per block:
+    #  Texture spent 22 % of its kernel in those; only bodies that are heavy or large stay out of the frame)
     cand = {k for k, st in enumerate(items)
             if isinstance(st, (S.Cond, S.If)) and (st.els is None or isinstance(st.els, S.Num)) and st.then is not None
             and _pure_scalar(prog, st.cond)
-            and (_assigned_names(prog, [st.then]) & _read_names(prog, [st.cond]))}
+            and (_assigned_names(prog, [st.then]) & _read_names(prog, [st.cond]))
+            and (_heavy(prog, st.then) or _ast_size(prog, st.then) > GUARD_MIN_BODY)}
     while cand:
         rest = [st for k, st in enumerate(items) if k not in cand]
         wrest = _assigned_names(prog, rest)
@@ -227,13 +248,21 @@ def _heavy(prog: Program, x, seen=None) -> bool:
 EVENT = "__event"
 
 
-def split_events(prog: Program, stmts, keep=frozenset(), origin=None, cache=None):
+def split_events(prog: Program, stmts, keep=frozenset(), origin=None, cache=None, lower_modes=True):
     """Statements `C ? ( ... )` (no else) of @sample -- at the top or inside other conditionals, not inside loops or functions --
     whose body is heavy (_heavy) and whose condition is a plain expression: the "every hop: run the FFT" / "buffer full: convolve
     a block" idiom. The lowering replaces each by a marker that keeps the condition; the kernel evaluates the conditions first in
     every chunk, lets the frames before the first one that holds take the parallel path, runs that one frame with the serial
     section code (zt_frame) and starts over behind it. Returns (rewritten statements, bodies dropped)."""
     dropped = []
+    wsyn = _assigned_names(prog, stmts)
+
+    def mode_switch(cond) -> bool:
+        """The condition reads nothing @sample assigns (and no audio): constant over a block -- a mode switch (`tex_loaded > 0`), not
+        a rare event. While it holds it holds in every frame, so as an event it would hand the whole block to the serial code;
+        lowered, its body runs time-parallel, and a chunk in which it does not hold skips the loops it guards (emit_loop). What
+        the lowering cannot take in such a body still becomes an event, further in (FrameGraph._or_event)."""
+        return not any(nm in wsyn or is_spl_name(nm) is not None for nm in _read_names(prog, [cond]))
 
     def rw(x, stmt: bool):
         # (what holds no event keeps its identity: FrameGraph.event_ids names statements by it, from one build of the plan to the next)
@@ -246,7 +275,7 @@ def split_events(prog: Program, stmts, keep=frozenset(), origin=None, cache=None
         if isinstance(x, (S.Cond, S.If)):
             st = stmt or isinstance(x, S.If)
             if (st and x.then is not None and (x.els is None or isinstance(x.els, S.Num)) and _pure_scalar(prog, x.cond)
-                    and _heavy(prog, x.then) and id(x) not in keep):
+                    and _heavy(prog, x.then) and id(x) not in keep and not (lower_modes and mode_switch(x.cond))):
                 dropped.append(x)
                 mark = S.Call(EVENT, [x.cond], line=x.line, col=x.col)
                 if origin is not None:
@@ -259,7 +288,7 @@ def split_events(prog: Program, stmts, keep=frozenset(), origin=None, cache=None
             return type(x)(x.cond, th, el, line=x.line, col=x.col)
         return x
 
-    key = (tuple(id(st) for st in stmts), frozenset(keep))
+    key = (tuple(id(st) for st in stmts), frozenset(keep), lower_modes)
     if cache is not None and cache.get("key") == key:
         if origin is not None:
             origin.update(cache["origin"])

@@ -112,6 +112,12 @@ class TparAbort(Exception):
 
 
 MAX_LIVE_NODES = 2400  # a frame larger than this is not lowered (kernel size: see _build_plan)
+MAX_COUPLED_STATES = 4     # states of one affine / switched recurrence (zt_scan1, zt_scan2, zt_scanN<3>, zt_scanN<4>)
+MODE_LOWERING_MAX_NODES = 1500   # ... and beyond this the bodies of block-constant conditions stay out of the frame (events)
+
+
+class _TooLarge(Unsupported):
+    pass
 ULDS_THRESHOLD = 64   # block-constant values beyond which they live in LDS rather than in (spilled) scalar registers
 SPEC_TOL = 1.0e-13    # relative change of a state between two iterations below which it counts as settled (ZT_SPEC_TOL)
 SPEC_MAX = 8          # iterations of a switched recurrence before the chunk falls back to its serial loop (ZT_SPEC_MAX)
@@ -197,10 +203,19 @@ def build_plan(prog: Program, nch: int) -> Plan:
     event_ids: set = set()
     no_event: set = set()
     why: Dict[int, str] = {}
+    why["#lower_modes"] = True
     for _round in range(24):
         try:
             plan = _build_plan(prog, nch, event_ids, no_event, why)
         except _Replan:
+            continue
+        except _TooLarge:
+            if not why["#lower_modes"]:
+                raise
+            # with the bodies of its mode switches lowered the frame is too much for one kernel: they run as events, as
+            # split_events takes every other heavy branch (a block in which one holds then goes to the serial code)
+            event_ids.clear(); no_event.clear()
+            why.clear(); why["#lower_modes"] = False
             continue
         except _Blame as bl:
             ast = next((x for x in reversed(bl.blame_ctx) if id(x) not in event_ids and id(x) not in no_event), None)
@@ -220,7 +235,8 @@ def _build_plan(prog: Program, nch: int, event_ids: set, no_event: set, why: Dic
     ev_bodies = []
     origin: Dict[int, object] = {}
     if not os.environ.get("ZA_TPAR_NO_EVENTS"):
-        stmts, ev_bodies = split_events(prog, stmts, keep=frozenset(no_event), origin=origin, cache=why.setdefault("#split", {}))
+        stmts, ev_bodies = split_events(prog, stmts, keep=frozenset(no_event), origin=origin, cache=why.setdefault("#split", {}),
+                                        lower_modes=bool(why.get("#lower_modes", True)))
     g = FrameGraph(prog, nch, stmts, event_ids, no_event)
     g.event_origin = origin
     g.reasons = why
@@ -405,7 +421,9 @@ def _build_plan(prog: Program, nch: int, event_ids: set, no_event: set, why: Dic
     if len(live) > MAX_LIVE_NODES and not os.environ.get("ZA_TPAR_ANY_SIZE"):
         # one kernel holds the whole frame: 3DPanner's 1 800 nodes are ~35 000 instructions (two minutes of device compiler,
         # branches past the 128 KB a short branch reaches), Sample's 8 750 would be several times that
-        raise Unsupported(f"the frame is too large for one kernel ({len(live)} nodes)")
+        raise _TooLarge(f"the frame is too large for one kernel ({len(live)} nodes)")
+    if len(live) > MODE_LOWERING_MAX_NODES and why.get("#lower_modes", True) and not os.environ.get("ZA_TPAR_ANY_SIZE"):
+        raise _TooLarge(f"{len(live)} nodes with the mode switches' bodies in the frame")
     loops = [L for L in g.loops if L.id in live_loops]
     loops.sort(key=lambda L: (L.depth, L.id))
     for L in loops:
@@ -970,7 +988,7 @@ def _classify(g: FrameGraph, reg: Region, c: Component, ci: int = 0, live=None):
     mem = {m.i for m in c.members}
     names = c.names
     d = len(names)
-    if d > 2:
+    if d > MAX_COUPLED_STATES:
         return
 
     def add(a: N, b: N) -> N:
@@ -1001,12 +1019,13 @@ def _classify(g: FrameGraph, reg: Region, c: Component, ci: int = 0, live=None):
         conds: List[N] = []
         gnodes: List[N] = []
 
-        def guess_for(cond: N) -> N:
+        def guess_for(cond: N, numeric: bool = False) -> N:
             for k, x in enumerate(conds):
                 if x is cond:
                     return gnodes[k]
             conds.append(cond)
-            gn = g.mk("guess", name=f"{ci}", val=len(gnodes))
+            # (op "num": the placeholder stands for the VALUE of `cond` -- floor(...) of a state -- not for its truth)
+            gn = g.mk("guess", op="num" if numeric else None, name=f"{ci}", val=len(gnodes))
             gn.loop = reg.loop
             gnodes.append(gn)
             return gn
@@ -1056,6 +1075,12 @@ def _classify(g: FrameGraph, reg: Region, c: Component, ci: int = 0, live=None):
                     a, b = aff(n.args[0]), aff(n.args[1])
                     if a and b:
                         r = pick(guess_for(g.op("<" if op == "min" else ">", n.args[0], n.args[1])), a, b)
+                elif op in ("floor", "ceil") and allow_guess:
+                    # a wrap written with floor (`ph -= floor(ph)`): piecewise constant in the states -- with its VALUE fixed per
+                    # frame the recurrence is affine; the value the scanned states imply must reproduce the guess, like a switch
+                    a = aff(n.args[0])
+                    if a:
+                        r = ({}, guess_for(n, numeric=True))
                 elif op == "fabs" and allow_guess:                # |x| = x < 0 ? -x : x
                     a = aff(n.args[0])
                     if a:

@@ -332,14 +332,18 @@ def _simulate(self: Plan, vars0: Dict[str, float], x: np.ndarray, sliders=None, 
                         loc = {reg.st[nm].i: states[r] for r, nm in enumerate(comp.names)}
                         for m in comp.slice:
                             loc[m.i] = np.broadcast_to(_np_op(m.op, [loc[a.i] if a.i in loc else V(a) for a in m.args]), (WAVE,))
-                        return [_truthy(np.broadcast_to(loc[c.i] if c.i in loc else V(c), (WAVE,))) for c in comp.conds]
+                        out_ = []
+                        for c, gn_ in zip(comp.conds, comp.gnodes):
+                            cv_ = np.broadcast_to(loc[c.i] if c.i in loc else V(c), (WAVE,))
+                            out_.append(np.array(cv_, dtype=np.float64) if gn_.op == "num" else _truthy(cv_))
+                        return out_
 
                     prev = [np.full(WAVE, carry[nm]) for nm in comp.names]
                     gs = conds_from(prev)
                     converged, iters, still = False, 0, 0
                     while iters < SPEC_MAX:
                         iters += 1
-                        loc = {gn.i: np.where(gs[k], 1.0, 0.0) for k, gn in enumerate(comp.gnodes)}
+                        loc = {gn.i: (gs[k] if gn.op == "num" else np.where(gs[k], 1.0, 0.0)) for k, gn in enumerate(comp.gnodes)}
                         for n in comp.gdep:
                             loc[n.i] = _np_op(n.op, [loc[a.i] if a.i in loc else V(a) for a in n.args])
                         gv = lambda n: np.broadcast_to(loc[n.i] if n.i in loc else V(n), (WAVE,)).astype(np.float64)
