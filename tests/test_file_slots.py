@@ -28,6 +28,15 @@ SCRIPT = [
     (11, 0, 2, 0), (11, 0, 9, 0), (11, 0, 0, 0), (11, 0, -1, 0),   # raw handle numbers
     (10, 0, 0, 0),
     (7, 1, 65530, 20),       # would run past the arena: documented deviation (skipped below)
+    # a script that never closes what it opens (TextureXY opens slot 0 in every @block): the reference's handle table just grows
+    # (:4976-4981), so handle numbers keep counting up -- 4, 5, ... 15 -- and the newest one reads like any other
+] + [(1, 2, 0, 0)] * 12 + [
+    (4, 0, 0, 0), (6, 0, 0, 0), (7, 0, 400, 10),
+    (3, 0, 0, 0),            # close handle 15 -> free list
+    (2, 3, 0, 0),            # h1 = open(slot 3) reuses 15
+    (6, 1, 0, 0),
+    (1, 2, 0, 0),            # h0 -> new handle 16
+    (4, 0, 0, 0),
 ]
 
 
@@ -87,6 +96,28 @@ def test_port_file_slots():
             return out
         return step
     _run(make)
+
+
+def test_a_handle_that_left_the_window_is_refused_loudly():
+    """The runtime keeps the state of the 8 most recent handles; the reference keeps all of them. Using an older one must not
+    answer (differently from the reference) but raise the host-only error -- after 11 opens handle 1's cell holds handle 9."""
+    from oracle import port
+    if not port.port_path("fx_filekat").exists():
+        pytest.skip("fixture port not built")
+    p = port.Port("fx_filekat", 48000.0, mem_cap=MEM_CAP)
+    it, ch, sr = _files()[2]
+    p.file_slot_set(2, it, ch, sr)
+    p.set_sliders([0, 0, 0, 0]); p.prepare()
+    z = np.zeros((1, 4), np.float32)
+    for k in range(11):
+        p.set_sliders([1, 2, 0, 0]); p.process(z, 4)
+        assert p.var("ret") == k + 1
+    p.set_sliders([11, 0, 11, 0]); p.process(z, 4)           # the newest: fine
+    assert p.var("ret") == 300 and p.err == 0
+    p.set_sliders([11, 0, 4, 0]); p.process(z, 4)            # inside the window: fine
+    assert p.var("ret") == 300 and p.err == 0
+    p.set_sliders([11, 0, 1, 0]); p.process(z, 4)            # left the window
+    assert p.err & 4
 
 
 def test_port_midi_without_ports():

@@ -138,6 +138,33 @@ struct ZfClickBeGone {
     st[S_BASE] = base;
     return base;
   }
+  // Recursion 1 over a whole 64-frame chunk, software-pipelined by hand (round 4): its three recurrences -- the HPF pair, the
+  // envelope, the baseline -- each close over TWO dependent operations per frame, and written frame by frame they form one chain of
+  // five dependent VALU operations whose latency (SQ counters: the serial wave issues 35 % of its cycles) is what a frame costs.
+  // Here iteration n runs the HPFs of frame n, the envelope of frame n - 1 and the baseline of frame n - 2: three independent
+  // instruction streams side by side. Same IEEE operations on the same operands as detect_scaled(), frame for frame.
+  ZF_FN static void detect_chunk64(float* st, const Ctl& c, const float* vL, const float* vR, float* env_base_out) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 a2 = {c.a, c.a};
+    f2 hp = {st[S_HPL], st[S_HPR]};
+    float env = st[S_ENV], base = st[S_BASE];
+#pragma unroll
+    for (int n = 0; n < 64 + 2; ++n) {
+      if (n >= 2) {                                             // baseline of frame n - 2 (env still holds that frame's envelope)
+        base = env * c.base_a + base * c.one_m_base_a;
+        env_base_out[2 * (n - 2) + 1] = base;
+      }
+      if (n >= 1 && n <= 64) {                                  // envelope of frame n - 1 (hp still holds that frame's HPF outputs)
+        env = __builtin_fmaxf(__builtin_fmaxf(env * c.env_rel, fabsf(hp.x)), fabsf(hp.y));
+        env_base_out[2 * (n - 1)] = env;
+      }
+      if (n < 64) {                                             // HPFs of frame n
+        const f2 v = {vL[n], vR[n]};
+        hp = v + a2 * hp;
+      }
+    }
+    st[S_HPL] = hp.x; st[S_HPR] = hp.y; st[S_ENV] = env; st[S_BASE] = base;
+  }
   ZF_FN static float trigger(const Ctl& c, float env, float base, float e_norm) {                // :77,95 (feed-forward)
     const float ratio = env / (base + 1e-12f);
     return (float)((int)(ratio > c.ratio_thr) * (int)(e_norm > c.err_thr));

@@ -27,9 +27,10 @@ __global__ void __launch_bounds__(256) zf_cbg_wave_quad(ZabBatch b, ZabAudio a) 
   constexpr int G = 4;
   constexpr int RP = 68;      // rows one lane walks: 16-byte aligned (four frames per LDS instruction), lanes 0..3 land on banks 0, 4, 8, 12
   __shared__ float xs[G][2][96];                                      // [0..31]: the previous chunk's last 32 frames, [32..95]: this chunk
-  __shared__ __attribute__((aligned(16))) float us[2][G][2][RP];      // B -> S: HPF input, already scaled
+  constexpr int RP2 = 2 * 64 + 4;                                      // rows of (left, right) / (env, base) PAIRS, same alignment and banks
+  __shared__ __attribute__((aligned(16))) float us[2][G][RP2];        // B -> S: HPF input of both channels, already scaled, frame-major
   __shared__ float pp[3][G][5][64];                                   // B -> D / F: Pred fields per frame
-  __shared__ __attribute__((aligned(16))) float eb[2][G][2][RP];      // S -> D: env, base per frame
+  __shared__ __attribute__((aligned(16))) float eb[2][G][RP2];        // S -> D: (env, base) per frame
   __shared__ __attribute__((aligned(16))) float th[G][RP];            // D -> E -> F (wave 1 only): trigger, then hold
   __shared__ L::Ctl ctls[G];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -82,7 +83,14 @@ __global__ void __launch_bounds__(256) zf_cbg_wave_quad(ZabBatch b, ZabAudio a) 
   if (wave >= 2) fetch(0);
   __syncthreads();
 
+#ifdef ZF_QUAD_CLOCKS          // role clock (tools/cbg_quad_clocks.py): cycles each wavefront works per launch, of the launch's cycles
+  uint64_t zc_busy = 0;
+  const uint64_t zc_start = __builtin_readcyclecounter();
+#endif
   for (int64_t tick = 0; tick < nchunks + 2; ++tick) {
+#ifdef ZF_QUAD_CLOCKS
+    const uint64_t zc_t0 = __builtin_readcyclecounter();
+#endif
     if (wave >= 2) {
       // ---- B(tick): feed-forward front, lane = frame ------------------------------------------------------------------------
       const int64_t k = tick;
@@ -105,8 +113,8 @@ __global__ void __launch_bounds__(256) zf_cbg_wave_quad(ZabBatch b, ZabAudio a) 
           const L::Pred q = L::predict(c, aL, aR);
           pp[pb][g][0][lane] = q.xC_L; pp[pb][g][1][lane] = q.xC_R; pp[pb][g][2][lane] = q.pred_L; pp[pb][g][3][lane] = q.pred_R;
           pp[pb][g][4][lane] = q.e_norm;
-          us[ub][g][0][lane] = c.a * (aL(0) - aL(1));
-          us[ub][g][1][lane] = c.a * (aR(0) - aR(1));
+          us[ub][g][2 * lane] = c.a * (aL(0) - aL(1));
+          us[ub][g][2 * lane + 1] = c.a * (aR(0) - aR(1));
           // frames tn-32 .. tn-1 of the extended row become the next chunk's (or the next launch's) history
           float keepL = 0.f, keepR = 0.f;
           if (lane < 32) { keepL = xs[g][0][tn + lane]; keepR = xs[g][1][tn + lane]; }
@@ -124,18 +132,13 @@ __global__ void __launch_bounds__(256) zf_cbg_wave_quad(ZabBatch b, ZabAudio a) 
         if (tn == 64) {                                               // full chunk: straight-line code, LDS reads up front
           float ul[64], ur[64];
 #pragma unroll
-          for (int n = 0; n < 64; ++n) { ul[n] = us[ub][lane][0][n]; ur[n] = us[ub][lane][1][n]; }
-#pragma unroll
-          for (int n = 0; n < 64; ++n) {
-            float env, base;
-            L::detect_scaled(st, myc, ul[n], ur[n], env, base);
-            eb[ub][lane][0][n] = env; eb[ub][lane][1][n] = base;
-          }
+          for (int n = 0; n < 64; ++n) { ul[n] = us[ub][lane][2 * n]; ur[n] = us[ub][lane][2 * n + 1]; }
+          L::detect_chunk64(st, myc, ul, ur, &eb[ub][lane][0]);
         } else {
           for (int n = 0; n < tn; ++n) {
             float env, base;
-            L::detect_scaled(st, myc, us[ub][lane][0][n], us[ub][lane][1][n], env, base);
-            eb[ub][lane][0][n] = env; eb[ub][lane][1][n] = base;
+            L::detect_scaled(st, myc, us[ub][lane][2 * n], us[ub][lane][2 * n + 1], env, base);
+            eb[ub][lane][2 * n] = env; eb[ub][lane][2 * n + 1] = base;
           }
         }
       }
@@ -146,7 +149,7 @@ __global__ void __launch_bounds__(256) zf_cbg_wave_quad(ZabBatch b, ZabAudio a) 
         const int64_t t0 = k * 64;
         const int tn = (int)((frames - t0 < 64) ? (frames - t0) : 64);
         const int ub = (int)(k & 1), pb = (int)(k % 3);
-        for (int g = 0; g < ng; ++g) th[g][lane] = L::trigger(ctls[g], eb[ub][g][0][lane], eb[ub][g][1][lane], pp[pb][g][4][lane]);
+        for (int g = 0; g < ng; ++g) th[g][lane] = L::trigger(ctls[g], eb[ub][g][2 * lane], eb[ub][g][2 * lane + 1], pp[pb][g][4][lane]);
         zf_wave_sync();
         if (lane < ng) {
           if (tn == 64) {
@@ -173,8 +176,16 @@ __global__ void __launch_bounds__(256) zf_cbg_wave_quad(ZabBatch b, ZabAudio a) 
         zf_wave_sync();
       }
     }
+#ifdef ZF_QUAD_CLOCKS
+    zc_busy += __builtin_readcyclecounter() - zc_t0;
+#endif
     zf_quad_barrier();
   }
+#ifdef ZF_QUAD_CLOCKS
+  if (blockIdx.x == 5 && lane == 0)
+    printf("zf_cbg_wave_quad role %d: busy %llu of %llu cycles over %lld ticks\n", wave, (unsigned long long)zc_busy,
+           (unsigned long long)(__builtin_readcyclecounter() - zc_start), (long long)(nchunks + 2));
+#endif
 
   // ---- launch epilogue ----------------------------------------------------------------------------------------------------------
   if (wave == 0 && lane < ng) {

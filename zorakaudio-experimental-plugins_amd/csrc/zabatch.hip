@@ -92,7 +92,7 @@ __global__ void zab_k_fill(T* base, int64_t se, int64_t n, T v) {
 // mirrors ZaFileSlot / ZaFileView of csrc/zart_file.h (the runtime does not include the device headers)
 struct ZabFileSlotDev { const double* items; int64_t n_items; int32_t channels; int32_t assigned; double srate; };
 struct ZabFileViewDev { ZabFileSlotDev slot[16]; };
-enum { kFileHandleWords = 26 };
+enum { kFileHandleWords = 34 };      // ZA_FH_WORDS (csrc/zart_file.h)
 // mirrors ZaMsg / ZaBusView of csrc/zart_msg.h
 struct ZabMsgDev { uint64_t seq, chan, src, target; double tag, a, b, c, d; uint32_t kind, pad, blen, pad2; };
 struct ZabBusViewDev {

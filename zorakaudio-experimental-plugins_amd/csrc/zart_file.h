@@ -3,7 +3,12 @@
 // Restates the reference's runtime file handles (src/JSFXJuceProcessor.cpp:4893-5215): a plugin declares file slots, the
 // host decodes whatever the user assigned to a slot into a flat array of doubles ("items": interleaved audio samples),
 // and the script reads it through handles:
-//   file_open(slot)        -1 if the slot is unassigned, else a 1-based handle from a LIFO free list ........ :4948-4990
+//   file_open(slot)        -1 if the slot is unassigned, else a 1-based handle from a LIFO free list, else a NEW one: the
+//                          reference's handle table grows without bound (:4976-4981), and leaves lean on that -- TextureXY
+//                          opens slot 0 in every @block and never closes it. Handle numbers therefore grow the same way
+//                          here; the state of the ZA_FILE_HANDLES most recent ones is kept (a window: handle k lives in cell
+//                          k % 8 under its tag), and USING a handle that has left the window raises ZA_ERR_UNSUPPORTED
+//                          instead of answering differently from the reference ................................ :4948-4990
 //   file_close / file_rewind / file_seek(offset: trunc(x + 1e-5), clamped to [0, items]) .................... :5002-5054
 //   file_avail             remaining items ......................................................... :5056-5072
 //   file_riff(h, nch, sr)  1 and (channels, sample rate) for audio data, else 0 and zeros ............. :5087-5105
@@ -19,9 +24,9 @@
 
 #define ZA_FILE_SLOTS 16
 #define ZA_FILE_HANDLES 8
-// per-instance handle state, int64 words: [k] = slot + 1 of handle k (0: closed), [8 + k] = cursor,
-// [16] = handles ever created, [17] = free count, [18 + j] = free stack
-#define ZA_FH_WORDS 26
+// per-instance handle state, int64 words: cell c = k % 8 of handle k: [c] = slot + 1 (0: closed), [8 + c] = cursor,
+// [26 + c] = k (the tag); [16] = handles ever created, [17] = free count, [18 + j] = free stack (handle indices)
+#define ZA_FH_WORDS 34
 
 struct ZaFileSlot {
   const double* items;
@@ -38,7 +43,8 @@ template <class S> ZA_FN int za_file_h(S& s, double handle) {             // get
   if (!s.fh) return -1;
   const int64_t hid = za_f2i64(handle + 1.0e-5);
   if (hid <= 0 || hid > ZA_FH(16)) return -1;
-  const int k = (int)(hid - 1);
+  const int k = (int)((hid - 1) % ZA_FILE_HANDLES);
+  if (ZA_FH(26 + k) != hid - 1) { s.err |= ZA_ERR_UNSUPPORTED; return -1; }   // left the window (still valid in the reference)
   return ZA_FH(k) > 0 ? k : -1;
 }
 template <class S> ZA_FN const ZaFileSlot* za_file_data(S& s, int k) {     // the handle's slot if it holds data
@@ -52,19 +58,21 @@ template <class S> ZA_NOINLINE double za_file_open_o(S& s, double indexOrSlot, d
   if (!s.files || !s.fh) return -1.0;
   const int64_t sl = za_f2i64(indexOrSlot + 1.0e-5);
   if (sl < 0 || sl >= ZA_FILE_SLOTS || !s.files->slot[sl].assigned) return -1.0;
-  int k;
-  if (ZA_FH(17) > 0) {                       // LIFO free list
-    const int64_t nf = ZA_FH(17) - 1;
-    k = (int)ZA_FH(18 + nf);
+  int64_t hx;                                 // 0-based handle index
+  if (ZA_FH(17) > 0) {                       // LIFO free list (a closed handle was inside the window when it closed, and new
+    const int64_t nf = ZA_FH(17) - 1;        //  indices are only made while this list is empty: its cell is still its own)
+    hx = ZA_FH(18 + nf);
     ZA_FH(17) = nf;
   } else {
-    if (ZA_FH(16) >= ZA_FILE_HANDLES) { s.err |= ZA_ERR_UNSUPPORTED; return -1.0; }   // more open handles than provisioned
-    k = (int)ZA_FH(16);
-    ZA_FH(16) = k + 1;
+    hx = ZA_FH(16);
+    if (hx >= (int64_t)1 << 52) { s.err |= ZA_ERR_UNSUPPORTED; return -1.0; }
+    ZA_FH(16) = hx + 1;
   }
+  const int k = (int)(hx % ZA_FILE_HANDLES);
   ZA_FH(k) = sl + 1;
   ZA_FH(8 + k) = 0;
-  return (double)(k + 1);
+  ZA_FH(26 + k) = hx;
+  return (double)(hx + 1);
 }
 template <class S> ZA_FN double za_file_open(S& s, double indexOrSlot, double mode) { ZA_OUTCALL(za_file_open_o(e, indexOrSlot, mode)); }
 template <class S> ZA_FN double za_file_open_multi(S& s, double a, double b) { return za_file_open(s, a, b); }
@@ -72,8 +80,8 @@ template <class S> ZA_NOINLINE double za_file_close_o(S& s, double handle) {
   const int k = za_file_h(s, handle);
   if (k < 0) return 0.0;
   ZA_FH(k) = 0; ZA_FH(8 + k) = 0;
-  const int64_t nf = ZA_FH(17);
-  ZA_FH(18 + nf) = k;
+  const int64_t nf = ZA_FH(17);              // (at most ZA_FILE_HANDLES handles are inside the window, so are closable)
+  ZA_FH(18 + nf) = ZA_FH(26 + k);
   ZA_FH(17) = nf + 1;
   return 0.0;
 }

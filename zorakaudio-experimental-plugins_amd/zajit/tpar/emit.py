@@ -970,13 +970,40 @@ class _Emit:
         L.append("    }")
 
     # -- one region's schedule ----------------------------------------------------------------------------------------------------
-    def serial_loop(self, reg: Region, comps: List[Component], ind: str):
-        """64 uniform steps; leaves the state before each frame in k<st> of that frame's lane."""
+    def serial_loop(self, reg: Region, comps: List[Component], ind: str, rest_test: bool = False):
+        """64 uniform steps; leaves the state before each frame in k<st> of that frame's lane.
+        rest_test: first ask, frame-parallel, whether ANY frame of the chunk would move a state that sits at its carried value.
+        If none does, the states keep those values through the whole chunk (induction over the frames: frame 0 sees the carried
+        values and leaves them, so frame 1 sees them too, ...) and the 64 steps are skipped -- an idle voice of a voice loop, a
+        smoother that has arrived. Bit patterns are compared, so -0 / +0 and NaN count as moves."""
         L, ref = self.L, self.ref
         for c in comps:
             for nm in c.names:
                 s = reg.st[nm].i
                 L.append(f"{ind}double y{s} = {self.carry(reg, nm)}, k{s} = {self.carry(reg, nm)};")
+        if rest_test and not os.environ.get("ZA_TPAR_NO_REST_TEST"):
+            tag = reg.st[comps[0].names[0]].i
+            L.append(f"{ind}bool zrest{tag};")
+            L.append(f"{ind}{{")
+            moves = []
+            for c in comps:
+                mem = {m.i for m in c.members}
+
+                def pref(x: N, mem=mem) -> str:
+                    if x.kind in ("st", "lcin") and x.i in mem:
+                        return f"y{x.i}"
+                    if x.i in mem:
+                        return f"u{x.i}"
+                    return ref(x)
+
+                for m in c.members:
+                    if m.kind not in ("st", "lcin"):
+                        L.append(f"{ind}  const double u{m.i} = {_expr(m.op, [pref(x) for x in m.args])};")
+                for nm in c.names:
+                    moves.append(f"__double_as_longlong({pref(reg.outs[nm])}) != __double_as_longlong(y{reg.st[nm].i})")
+            L.append(f"{ind}  zrest{tag} = __ballot(valid && ({' || '.join(moves)})) == 0ull;")
+            L.append(f"{ind}}}")
+            L.append(f"{ind}if (!zrest{tag})")
         L.append(f"{ind}for (int t = 0; t < tn; ++t) {{")
         L.append(f"{ind}  const bool me = lane == t;")
         seen_ext = set()
@@ -1302,7 +1329,7 @@ class _Emit:
                 L.append(f"{ind}// serial recurrences sharing one loop: {', '.join(names)}")
                 if top:
                     L.append(f"{ind}ZT_STAMP(2)")
-                self.serial_loop(reg, it[1], ind)
+                self.serial_loop(reg, it[1], ind, rest_test=True)
                 if top:
                     L.append(f"{ind}ZT_STAMP(3)")
                 for nm in names:
