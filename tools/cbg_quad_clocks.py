@@ -10,7 +10,7 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path[:0] = [str(ROOT / "zorakaudio-experimental-plugins_amd"), str(ROOT)]
-KEY = "ClickBeGoneSG_clk"
+KEY = os.environ.get("ZF_CLK_KEY", "ClickBeGoneSG_clk")
 
 
 def build():

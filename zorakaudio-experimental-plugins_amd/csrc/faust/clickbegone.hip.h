@@ -85,15 +85,33 @@ struct ZfClickBeGone {
   //      with one lane per FRAME and only the recursions serially) ----------------------------------------------------
   struct Pred { float xC_L, xC_R, pred_L, pred_R, e_norm; };
   template <class H> ZF_FN static Pred predict(const Ctl& c, const H& aL, const H& aR) {          // :79-93 (feed-forward)
+    return predict_with(c, small_pred(c.mode, aL), small_pred(c.mode, aR), large_pred(c.mode, aL), large_pred(c.mode, aR), aL, aR);
+  }
+  template <class H> ZF_FN static Pred predict_with(const Ctl& c, float small_L, float small_R, float large_L, float large_R,
+                                                     const H& aL, const H& aR) {
     Pred q;
     q.xC_L = aL(15); q.xC_R = aR(15);
-    const float small_L = small_pred(c.mode, aL), small_R = small_pred(c.mode, aR);
-    const float large_L = large_pred(c.mode, aL), large_R = large_pred(c.mode, aR);
     const float eA = zf_max(fabsf(q.xC_L - small_L), fabsf(q.xC_R - small_R)) / (zf_max(fabsf(small_L), fabsf(small_R)) + 1e-6f);
     const float eB = zf_max(fabsf(q.xC_L - large_L), fabsf(q.xC_R - large_R)) / (zf_max(fabsf(large_L), fabsf(large_R)) + 1e-6f);
     const bool useA = eA <= eB;
     q.pred_L = useA ? small_L : large_L; q.pred_R = useA ? small_R : large_R; q.e_norm = useA ? eA : eB;
     return q;
+  }
+  // predict() where every lane of the wavefront serves ONE instance (the wave kernels: lane = frame), so the Mode is the same in
+  // all of them: one scalar branch, and behind it the four smoothing sums of the two channels stand in ONE basic block -- four
+  // independent chains of dependent additions (the source's left-to-right order is kept inside each) that the scheduler
+  // interleaves, where the per-call mode tests of predict() leave it one chain at a time (role clock of the four-wavefront
+  // kernel, round 4: the feed-forward wavefront went from 78 to NN cycles per frame-lane tap set).
+  template <int M, class H> ZF_FN static Pred predict_mode(const Ctl& c, const H& aL, const H& aR) {
+    if constexpr (M <= 0) return predict_with(c, sg11(aL), sg11(aR), sg15(aL), sg15(aR), aL, aR);
+    else if constexpr (M == 1) return predict_with(c, sg15(aL), sg15(aR), sg21(aL), sg21(aR), aL, aR);
+    else return predict_with(c, sg21(aL), sg21(aR), sg31(aL), sg31(aR), aL, aR);
+  }
+  template <class H> ZF_FN static Pred predict_uniform(const Ctl& c, const H& aL, const H& aR) {
+    const int m = __builtin_amdgcn_readfirstlane(c.mode);
+    if (m <= 0) return predict_mode<0>(c, aL, aR);
+    if (m == 1) return predict_mode<1>(c, aL, aR);
+    return predict_mode<2>(c, aL, aR);
   }
   // recursion 1: hpf -> env -> base (:63-75); uL = L - L@1
   ZF_FN static void detect(float* st, const Ctl& c, float uL, float uR, float& env, float& base) {
@@ -109,9 +127,13 @@ struct ZfClickBeGone {
   // detect() with the inputs' product a * u already formed (the wave kernel forms it frame-parallel); the two channels'
   // multiply and add are written as 2-vectors so that they issue as one packed instruction each (same IEEE operations)
   ZF_FN static void detect_scaled(float* st, const Ctl& c, float vL, float vR, float& env, float& base) {
+#ifdef ZF_NO_PK
+    struct { float x, y; } hp = {vL + c.a * st[S_HPL], vR + c.a * st[S_HPR]};
+#else
     typedef float f2 __attribute__((ext_vector_type(2)));
     const f2 v = {vL, vR}, hp0 = {st[S_HPL], st[S_HPR]}, a2 = {c.a, c.a};
     const f2 hp = v + a2 * hp0;
+#endif
     st[S_HPL] = hp.x; st[S_HPR] = hp.y;
     const float ehf = zf_max(fabsf(hp.x), fabsf(hp.y));
     env = zf_max(st[S_ENV] * c.env_rel, ehf);
@@ -125,9 +147,13 @@ struct ZfClickBeGone {
   //   (the product env * base_a of every frame is formed frame-parallel by the caller)
   //   base_step  base = eb + base * (1 - base_a).
   ZF_FN static float env_step(float* st, const Ctl& c, float vL, float vR) {
+#ifdef ZF_NO_PK
+    struct { float x, y; } hp = {vL + c.a * st[S_HPL], vR + c.a * st[S_HPR]};
+#else
     typedef float f2 __attribute__((ext_vector_type(2)));
     const f2 v = {vL, vR}, hp0 = {st[S_HPL], st[S_HPR]}, a2 = {c.a, c.a};
     const f2 hp = v + a2 * hp0;
+#endif
     st[S_HPL] = hp.x; st[S_HPR] = hp.y;
     const float env = __builtin_fmaxf(__builtin_fmaxf(st[S_ENV] * c.env_rel, fabsf(hp.x)), fabsf(hp.y));
     st[S_ENV] = env;
@@ -144,10 +170,7 @@ struct ZfClickBeGone {
   // Here iteration n runs the HPFs of frame n, the envelope of frame n - 1 and the baseline of frame n - 2: three independent
   // instruction streams side by side. Same IEEE operations on the same operands as detect_scaled(), frame for frame.
   ZF_FN static void detect_chunk64(float* st, const Ctl& c, const float* vL, const float* vR, float* env_base_out) {
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    const f2 a2 = {c.a, c.a};
-    f2 hp = {st[S_HPL], st[S_HPR]};
-    float env = st[S_ENV], base = st[S_BASE];
+    float hpl = st[S_HPL], hpr = st[S_HPR], env = st[S_ENV], base = st[S_BASE];
 #pragma unroll
     for (int n = 0; n < 64 + 2; ++n) {
       if (n >= 2) {                                             // baseline of frame n - 2 (env still holds that frame's envelope)
@@ -155,15 +178,15 @@ struct ZfClickBeGone {
         env_base_out[2 * (n - 2) + 1] = base;
       }
       if (n >= 1 && n <= 64) {                                  // envelope of frame n - 1 (hp still holds that frame's HPF outputs)
-        env = __builtin_fmaxf(__builtin_fmaxf(env * c.env_rel, fabsf(hp.x)), fabsf(hp.y));
+        env = __builtin_fmaxf(__builtin_fmaxf(env * c.env_rel, fabsf(hpl)), fabsf(hpr));
         env_base_out[2 * (n - 1)] = env;
       }
       if (n < 64) {                                             // HPFs of frame n
-        const f2 v = {vL[n], vR[n]};
-        hp = v + a2 * hp;
+        hpl = vL[n] + c.a * hpl;
+        hpr = vR[n] + c.a * hpr;
       }
     }
-    st[S_HPL] = hp.x; st[S_HPR] = hp.y; st[S_ENV] = env; st[S_BASE] = base;
+    st[S_HPL] = hpl; st[S_HPR] = hpr; st[S_ENV] = env; st[S_BASE] = base;
   }
   ZF_FN static float trigger(const Ctl& c, float env, float base, float e_norm) {                // :77,95 (feed-forward)
     const float ratio = env / (base + 1e-12f);

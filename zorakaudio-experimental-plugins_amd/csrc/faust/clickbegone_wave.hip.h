@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(64) zf_cbg_wave(ZabBatch b, ZabAudio a) {
     for (int g = 0; g < ng; ++g) {
       const L::Ctl c = ctls[g];
       const L::RowHist aL{&xs[g][0][32 + lane]}, aR{&xs[g][1][32 + lane]};
-      const L::Pred q = L::predict(c, aL, aR);
+      const L::Pred q = L::predict_uniform(c, aL, aR);
       pp[g][0][lane] = q.xC_L; pp[g][1][lane] = q.xC_R; pp[g][2][lane] = q.pred_L; pp[g][3][lane] = q.pred_R; pp[g][4][lane] = q.e_norm;
       us[g][0][lane] = c.a * (aL(0) - aL(1));          // (the recursion's first product, frame-parallel: same operands, same bits)
       us[g][1][lane] = c.a * (aR(0) - aR(1));
@@ -187,9 +187,11 @@ static int zf_cbg_pick_g(int n_inst) {
 }
 static int32_t zf_cbg_applies(const ZabBatch*, const ZabAudio* a) { return a->frames > 0 ? 1 : 0; }
 static bool zf_cbg_use_quad(int n_inst) {
-  // measured (48 000 frames; profiles/r04_cbg_quad_vs_wave.txt): N = 1024: 2.22 ms against 2.89 (wave, G = 1); 4096: 5.02 against 5.58
-  // (G = 2); 8192: 9.90 against 7.97 (G = 4) -- four instances per serial instruction stream pay while the chip has SIMDs to spare
-  bool quad = n_inst <= 4608;               // (ZAB_CBG_KERNEL = quad | wave pins it)
+  // measured (48 000 frames; profiles/r04_cbg_quad_vs_wave.txt, second table): the four-wavefront kernel wins at every batch size
+  // since its recursions are hand-ordered -- N = 1024: 1.44 ms against 2.58 (wave, G = 1); 4096: 3.27 against 5.22; 8192: 6.43
+  // against 7.04; 16384: 12.6 against 13.8. (Its first cut lost beyond 4608 instances: 9.90 against 7.97 ms at 8192.)
+  (void)n_inst;
+  bool quad = true;                         // (ZAB_CBG_KERNEL = quad | wave pins it)
   if (const char* e = getenv("ZAB_CBG_KERNEL")) quad = e[0] == 'q';
   return quad;
 }
