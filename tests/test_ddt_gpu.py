@@ -14,7 +14,9 @@ DDT_CASES = ["DDT_default", "DDT_far_extreme", "DDT_near_eco_direct", "DDT_diffu
 # the fast kernels run NW wavefronts per instance (picked from the batch size); ZAB_DDT_NW pins it so every variant is covered.
 # fastN: zab_ddt_fast (filtered rings, long launches); wideN[p|d]: zab_ddt_wide, the single-history-ring kernel that takes
 # short launches and delays too long for two rings (ZAB_DDT_KERNEL pins either; p / d pin wide's ring addressing mode)
-FAST_VARIANTS = ["fast1", "fast2", "fast4", "fast8", "wide1", "wide2", "wide8", "wide1p", "wide2p", "wide1d"]
+# fastNw: the same kernel compiled for three waves per SIMD (168 registers, single-buffered taps; ZAB_DDT_MINW pins it -- unpinned
+# it takes launches of >= 160 000 frames on batches of >= 1024 instances)
+FAST_VARIANTS = ["fast1", "fast2", "fast4", "fast8", "fast2w", "fast4w", "fast8w", "wide1", "wide2", "wide8", "wide1p", "wide2p", "wide1d"]
 
 
 @pytest.fixture(autouse=True)
@@ -22,6 +24,7 @@ def _unpin_nw(monkeypatch):
     monkeypatch.delenv("ZAB_DDT_NW", raising=False)
     monkeypatch.delenv("ZAB_DDT_RING", raising=False)
     monkeypatch.delenv("ZAB_DDT_KERNEL", raising=False)
+    monkeypatch.delenv("ZAB_DDT_MINW", raising=False)
 
 
 def _paths(zabatch, monkeypatch):
@@ -31,7 +34,8 @@ def _paths(zabatch, monkeypatch):
             monkeypatch.setenv("ZAB_DDT_NW", name[4])
             monkeypatch.delenv("ZAB_DDT_RING", raising=False)
             monkeypatch.setenv("ZAB_DDT_KERNEL", name[:4])          # (unpinned, the launch length picks the kernel)
-            if name[5:]:          # power-of-two ring with masked offsets / doubled ring without wrap
+            monkeypatch.setenv("ZAB_DDT_MINW", "3" if name[5:] == "w" else "2")
+            if name[5:] in ("p", "d"):          # power-of-two ring with masked offsets / doubled ring without wrap
                 monkeypatch.setenv("ZAB_DDT_RING", {"p": "pow2", "d": "dbl"}[name[5:]])
             return zabatch.ZAB_PATH_FAST
         return zabatch.ZAB_PATH_GENERIC

@@ -30,9 +30,6 @@
 
 #define D2_KF 4
 #define D2_CH (64 * D2_KF)
-#ifndef D2_MINW
-#define D2_MINW 2                      /* waves per SIMD the register allocation must allow */
-#endif
 
 typedef float d2_f4 __attribute__((ext_vector_type(4)));   // a float4 the register allocator keeps as ONE 128-bit tuple
 
@@ -220,9 +217,35 @@ __device__ __forceinline__ void d2_tap_acc(const D2TapS& tp, double (&l)[D2_KF],
     acc[1][k] = __builtin_fma(tp.gR, r[k], acc[1][k]);
   }
 }
-// taps [i0, i1) of the staged list; the reads of a tap are issued one tap ahead of their FMAs
+// taps [i0, i1) of the staged list
+// MW = 2: the reads of a tap are issued one tap ahead of their FMAs (two sets of tap values: 64 registers).
+// MW = 3 (three waves per SIMD, 168 registers): ONE set of tap values; what a tap waits for its reads is filled with the next
+// tap's address arithmetic (two v_readlane, two adds) and its own gains' four v_readlane, the rest is the other two waves'.
+template <int MW>
 __device__ __forceinline__ void d2_tap_run(const D2TapRegs& R, int lane8, int i0, int i1, double (&acc)[2][D2_KF]) {
   if (i0 >= i1) return;
+  if constexpr (MW >= 3) {
+    const int last = i1 - 1;
+    unsigned pl = (unsigned)(__builtin_amdgcn_readlane(R.aL, i0) + lane8), pr = (unsigned)(__builtin_amdgcn_readlane(R.aR, i0) + lane8);
+    for (int i = i0; i < i1; ++i) {
+      double l[D2_KF], r[D2_KF];
+#pragma unroll
+      for (int k = 0; k < D2_KF; ++k) {
+        l[k] = *(d2_lds_cvd)(uintptr_t)(pl + 512u * k);
+        r[k] = *(d2_lds_cvd)(uintptr_t)(pr + 512u * k);
+      }
+      D2TapS tp;
+      tp.gL = ddt_readlane(R.gL, i);
+      tp.gR = ddt_readlane(R.gR, i);
+      const int nx = i < last ? i + 1 : last;
+      pl = (unsigned)(__builtin_amdgcn_readlane(R.aL, nx) + lane8);
+      pr = (unsigned)(__builtin_amdgcn_readlane(R.aR, nx) + lane8);
+      __builtin_amdgcn_sched_barrier(0);
+      d2_tap_acc(tp, l, r, acc);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    return;
+  }
   const int last = i1 - 1;
   double al[D2_KF], ar[D2_KF], bl[D2_KF], br[D2_KF];
   D2TapS ta = d2_tap_get(R, i0), tb;
@@ -247,7 +270,7 @@ __device__ __forceinline__ void d2_tap_run(const D2TapRegs& R, int lane8, int i0
 
 // lane = frames {f0 + l, f0 + 64 + l, ...}. METERS: early and late sums kept apart, meters fed (:510-536).
 // corr: the a^(n+1) K terms still matter for this chunk (wave-uniform).
-template <bool PARTIAL, bool METERS>
+template <bool PARTIAL, bool METERS, int MW>
 __device__ __forceinline__ void d2_tap_phase(const D2Ctx& C, const D2TapRegs& R, int lane, int64_t f0, bool corr,
                                              double (&accM)[6], double& accC, double wM, double wC, bool want_last,
                                              float (&o0)[D2_KF], float (&o1)[D2_KF] DDT_STAMP_ARGS) {
@@ -271,10 +294,10 @@ __device__ __forceinline__ void d2_tap_phase(const D2Ctx& C, const D2TapRegs& R,
     }
   }
   if (METERS) {
-    d2_tap_run(R, lane8, 0, C.nE, sA);
-    d2_tap_run(R, lane8, C.nE, C.nT, sB);
+    d2_tap_run<MW>(R, lane8, 0, C.nE, sA);
+    d2_tap_run<MW>(R, lane8, C.nE, C.nT, sB);
   } else {
-    d2_tap_run(R, lane8, 0, C.nT, sA);                     // early and late taps into one sum
+    d2_tap_run<MW>(R, lane8, 0, C.nT, sA);                     // early and late taps into one sum
   }
   DDT_STAMP(5)
 
@@ -325,7 +348,7 @@ __device__ __forceinline__ void d2_tap_phase(const D2Ctx& C, const D2TapRegs& R,
   }
 }
 
-template <int NW>
+template <int NW, int MW>
 __device__ __forceinline__ void d2_body(const ZabBatch& b, const ZabAudio& a, int W, int nh) {
   extern __shared__ __attribute__((aligned(16))) double ddt_lds[];
   double* ringE = ddt_lds;                                 // [W + CH]
@@ -578,8 +601,8 @@ __device__ __forceinline__ void d2_body(const ZabBatch& b, const ZabAudio& a, in
       }
       if (active) {
         const bool corr = f0 < corr_until;
-        if (part) d2_tap_phase<true, MET>(C, R, lane, f0, corr, accM, accC, wM, wC, want_last, o0, o1 DDT_STAMP_PASS);
-        else d2_tap_phase<false, MET>(C, R, lane, f0, corr, accM, accC, wM, wC, want_last, o0, o1 DDT_STAMP_PASS);
+        if (part) d2_tap_phase<true, MET, MW>(C, R, lane, f0, corr, accM, accC, wM, wC, want_last, o0, o1 DDT_STAMP_PASS);
+        else d2_tap_phase<false, MET, MW>(C, R, lane, f0, corr, accM, accC, wM, wC, want_last, o0, o1 DDT_STAMP_PASS);
         my_last_chunk = c;
       }
     }
@@ -730,14 +753,18 @@ __device__ __forceinline__ void d2_body(const ZabBatch& b, const ZabAudio& a, in
 #undef D2_PF_WAIT
 
 // _nwK: K wavefronts per instance; W = ring length (frames), nh = history chunks filtered before the launch's first chunk
-#define D2_KERNEL(name, NW)                                                                                     \
-  extern "C" __global__ void __launch_bounds__(64 * NW, D2_MINW) name(ZabBatch b, ZabAudio a, int W, int nh) { \
-    d2_body<NW>(b, a, W, nh);                                                                                   \
+#define D2_KERNEL(name, NW, MW)                                                                             \
+  extern "C" __global__ void __launch_bounds__(64 * NW, MW) name(ZabBatch b, ZabAudio a, int W, int nh) {      \
+    d2_body<NW, MW>(b, a, W, nh);                                                                               \
   }
-D2_KERNEL(zab_ddt_fast, 1)
-D2_KERNEL(zab_ddt_fast_nw2, 2)
-D2_KERNEL(zab_ddt_fast_nw4, 4)
-D2_KERNEL(zab_ddt_fast_nw8, 8)
+D2_KERNEL(zab_ddt_fast, 1, 2)
+D2_KERNEL(zab_ddt_fast_nw2, 2, 2)
+D2_KERNEL(zab_ddt_fast_nw4, 4, 2)
+D2_KERNEL(zab_ddt_fast_nw8, 8, 2)
+// ..w3: register allocation for three waves per SIMD (168), single-buffered taps (d2_tap_run)
+D2_KERNEL(zab_ddt_fast_nw2w3, 2, 3)
+D2_KERNEL(zab_ddt_fast_nw4w3, 4, 3)
+D2_KERNEL(zab_ddt_fast_nw8w3, 8, 3)
 #undef D2_KERNEL
 
 static size_t d2_lds_bytes(int W, int nw) {
@@ -754,12 +781,12 @@ static int d2_pick_nw(int n_inst) {
 }
 // Ring length and waves per instance; W = 0: the two filtered rings do not fit (or the history they need is longer than
 // the mem[] rings hold) -> the wide-history kernel.
-static void d2_geometry(const ZabBatch* b, int64_t frames, int& W, int& nw, int& nh) {
+static void d2_geometry_nw(const ZabBatch* b, int64_t frames, int nw0, int& W, int& nw, int& nh) {
   const DdtPlan p = ddt_plan(b);
   W = 0; nw = 1; nh = 0;
   if (!p.ok) return;
   const size_t cap = 160 * 1024 - 512;
-  for (nw = d2_pick_nw(b->n_inst); nw >= 1; nw >>= 1) {
+  for (nw = nw0; nw >= 1; nw >>= 1) {
     const int need = p.dmax + nw * D2_CH + 1;
     const int w = (need + 7) / 8 * 8;
     // history: frames [-(dmax + 1), 0) must have been filtered; the launch's first chunk reaches back to f_first
@@ -770,6 +797,29 @@ static void d2_geometry(const ZabBatch* b, int64_t frames, int& W, int& nw, int&
     if (d2_lds_bytes(w, nw) <= cap && h * D2_CH - f_first <= DDT_RING) { W = w; nh = (int)h; return; }
   }
   nw = 1;
+}
+// Waves per SIMD the launch is compiled for (mw) and waves per instance. Three waves per SIMD need twelve waves per CU inside the
+// LDS: at the default delays (rings of 1176 + 256 frames) that is three workgroups of FOUR waves (49 KB each), not five of two
+// (33 KB each: four fit). Measured on MI355X (profiles/r04_ddt_w3.txt), 4096 instances: the 168-register kernels' PLAIN chunks
+// cost 0.0291 ms per 1000 frames against 0.0347 (nw2, two waves per SIMD, double-buffered taps), their METERED chunks -- two
+// tap sums, the meters' arithmetic, what the allocation spills (100 B) -- 0.0578 against 0.0492. A launch meters its last
+// 57 344 frames, so the 168-register kernel takes the launches that are mostly plain: 480 000 frames 15.6 against 17.5 ms,
+// 96 000 frames 4.44 against 4.17. nw2w3 (8 waves per CU either way, the taps' LDS latency exposed) loses everywhere: 19.8 ms.
+// ZAB_DDT_MINW = 2 | 3 and ZAB_DDT_NW pin the choice.
+#ifndef D2_W3_MIN_FRAMES
+#define D2_W3_MIN_FRAMES 160000
+#endif
+static void d2_geometry(const ZabBatch* b, int64_t frames, int& W, int& nw, int& nh, int& mw) {
+  mw = 2;
+  const char* em = getenv("ZAB_DDT_MINW");
+  const bool pinned_nw = getenv("ZAB_DDT_NW") != nullptr;
+  const int want = em ? (atoi(em) == 2 ? 2 : 3) : ((b->n_inst >= 1024 && frames >= D2_W3_MIN_FRAMES) ? 3 : 2);
+  if (want == 3) {
+    d2_geometry_nw(b, frames, pinned_nw ? d2_pick_nw(b->n_inst) : 4, W, nw, nh);
+    const size_t cap = 160 * 1024 - 512;
+    if (W != 0 && nw > 1 && (em || pinned_nw || (nw == 4 && 3 * d2_lds_bytes(W, nw) <= cap))) { mw = 3; return; }
+  }
+  d2_geometry_nw(b, frames, d2_pick_nw(b->n_inst), W, nw, nh);
 }
 
 // Which kernel takes a launch. zab_ddt_fast filters the history a tap can reach (Dmax frames) before the launch's first
@@ -791,9 +841,9 @@ static bool d2_wanted(int64_t frames) {
 static int32_t za_fast_applies(const ZabBatch* b, const ZabAudio* a) {
   if (!b->instance_major || b->var_se != 1 || b->mem_se != 1 || b->sl_se != 1) return 0;
   if (a->frames <= 0) return 0;
-  int W, nw, nh;
+  int W, nw, nh, mw;
   if (d2_wanted(a->frames)) {
-    d2_geometry(b, a->frames, W, nw, nh);
+    d2_geometry(b, a->frames, W, nw, nh, mw);
     if (W != 0) return 1;
   }
   ddt_geometry(b, W, nw);
@@ -801,31 +851,30 @@ static int32_t za_fast_applies(const ZabBatch* b, const ZabAudio* a) {
 }
 
 static hipError_t za_launch_fast(const ZabBatch* b, const ZabAudio* a, hipStream_t st) {
-  int W = 0, nw, nh;
-  if (d2_wanted(a->frames)) d2_geometry(b, a->frames, W, nw, nh);
+  int W = 0, nw, nh, mw = 2;
+  if (d2_wanted(a->frames)) d2_geometry(b, a->frames, W, nw, nh, mw);
   if (W == 0) return ddt_wide_launch(b, a, st);
   const size_t lds = d2_lds_bytes(W, nw);
+  typedef void (*D2Fn)(ZabBatch, ZabAudio, int, int);
+  static const D2Fn fns[2][4] = {{zab_ddt_fast, zab_ddt_fast_nw2, zab_ddt_fast_nw4, zab_ddt_fast_nw8},
+                                 {zab_ddt_fast, zab_ddt_fast_nw2w3, zab_ddt_fast_nw4w3, zab_ddt_fast_nw8w3}};
   static ZaPerDevice once;               // (function attributes are per device: a group runs one engine per GPU)
   once.once([] {
     const int cap = 160 * 1024 - 512;
-    (void)hipFuncSetAttribute((const void*)zab_ddt_fast, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-    (void)hipFuncSetAttribute((const void*)zab_ddt_fast_nw2, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-    (void)hipFuncSetAttribute((const void*)zab_ddt_fast_nw4, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-    (void)hipFuncSetAttribute((const void*)zab_ddt_fast_nw8, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    for (int m = 0; m < 2; ++m)
+      for (int k = 0; k < 4; ++k) (void)hipFuncSetAttribute((const void*)fns[m][k], hipFuncAttributeMaxDynamicSharedMemorySize, cap);
   });
+  if (nw == 1) mw = 2;
+  const int ki = nw == 1 ? 0 : nw == 2 ? 1 : nw == 4 ? 2 : 3;
+  const D2Fn fn = fns[mw - 2][ki];
   const dim3 grid(b->n_inst), block(64 * nw);
-  snprintf(ddt_kernel_name, sizeof ddt_kernel_name, nw == 1 ? "zab_ddt_fast" : "zab_ddt_fast_nw%d", nw);
+  if (nw == 1) snprintf(ddt_kernel_name, sizeof ddt_kernel_name, "zab_ddt_fast");
+  else snprintf(ddt_kernel_name, sizeof ddt_kernel_name, mw == 3 ? "zab_ddt_fast_nw%dw3" : "zab_ddt_fast_nw%d", nw);
   if (getenv("ZAB_DDT_DEBUG")) {                           // geometry and residency of the launch
-    const void* fn = nw == 1 ? (const void*)zab_ddt_fast : nw == 2 ? (const void*)zab_ddt_fast_nw2 : nw == 4 ? (const void*)zab_ddt_fast_nw4 : (const void*)zab_ddt_fast_nw8;
     int wgs = -1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs, fn, 64 * nw, lds);
-    fprintf(stderr, "zab_ddt_fast: nw %d W %d nh %d lds %zu B -> %d workgroups (%d waves) per CU\n", nw, W, nh, lds, wgs, wgs * nw);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs, (const void*)fn, 64 * nw, lds);
+    fprintf(stderr, "%s: nw %d W %d nh %d lds %zu B -> %d workgroups (%d waves) per CU\n", ddt_kernel_name, nw, W, nh, lds, wgs, wgs * nw);
   }
-  switch (nw) {
-    case 1: hipLaunchKernelGGL(zab_ddt_fast, grid, block, lds, st, *b, *a, W, nh); break;
-    case 2: hipLaunchKernelGGL(zab_ddt_fast_nw2, grid, block, lds, st, *b, *a, W, nh); break;
-    case 4: hipLaunchKernelGGL(zab_ddt_fast_nw4, grid, block, lds, st, *b, *a, W, nh); break;
-    default: hipLaunchKernelGGL(zab_ddt_fast_nw8, grid, block, lds, st, *b, *a, W, nh); break;
-  }
+  hipLaunchKernelGGL(fn, grid, block, lds, st, *b, *a, W, nh);
   return hipGetLastError();
 }
