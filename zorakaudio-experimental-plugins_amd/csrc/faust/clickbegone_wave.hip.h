@@ -16,7 +16,8 @@
 
 #include "clickbegone.hip.h"
 
-#define ZF_CBG_FAST_NAME "zf_cbg_wave"
+static char zf_cbg_kernel_name[24] = "zf_cbg_wave_quad";   /* the kernel the last launch took: zf_cbg_wave_quad | zf_cbg_wave */
+#define ZF_CBG_FAST_NAME zf_cbg_kernel_name
 
 template <int G>
 __global__ void __launch_bounds__(64) zf_cbg_wave(ZabBatch b, ZabAudio a) {
@@ -196,7 +197,9 @@ static bool zf_cbg_use_quad(int n_inst) {
   return quad;
 }
 static hipError_t zf_cbg_launch(const ZabBatch* b, const ZabAudio* a, hipStream_t st) {
-  if (zf_cbg_use_quad(b->n_inst)) {
+  const bool quad = zf_cbg_use_quad(b->n_inst);
+  snprintf(zf_cbg_kernel_name, sizeof zf_cbg_kernel_name, quad ? "zf_cbg_wave_quad" : "zf_cbg_wave");
+  if (quad) {
     hipLaunchKernelGGL(zf_cbg_wave_quad, dim3((b->n_inst + 3) / 4), dim3(256), 0, st, *b, *a);
     return hipGetLastError();
   }
