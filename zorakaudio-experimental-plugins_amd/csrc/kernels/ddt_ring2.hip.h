@@ -136,7 +136,7 @@ __device__ __forceinline__ void d2_filter_local(const D2Ctx& C, int lane, int64_
 template <bool HIST, bool METERS>
 __device__ __forceinline__ void d2_filter_publish(const D2Ctx& C, int lane, int pos, const double (&cw)[4], bool chained,
                                                   const double (&x0)[D2_KF], const double (&x1)[D2_KF], double (&y)[4][D2_KF],
-                                                  const double (&G)[4], double& accD, double wMd, bool want_last) {
+                                                  const double (&G)[4], double& accD, bool want_last) {
 #pragma unroll
   for (int s = HIST ? 2 : 0; s < 4; ++s) {
     const int p = s < 2 ? 0 : s - 1;
@@ -175,7 +175,7 @@ __device__ __forceinline__ void d2_filter_publish(const D2Ctx& C, int lane, int 
       double z = 0.0;
 #pragma unroll
       for (int k = 0; k < D2_KF; ++k) z = __builtin_fma(C.U->cwMd[k], fabs(y[0][k]) + fabs(y[1][k]), z);
-      accD = __builtin_fma(accD, C.U->dMi, wMd * z);
+      accD = __builtin_fma(accD, C.U->dMi, z);            // (the lane's own weight is applied once, after the loop)
       if (want_last && lane == 63) { C.U->fin[6] = y[0][D2_KF - 1]; C.U->fin[7] = y[1][D2_KF - 1]; }
     }
   }
@@ -272,7 +272,7 @@ __device__ __forceinline__ void d2_tap_run(const D2TapRegs& R, int lane8, int i0
 // corr: the a^(n+1) K terms still matter for this chunk (wave-uniform).
 template <bool PARTIAL, bool METERS, int MW>
 __device__ __forceinline__ void d2_tap_phase(const D2Ctx& C, const D2TapRegs& R, int lane, int64_t f0, bool corr,
-                                             double (&accM)[6], double& accC, double wM, double wC, bool want_last,
+                                             double (&accM)[6], double& accC, bool want_last,
                                              float (&o0)[D2_KF], float (&o1)[D2_KF] DDT_STAMP_ARGS) {
   const int lane8 = 8 * lane;
   double sA[2][D2_KF], sB[2][D2_KF];                       // METERS: sA early, sB late; else sA holds both
@@ -343,8 +343,8 @@ __device__ __forceinline__ void d2_tap_phase(const D2Ctx& C, const D2TapRegs& R,
   if (METERS) {
     const double dMi = C.U->dMi, dCi = C.U->dCi;
 #pragma unroll
-    for (int q = 1; q < 6; ++q) accM[q] = __builtin_fma(accM[q], dMi, wM * zM[q]);
-    accC = __builtin_fma(accC, dCi, wC * zC);
+    for (int q = 1; q < 6; ++q) accM[q] = __builtin_fma(accM[q], dMi, zM[q]);      // (lane weights: after the loop)
+    accC = __builtin_fma(accC, dCi, zC);
   }
 }
 
@@ -509,7 +509,6 @@ __device__ __forceinline__ void d2_body(const ZabBatch& b, const ZabAudio& a, in
 
   // per-lane meter state and weights: only the metered iterations touch them (defined just before those run)
   double accM[6] = {0, 0, 0, 0, 0, 0}, accC = 0.0;
-  double wMd = 0.0, wM = 0.0, wC = 0.0;
 
   auto iteration = [&](auto part_c, auto hist_c, auto met_c, const int64_t it) __attribute__((always_inline)) {
     constexpr bool PART = decltype(part_c)::value, HIST = decltype(hist_c)::value, MET = decltype(met_c)::value;
@@ -556,7 +555,7 @@ __device__ __forceinline__ void d2_body(const ZabBatch& b, const ZabAudio& a, in
       for (int s = S0; s < 4; ++s) carry[s] = run[s];      // state after this iteration's last chunk (same in every wave)
     }
     DDT_STAMP(1)
-    if (active) d2_filter_publish<HIST, MET>(C, lane, pos, cw, wave != 0, x0, x1, y, G, accM[0], wMd, want_last);
+    if (active) d2_filter_publish<HIST, MET>(C, lane, pos, cw, wave != 0, x0, x1, y, G, accM[0], want_last);
     DDT_STAMP(2)
     if (NW > 1) ddt_barrier();                             // rings hold every frame of this iteration
     else {                                                 // (one wave: its LDS accesses execute in order; the compiler must keep them so)
@@ -601,8 +600,8 @@ __device__ __forceinline__ void d2_body(const ZabBatch& b, const ZabAudio& a, in
       }
       if (active) {
         const bool corr = f0 < corr_until;
-        if (part) d2_tap_phase<true, MET, MW>(C, R, lane, f0, corr, accM, accC, wM, wC, want_last, o0, o1 DDT_STAMP_PASS);
-        else d2_tap_phase<false, MET, MW>(C, R, lane, f0, corr, accM, accC, wM, wC, want_last, o0, o1 DDT_STAMP_PASS);
+        if (part) d2_tap_phase<true, MET, MW>(C, R, lane, f0, corr, accM, accC, want_last, o0, o1 DDT_STAMP_PASS);
+        else d2_tap_phase<false, MET, MW>(C, R, lane, f0, corr, accM, accC, want_last, o0, o1 DDT_STAMP_PASS);
         my_last_chunk = c;
       }
     }
@@ -625,18 +624,13 @@ __device__ __forceinline__ void d2_body(const ZabBatch& b, const ZabAudio& a, in
   {
     const std::false_type no{};
     const std::true_type yes{};
-    auto meter_weights = [&]() __attribute__((always_inline)) {
-      wMd = ddt_ipow((aM * aM) * (aM * aM), 63 - lane);    // filter phase: lane = KF consecutive frames
-      wM = ddt_ipow(aM, 63 - lane); wC = ddt_ipow(aC, 63 - lane);   // tap phase: lane = frames 64 apart
-    };
     int64_t it = 0;
     for (; it < it0; ++it) iteration(no, yes, no, it);
     if (f_first < 0) {                                     // workgroup-uniform
-      if (it >= it_m) { meter_weights(); iteration(yes, no, yes, it); } else iteration(yes, no, no, it);
+      if (it >= it_m) iteration(yes, no, yes, it); else iteration(yes, no, no, it);
       ++it;
     }
     for (; it < it_m; ++it) iteration(no, no, no, it);
-    meter_weights();
     for (; it < niter; ++it) iteration(no, no, yes, it);
   }
 #ifdef DDT_STAMPS
@@ -651,9 +645,16 @@ __device__ __forceinline__ void d2_body(const ZabBatch& b, const ZabAudio& a, in
     // a wave's partials are relative to the end of ITS last chunk; bring them to the end of the launch
     const int64_t behind = my_last_chunk >= 0 ? (ntot - 1 - my_last_chunk) * D2_CH : 0;
     const double fM = ddt_ipow(aM, behind), fC = ddt_ipow(aC, behind);
+    // ... and each lane's frames enter with the lane's own weight, a^(distance to the chunk's end): the accumulators above are
+    // kept unweighted (accM = accM * a^(CH NW) + z per chunk), the weight factors out of the sum and is applied here -- three
+    // per-lane doubles fewer across the loop (under the 168-register cap they were what pushed the accumulators into scratch,
+    // whose stores then stood in every chunk's vmcnt(0): 2392 -> NNN ticks per metered wave-chunk, tools/ddt_stamps.py)
+    const double wMd = ddt_ipow((aM * aM) * (aM * aM), 63 - lane);    // filter phase: lane = KF consecutive frames
+    const double wM = ddt_ipow(aM, 63 - lane), wC = ddt_ipow(aC, 63 - lane);   // tap phase: lane = frames 64 apart
+    red[0] = accM[0] * (wMd * fM);
 #pragma unroll
-    for (int q = 0; q < 6; ++q) red[q] = accM[q] * fM;
-    red[6] = accC * fC;
+    for (int q = 1; q < 6; ++q) red[q] = accM[q] * (wM * fM);
+    red[6] = accC * (wC * fC);
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1)
