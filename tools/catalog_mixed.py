@@ -24,11 +24,27 @@ def main() -> int:
     ap.add_argument("--block", type=int, default=512)
     ap.add_argument("--out", default="")
     args = ap.parse_args()
+    ks = [int(x) for x in args.per_leaf.split(",")]
+    if len(ks) > 1:
+        # one process per batch size: a queue keeps the scratch of the largest kernel it ever ran (Sample: 36 KB per lane), and the
+        # second pass's 32 new queues on top of the first pass's ran the device out of scratch (HSA_STATUS_ERROR_OUT_OF_RESOURCES).
+        # This process touches no GPU itself.
+        import subprocess
+        import tempfile
+        rows = []
+        for k in ks:
+            with tempfile.NamedTemporaryFile(suffix=".json") as tf:
+                subprocess.run([sys.executable, __file__, "--per-leaf", str(k), "--seconds", str(args.seconds), "--block", str(args.block),
+                                "--out", tf.name], check=True)
+                rows += json.loads(Path(tf.name).read_text())
+        if args.out:
+            Path(args.out).write_text(json.dumps(rows, indent=1))
+        return 0
     lib = ROOT / "zorakaudio-experimental-plugins_amd" / "lib"
     leaves = sorted(p.stem for p in lib.glob("*.json") if not p.stem.startswith("fx_"))
     frames = int(args.seconds * 48000)
     out = []
-    for k in (int(x) for x in args.per_leaf.split(",")):
+    for k in ks:
         engines, skipped = [], []
         for leaf in leaves:
             meta = zabatch.leaf_meta(leaf)

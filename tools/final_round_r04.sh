@@ -26,11 +26,11 @@ B)
   python tools/fft_bench.py > $O/${TAG}_fft_bench.log 2>&1 || exit 1
   ;;
 C)
-  ZAB_DDT_NW=2 tools/sq_pass.sh ${TAG}_sq_ddt DDT 4096 480000 auto > $O/${TAG}_sq_ddt.log 2>&1 || exit 1
+  tools/sq_pass.sh ${TAG}_sq_ddt DDT 4096 480000 auto 0 ddt > $O/${TAG}_sq_ddt.log 2>&1 || exit 1
   tools/sq_pass.sh ${TAG}_sq_alias_tpar Alias 1024 48000 fast 524288 > $O/${TAG}_sq_alias_tpar.log 2>&1 || exit 1
   tools/sq_pass.sh ${TAG}_sq_alias_generic Alias 1024 48000 generic 524288 > $O/${TAG}_sq_alias_generic.log 2>&1 || exit 1
-  ZAB_CBG_KERNEL=quad tools/sq_pass.sh ${TAG}_sq_cbg_quad ClickBeGoneSG 1024 48000 fast > $O/${TAG}_sq_cbg_quad.log 2>&1 || exit 1
-  ZAB_CBG_KERNEL=wave tools/sq_pass.sh ${TAG}_sq_cbg_wave ClickBeGoneSG 1024 48000 fast > $O/${TAG}_sq_cbg_wave.log 2>&1 || exit 1
+  ZAB_CBG_KERNEL=quad tools/sq_pass.sh ${TAG}_sq_cbg_quad ClickBeGoneSG 1024 48000 fast 0 zf_cbg > $O/${TAG}_sq_cbg_quad.log 2>&1 || exit 1
+  ZAB_CBG_KERNEL=wave tools/sq_pass.sh ${TAG}_sq_cbg_wave ClickBeGoneSG 1024 48000 fast 0 zf_cbg > $O/${TAG}_sq_cbg_wave.log 2>&1 || exit 1
   bash tools/ddt_nw_per_gpu_batch.sh > $O/${TAG}_ddt_per_gpu_batch.txt 2>&1 || exit 1
   python -m pytest tests/test_ddt_gpu.py tests/test_group_gpu.py -m gpu -q -x > $O/${TAG}_ddt_group.log 2>&1 || exit 1
   ;;

@@ -276,9 +276,10 @@ def _build_plan(prog: Program, nch: int, event_ids: set, no_event: set, why: Dic
     plan.st = {name: vn for name, vn in g.varnodes.items() if vn.kind == "st"}
     plan.cells = dict(g.cells)
     plan.stores, plan.loads = list(g.stores), list(g.loads)
-    if (not written and not plan.stores and not plan.events and not g.loops
+    if (not written and not plan.stores and not plan.events and not plan.guards and not g.loops
             and all(o.kind == "in" and int(o.val) == ch for ch, o in enumerate(plan.spl_out))):
-        # every channel goes out as it came in and nothing else happens per frame: such a leaf is its @block (message-bus / gmem
+        # every channel goes out as it came in and nothing else happens per frame, rare heavy branches included (a guard's body runs with
+        # the wavefront's lanes cooperating -- the FFT harness: 304 against 355 us per round trip): such a leaf is its @block (message-bus / gmem
         # bookkeeping), which the lane-per-instance kernel runs with the state in registers from block to block (3DPannerManager,
         # 256 instances x 48 000 frames: 1124 ms against 1570 ms on a time-parallel kernel with nothing to parallelise)
         raise Unsupported("@sample is empty: nothing to run time-parallel")
