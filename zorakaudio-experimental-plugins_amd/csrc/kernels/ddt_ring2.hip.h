@@ -810,15 +810,44 @@ static void d2_geometry_nw(const ZabBatch* b, int64_t frames, int nw0, int& W, i
 #ifndef D2_W3_MIN_FRAMES
 #define D2_W3_MIN_FRAMES 160000
 #endif
+static int d2_cu_count() {                     // compute units of the current device (cached per device ordinal)
+  static int cached[16] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+  if (!cached[dev]) {
+    int v = 0;
+    cached[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+  }
+  return cached[dev];
+}
+// Which of the two wins is a matter of ROUNDS: the 194-register kernel keeps 4 workgroups (of two waves) per CU resident, the
+// 168-register one 3 (of four waves), and a batch runs in ceil(instances / resident workgroups) rounds -- 1024 instances are one
+// round of the former (4.54 ms x 480 000 frames) and two of the latter (4.97), 1536 two and two (8.76 against 6.56), 4096 four and
+// six (17.5 against 15.7). A round's time goes with the workgroups per CU times the per-instance rate of plain chunks measured above.
 static void d2_geometry(const ZabBatch* b, int64_t frames, int& W, int& nw, int& nh, int& mw) {
   mw = 2;
   const char* em = getenv("ZAB_DDT_MINW");
   const bool pinned_nw = getenv("ZAB_DDT_NW") != nullptr;
-  const int want = em ? (atoi(em) == 2 ? 2 : 3) : ((b->n_inst >= 1024 && frames >= D2_W3_MIN_FRAMES) ? 3 : 2);
-  if (want == 3) {
-    d2_geometry_nw(b, frames, pinned_nw ? d2_pick_nw(b->n_inst) : 4, W, nw, nh);
-    const size_t cap = 160 * 1024 - 512;
-    if (W != 0 && nw > 1 && (em || pinned_nw || (nw == 4 && 3 * d2_lds_bytes(W, nw) <= cap))) { mw = 3; return; }
+  const size_t cap = 160 * 1024 - 512;
+  if (em ? atoi(em) != 2 : (b->n_inst >= 1024 && frames >= D2_W3_MIN_FRAMES)) {
+    int W3, nw3, nh3;
+    d2_geometry_nw(b, frames, pinned_nw ? d2_pick_nw(b->n_inst) : 4, W3, nw3, nh3);
+    bool take = W3 != 0 && nw3 > 1 && (em || pinned_nw);
+    if (W3 != 0 && nw3 == 4 && !take && 3 * d2_lds_bytes(W3, 4) <= cap) {
+      int W2, nw2, nh2;
+      d2_geometry_nw(b, frames, d2_pick_nw(b->n_inst), W2, nw2, nh2);
+      if (W2 == 0 || nw2 < 2) take = true;
+      else {
+        const int64_t cus = d2_cu_count();
+        int64_t wg2 = (int64_t)(cap / d2_lds_bytes(W2, nw2));
+        if (wg2 > 8 / nw2) wg2 = 8 / nw2;
+        if (wg2 < 1) wg2 = 1;
+        const double cost2 = (double)((b->n_inst + wg2 * cus - 1) / (wg2 * cus)) * (double)wg2 * 0.0347;
+        const double cost3 = (double)((b->n_inst + 3 * cus - 1) / (3 * cus)) * 3.0 * 0.0291;
+        take = cost3 < cost2;
+      }
+    }
+    if (take) { W = W3; nw = nw3; nh = nh3; mw = 3; return; }
   }
   d2_geometry_nw(b, frames, d2_pick_nw(b->n_inst), W, nw, nh);
 }
