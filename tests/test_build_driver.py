@@ -61,7 +61,8 @@ def test_correctness_check_rows(leaf):
     assert {r["path"] for r in rows} == {"fast", "generic"} and len(rows) == 2 * len(check.cases_of(leaf))
     for r in rows:
         assert r["ok"], r
-        assert r["max_dbfs"] <= -100.0 and r["vars_worst"] <= 1e-8 and r["mem_worst"] <= 1e-8 and r["mem_high_ok"]
+        assert r["max_dbfs"] <= -100.0 and r["vars_worst"] <= 1e-8 and r["mem_high_ok"]
+        assert r["mem_worst"] is not None and r["mem_worst"] <= 1e-8          # (these leaves' arenas are small: compared)
     assert any(r["kernel"].startswith("zab_ddt") or r["kernel"].endswith("_tpar") for r in rows if r["path"] == "fast")
 
 

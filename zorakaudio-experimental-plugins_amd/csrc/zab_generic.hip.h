@@ -387,7 +387,11 @@ static hipError_t za_launch_slider(const ZabBatch* b, hipStream_t st) {
 static hipError_t za_launch_prepare(const ZabBatch* b, hipStream_t st) {
 #if ZA_USES_FFT
   static ZaPerDevice za_fft_once;        // (the twiddle / permutation tables are __device__ globals: one copy per GPU)
-  za_fft_once.once([st] { hipLaunchKernelGGL(za_fft_table_kernel, dim3(ZA_FFT_MAX / 2 / 256), dim3(256), 0, st); });
+  za_fft_once.once([st] {       // (waited for here: another engine of this leaf on the same device runs on its own stream and must
+                                //  not read the tables before this kernel has written them; once per device and module)
+    hipLaunchKernelGGL(za_fft_table_kernel, dim3(ZA_FFT_MAX / 2 / 256), dim3(256), 0, st);
+    (void)hipStreamSynchronize(st);
+  });
 #endif
   hipLaunchKernelGGL(ZA_KERNEL(prepare), dim3((b->n_inst + b->ipw - 1) / b->ipw), dim3(64), 0, st, *b);
   return hipGetLastError();

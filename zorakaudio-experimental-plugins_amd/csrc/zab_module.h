@@ -10,7 +10,8 @@
 
 // One-time initialisations of a module are per DEVICE, not per process: __device__ tables and function attributes belong to the
 // device that was current when they were set, and one process may hold engines on several GPUs (zab_group_*). Runs f() the
-// first time it is reached with a given device current.
+// first time it is reached with a given device current; f() must have COMPLETED its work when it returns (the device is marked
+// done under the lock: a second engine on another stream takes the mark as "ready to use").
 struct ZaPerDevice {
   std::mutex mu;
   uint64_t done[4] = {0, 0, 0, 0};

@@ -20,6 +20,7 @@ Outputs (all git-ignored, all travel to the GPU box):
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import subprocess
@@ -265,24 +266,33 @@ def build_module(jsfx_path, name: Optional[str] = None, force=False, verbose=Fal
     for extra in ("zart_fft.h", "zart_gmem.h", "zart_pool.h", "zart_file.h", "zart_msg.h"):
         if (CSRC / extra).exists():
             deps.append(CSRC / extra)
-    stale = (force or not so.exists() or not src.exists() or src.read_text() != text
-             or any(so.stat().st_mtime < d.stat().st_mtime for d in deps))
-    lb_note = LIB / f"{prog.name}.longbranch"
-    if stale:
-        src.write_text(text)
-        t0 = time.time()
-        _run([HIPCC] + HIP_FLAGS + leaf_flags + ["-I", str(CSRC), "-o", str(so), str(src)])
-        if verbose:
-            print(f"  hipcc {prog.name}: {time.time() - t0:.1f}s")
-        lb_note.unlink(missing_ok=True)
-        if "ZA_FAST_KERNEL_NAME \"zab_" in text and "_tpar\"" in text and prog.name not in NO_TPAR:
-            nlb = long_branches(so, f"zab_{_cid(prog.name)}_tpar")
-            if nlb > LONG_BRANCH_LIMIT:          # see long_branches(): the generic kernel stays the leaf's only one
-                lb_note.write_text(str(nlb))
-    if lb_note.exists() and not os.environ.get("ZA_TPAR_ALLOW_LONG_BRANCHES"):
-        NO_TPAR[prog.name] = f"the device compiler needed {lb_note.read_text()} long-branch expansions in the time-parallel kernel (not trusted)"
+    lb_note = LIB / f"{prog.name}.longbranch"      # "<count>\n<sha1 of the module text whose time-parallel kernel was refused>"
+    allow_lb = bool(os.environ.get("ZA_TPAR_ALLOW_LONG_BRANCHES"))
+    deps_newer = lambda: any(so.stat().st_mtime < d.stat().st_mtime for d in deps)
+    text_sha = hashlib.sha1(text.encode()).hexdigest()
+    refused = None
+    if lb_note.exists() and not allow_lb and not force:
+        note = lb_note.read_text().split()
+        if len(note) == 2 and note[1] == text_sha:
+            refused = note[0]           # the same text was compiled, counted and refused before: do not compile it again
+    if refused is None:
+        stale = force or not so.exists() or not src.exists() or src.read_text() != text or deps_newer()
+        if stale:
+            src.write_text(text)
+            t0 = time.time()
+            _run([HIPCC] + HIP_FLAGS + leaf_flags + ["-I", str(CSRC), "-o", str(so), str(src)])
+            if verbose:
+                print(f"  hipcc {prog.name}: {time.time() - t0:.1f}s")
+            lb_note.unlink(missing_ok=True)
+            if "ZA_FAST_KERNEL_NAME \"zab_" in text and "_tpar\"" in text and prog.name not in NO_TPAR:
+                nlb = long_branches(so, f"zab_{_cid(prog.name)}_tpar")
+                if nlb > LONG_BRANCH_LIMIT and not allow_lb:      # see long_branches(): the generic kernel stays the leaf's only one
+                    lb_note.write_text(f"{nlb}\n{text_sha}")
+                    refused = str(nlb)
+    if refused is not None:
+        NO_TPAR[prog.name] = f"the device compiler needed {refused} long-branch expansions in the time-parallel kernel (not trusted)"
         text = module_source(unit)
-        if src.read_text() != text:
+        if force or not so.exists() or not src.exists() or src.read_text() != text or deps_newer():
             src.write_text(text)
             _run([HIPCC] + HIP_FLAGS + leaf_flags + ["-I", str(CSRC), "-o", str(so), str(src)])
     meta = unit.meta()
