@@ -648,7 +648,7 @@ __device__ __forceinline__ void d2_body(const ZabBatch& b, const ZabAudio& a, in
     // ... and each lane's frames enter with the lane's own weight, a^(distance to the chunk's end): the accumulators above are
     // kept unweighted (accM = accM * a^(CH NW) + z per chunk), the weight factors out of the sum and is applied here -- three
     // per-lane doubles fewer across the loop (under the 168-register cap they were what pushed the accumulators into scratch,
-    // whose stores then stood in every chunk's vmcnt(0): 2392 -> NNN ticks per metered wave-chunk, tools/ddt_stamps.py)
+    // whose stores then stood in every chunk's vmcnt(0): 2392 -> 1912 ticks per metered wave-chunk, tools/ddt_stamps.py)
     const double wMd = ddt_ipow((aM * aM) * (aM * aM), 63 - lane);    // filter phase: lane = KF consecutive frames
     const double wM = ddt_ipow(aM, 63 - lane), wC = ddt_ipow(aC, 63 - lane);   // tap phase: lane = frames 64 apart
     red[0] = accM[0] * (wMd * fM);
