@@ -236,6 +236,30 @@ def test_gpu_fft_known_answers(n, leaf):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("path", ["auto", "generic"])
+@pytest.mark.parametrize("mask", [1, 9, 31])       # fft alone (WDL order out); fft, ifft; the four builtins as fused natural-order pairs
+@pytest.mark.parametrize("size", [2048, 4096])
+def test_gpu_sliced_transforms_keep_the_bits_of_the_in_lds_form(size, mask, path):
+    """Transforms beyond the 1024-point LDS buffer run in two stages of 1024-point chunks (zart_fft.h, za_fft_coop); the *_full
+    build keeps the whole transform in LDS. Same butterflies, twiddles and order per element: the arenas must be identical,
+    on full and on partly filled wavefronts (70 instances) and on both kernels."""
+    import zabatch
+    if not zabatch.module_path("fx_fftbench_full").exists():
+        pytest.skip("fx_fftbench_full not built")
+    p = {"auto": zabatch.ZAB_PATH_AUTO, "generic": zabatch.ZAB_PATH_GENERIC}[path]
+    got = {}
+    for leaf in ("fx_fftbench", "fx_fftbench_full"):
+        with zabatch.Engine(leaf, 70, mem_cap=1 << 17, path=p) as e:
+            row = np.zeros(64); row[0] = size; row[1] = 1; row[2] = mask
+            e.set_sliders(row); e.prepare()
+            e.process_host(np.zeros((70, e.nch, 64), np.float32), block=64)
+            got[leaf] = e.read_mem(0, 2 * size)
+    assert np.isfinite(got["fx_fftbench"]).all() and np.abs(got["fx_fftbench"]).max() > 1.0
+    assert np.array_equal(got["fx_fftbench"], got["fx_fftbench_full"])
+    assert np.array_equal(got["fx_fftbench"][0], got["fx_fftbench"][69])
+
+
+@pytest.mark.gpu
 def test_gpu_stft_fixture_matches_reference_vm():
     import zabatch
     g = load_golden("fx_stft_default")

@@ -48,6 +48,7 @@ extern "C" int zab_module_fft_lds_points(void) { return ZA_FFT_LDS_POINTS; }   /
 __device__ double za_fft_cos[ZA_FFT_MAX / 2];
 __device__ double za_fft_sin[ZA_FFT_MAX / 2];
 __device__ double za_fft_twc[ZA_FFT_LDS_POINTS];     // (cos, sin)(2 pi j / ZA_FFT_LDS_POINTS), j < ZA_FFT_LDS_POINTS / 2
+__device__ double za_fft_tw4[ZA_FFT_COOP_MAX];       // (cos, sin)(2 pi j / ZA_FFT_COOP_MAX), j < ZA_FFT_COOP_MAX / 2: the sliced transforms' second stage
 __device__ uint16_t za_fft_perm[2 * ZA_FFT_COOP_MAX];     // [n + i] = natural bin stored at position i of an n-point transform
 __device__ uint16_t za_fft_iperm[2 * ZA_FFT_COOP_MAX];    // [n + k] = position that holds natural bin k
 #else
@@ -102,6 +103,10 @@ extern "C" __global__ void za_fft_table_kernel() {
     if (j % (ZA_FFT_MAX / ZA_FFT_LDS_POINTS) == 0) {      // the in-LDS passes' twiddles, (cos, sin) side by side: 8 KB that stay in L1
       za_fft_twc[2 * (j / (ZA_FFT_MAX / ZA_FFT_LDS_POINTS))] = cs;
       za_fft_twc[2 * (j / (ZA_FFT_MAX / ZA_FFT_LDS_POINTS)) + 1] = sn;
+    }
+    if (j % (ZA_FFT_MAX / ZA_FFT_COOP_MAX) == 0) {
+      za_fft_tw4[2 * (j / (ZA_FFT_MAX / ZA_FFT_COOP_MAX))] = cs;
+      za_fft_tw4[2 * (j / (ZA_FFT_MAX / ZA_FFT_COOP_MAX)) + 1] = sn;
     }
   }
   if (j >= 2 && j < 2 * ZA_FFT_COOP_MAX) {      // j = n + i with n the largest power of two <= j (real transforms use sizes from 8)
@@ -244,6 +249,64 @@ __device__ __forceinline__ void za_fft_lds_pass(double* buf, const double* tw, i
   __builtin_amdgcn_wave_barrier();
 }
 
+// The same R fused passes over the whole LDS buffer for the sliced transforms (za_fft_coop, nl > ZA_FFT_LDS_POINTS): the buffer
+// holds a chunk of a larger transform, so which twiddle a butterfly takes is the caller's business -- twf(jl, lhb, wr, wi) with jl
+// the upper point's offset inside its local group of 2 << lhb positions. Positions are swizzled by ZA_B2: low four bits XOR
+// bits 4-7, a bijection of the lanes of a 16-lane phase whether they step through a row (these passes: h0 >= 16) or down a column.
+#define ZA_B2(i) (2 * ((int)(i) ^ (((int)(i) >> 4) & 15)))
+template <int R, class TW>
+__device__ __forceinline__ void za_fft_lds_pass_v(double* buf, int h0, int sign, int rank, int nact, TW twf) {
+  constexpr int Q = 1 << R;
+  constexpr int U = R == 3 ? 1 : 2;
+  constexpr int items = ZA_FFT_LDS_POINTS >> R;
+  const int hb = 31 - __builtin_clz((unsigned)h0);
+  for (int idx0 = rank; idx0 < items; idx0 += U * nact) {
+    double xr[U][Q], xi[U][Q], wr[U][Q - 1], wi[U][Q - 1];
+    int base[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = idx0 + u * nact;
+      const int ix = idx < items ? idx : 0;
+      const int j = ix & (h0 - 1);
+      const int b0 = ((ix >> hb) << (hb + R)) + j;        // points b0 + k * h0, k < Q
+      base[u] = idx < items ? b0 : -1;
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int m = 0; m < (1 << r); ++m) twf(j + m * h0, hb + r, wr[u][(1 << r) - 1 + m], wi[u][(1 << r) - 1 + m]);
+#pragma unroll
+      for (int k = 0; k < Q; ++k) {
+        xr[u][k] = buf[ZA_B2(b0 + k * h0)];
+        xi[u][k] = buf[ZA_B2(b0 + k * h0) + 1];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int k = 0; k < Q; ++k) {
+          if (k & (1 << r)) continue;
+          const int c = k | (1 << r), t = (1 << r) - 1 + (k & ((1 << r) - 1));
+          const double w_i = sign < 0 ? -wi[u][t] : wi[u][t];
+          const double tr = xr[u][c] * wr[u][t] - xi[u][c] * w_i, ti = xr[u][c] * w_i + xi[u][c] * wr[u][t];
+          const double ar = xr[u][k], ai = xi[u][k];
+          xr[u][k] = ar + tr; xi[u][k] = ai + ti;
+          xr[u][c] = ar - tr; xi[u][c] = ai - ti;
+        }
+      }
+      if (base[u] >= 0) {
+#pragma unroll
+        for (int k = 0; k < Q; ++k) {
+          buf[ZA_B2(base[u] + k * h0)] = xr[u][k];
+          buf[ZA_B2(base[u] + k * h0) + 1] = xi[u][k];
+        }
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
 __device__ __forceinline__ void za_fft_lds_stages(double* buf, const double* tw, int nlp, int sign, int rank, int nact) {
   int rem = 31 - __builtin_clz((unsigned)nlp), h = 1;
   while (rem > 0) {
@@ -347,8 +410,7 @@ ZA_NOINLINE bool za_fft_coop(S& s, bool ok, int64_t base, int n, int op, int64_t
 #define ZA_S(a) fp[(int64_t)(a) * fs]
 #define ZA_SLICE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); \
                              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
-      constexpr int P = ZA_FFT_LDS_POINTS, PB = 31 - __builtin_clz(P);
-      const int B = nl / P, q = bits - PB;                     // blocks of P points; B = 2^q
+      constexpr int P = ZA_FFT_LDS_POINTS;
       if (op == ZA_COOP_PERMUTE || op == ZA_COOP_IPERMUTE) {
         // through the scratch. Position i of a WDL-ordered buffer holds natural bin perm[i]:
         //   fft_permute  (WDL order -> natural): out[k] = in[iperm[k]];   fft_ipermute (natural -> WDL order): out[i] = in[perm[i]]
@@ -362,189 +424,108 @@ ZA_NOINLINE bool za_fft_coop(S& s, bool ok, int64_t base, int n, int op, int64_t
         ZA_SLICE_SYNC();
         continue;
       }
+      // Two stages of (up to) six radix-2 passes each, a 1024-point chunk at a time through LDS; the buffer makes ONE trip through
+      // the scratch between them (four 64 KB trips per 4096-point transform instead of round 3's six, no separate sorting pass).
+      // With p the position in the bit-reversed array (p = bitrev(i)), passes 1 .. a only combine positions inside aligned
+      // sub-blocks of A = 2^a positions, passes a + 1 .. a + 6 only positions that agree in their low a bits:
+      //   stage A (a = bits - 6): sub-block g = p >> a holds the elements i = q * 64 + c, q < A, of residue c = bitrev6(g) mod 64; a
+      //     chunk takes G = 1024 / A consecutive residues (256- / 512-byte runs of the buffer), LDS position m * G + (c mod G)
+      //     with m = bitrev_a(q) the position inside the sub-block; every sub-block runs the first a passes of its own
+      //     A-point transform (twiddles of the compact table);
+      //   stage B: group u = p mod A holds p = u + A v, v < 64; a chunk takes 16 consecutive u -- 16 KB the scratch holds
+      //     contiguously, sorted (u >> 4, v, u & 15) by stage A's stores -- at LDS position v * 16 + (u & 15) and runs the
+      //     last six passes (twiddle index u + A (v mod half): the 4096-point table za_fft_tw4); position p is natural bin p.
+      // Same butterflies, twiddles and order of operations per element as the in-LDS form, hence the same bits. LDS positions
+      // are swizzled by ZA_B2 (low four bits XOR bits 4-7): the chunk is read by rows in the passes and by columns when it is
+      // sorted into the scratch, both one bank group per lane of a 16-lane phase.
+      static_assert(ZA_FFT_LDS_POINTS != 1024 || ZA_FFT_COOP_MAX == 4096, "two-stage slicing: 1024-point chunks, 64 x 64 at most");
       const int sign = (op == ZA_COOP_FFT || op == ZA_COOP_FFT_NAT) ? -1 : +1;
-      constexpr int ZA_GU = P / 64 < 16 ? (P / 64 < 1 ? 1 : P / 64) : 16;      // a full wavefront fetches a block in one batch of loads
-#ifndef ZA_FFT_NAT_STRIDED
-      if (is_nat) {
-        // Natural order in, natural order out (the fused pairs: how every leaf calls these sizes). The strided block gathers of the
-        // general path take 16 bytes out of every 64-byte segment of the buffer, once per block: four times the buffer through
-        // HBM (PMC: 3.5 x the algorithmic bytes, profiles/r03_fft_pmc_traffic.json). Here the buffer is read ONCE, coalesced,
-        // and left in the scratch sorted by residue (S_r[t] = x[t B + r]: what block bitrev(r) gathers, now contiguous); the
-        // buffer itself -- free from then on -- takes the block results, and the last passes run in place on it (a lane reads
-        // the four elements it will write). Six 64 KB trips instead of seven and a half, every one of them coalesced.
-        // (measured and rejected: the next block's loads issued before this block's LDS passes, and the chunk copies of the first
-        //  phase double-buffered -- the extra live registers spill under the 256 cap: 297 -> 503 / 558 us)
-        for (int c = 0; c < B; ++c) {
-          for (int i0 = rank; i0 < P; i0 += ZA_GU * nact) {
-            double vr[ZA_GU], vi[ZA_GU];
-#pragma unroll
-            for (int u = 0; u < ZA_GU; ++u) {
-              const int i = i0 + u * nact < P ? i0 + u * nact : i0;
-              vr[u] = ZA_G(2 * (c * P + i)); vi[u] = ZA_G(2 * (c * P + i) + 1);
-            }
-#pragma unroll
-            for (int u = 0; u < ZA_GU; ++u) {
-              const int i = i0 + u * nact;
-              if (i < P) {
-                const int k = c * P + i, r = k & (B - 1), t = k >> q;
-                ZA_S(2 * (r * P + t)) = vr[u]; ZA_S(2 * (r * P + t) + 1) = vi[u];
-              }
-            }
-          }
-        }
-        ZA_SLICE_SYNC();
-        for (int b = 0; b < B; ++b) {
-          const int rb = (int)za_bitrev((uint32_t)b, q);
-          for (int t0 = rank; t0 < P; t0 += ZA_GU * nact) {
-            double vr[ZA_GU], vi[ZA_GU];
-#pragma unroll
-            for (int u = 0; u < ZA_GU; ++u) {
-              const int t = t0 + u * nact < P ? t0 + u * nact : t0;
-              vr[u] = ZA_S(2 * (rb * P + t)); vi[u] = ZA_S(2 * (rb * P + t) + 1);
-            }
-#pragma unroll
-            for (int u = 0; u < ZA_GU; ++u) {
-              const int t = t0 + u * nact;
-              if (t < P) {
-                const uint32_t m = za_bitrev((uint32_t)t, PB);
-                buf[ZA_B(m)] = vr[u]; buf[ZA_B(m) + 1] = vi[u];
-              }
-            }
-          }
-          __builtin_amdgcn_wave_barrier();
-          za_fft_lds_stages(buf, tw, P, sign, rank, nact);
-          for (int m = rank; m < P; m += nact) {
-            ZA_G(2 * (P * b + m)) = buf[ZA_B(m)];
-            ZA_G(2 * (P * b + m) + 1) = buf[ZA_B(m) + 1];
-          }
-          __builtin_amdgcn_wave_barrier();
-        }
-      
-        ZA_SLICE_SYNC();
-        constexpr int JV = 4;
-        for (int j0 = rank; j0 < P; j0 += JV * nact) {
-          double er[JV][4], ei[JV][4], w1r[JV], w1i[JV], w2r[JV], w2i[JV], w3r[JV], w3i[JV];
-#pragma unroll
-          for (int u = 0; u < JV; ++u) {
-            const int j = j0 + u * nact < P ? j0 + u * nact : j0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-              if (k < B) { er[u][k] = ZA_G(2 * (j + P * k)); ei[u][k] = ZA_G(2 * (j + P * k) + 1); }
-            const int st1 = ZA_FFT_MAX / (2 * P), st2 = ZA_FFT_MAX / (4 * P);
-            w1r[u] = za_fft_cos[j * st1]; w1i[u] = za_fft_sin[j * st1];
-            if (B == 4) {
-              w2r[u] = za_fft_cos[j * st2]; w2i[u] = za_fft_sin[j * st2];
-              w3r[u] = za_fft_cos[(j + P) * st2]; w3i[u] = za_fft_sin[(j + P) * st2];
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < JV; ++u) {
-            auto bfly = [&](int a, int c2, double wr, double wi0) __attribute__((always_inline)) {
-              const double w_i = sign < 0 ? -wi0 : wi0;
-              const double tr = er[u][c2] * wr - ei[u][c2] * w_i, ti = er[u][c2] * w_i + ei[u][c2] * wr;
-              const double xr = er[u][a], xi = ei[u][a];
-              er[u][a] = xr + tr; ei[u][a] = xi + ti;
-              er[u][c2] = xr - tr; ei[u][c2] = xi - ti;
-            };
-            bfly(0, 1, w1r[u], w1i[u]);
-            if (B == 4) bfly(2, 3, w1r[u], w1i[u]);
-            if (B == 4) {
-              bfly(0, 2, w2r[u], w2i[u]);
-              bfly(1, 3, w3r[u], w3i[u]);
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < JV; ++u) {
-            if (j0 + u * nact < P) {
-              const int j = j0 + u * nact;
-#pragma unroll
-              for (int k = 0; k < 4; ++k)
-                if (k < B) { ZA_G(2 * (j + P * k)) = er[u][k]; ZA_G(2 * (j + P * k) + 1) = ei[u][k]; }
-            }
-          }
-        }
-        ZA_SLICE_SYNC();
-        continue;
-      }
-#endif
-      for (int b = 0; b < B; ++b) {
-        // block b of the bit-reversed array: its position m takes natural element k = bitrev_P(m) * B + bitrev_q(b)
-        const int rb = (int)za_bitrev((uint32_t)b, q);
-        for (int t0 = rank; t0 < P; t0 += ZA_GU * nact) {
+      constexpr int ZA_GU = 16;                                // a full wavefront moves a chunk in one batch of loads
+      const int a = bits - 6, A = 1 << a, gb = 10 - a, G = 1 << gb;
+      for (int C = 0; C < (64 >> gb); ++C) {
+        for (int e0 = rank; e0 < P; e0 += ZA_GU * nact) {
           double vr[ZA_GU], vi[ZA_GU];
 #pragma unroll
           for (int u = 0; u < ZA_GU; ++u) {
-            const int t = t0 + u * nact;
-            const int k = (t < P ? t : 0) * B + rb;
-            const int src = op == ZA_COOP_IFFT ? (int)za_fft_iperm[nl + k] : k;  // ifft: the position that holds bin k
+            const int e = e0 + u * nact < P ? e0 + u * nact : e0;
+            const int i = ((e >> gb) << 6) + G * C + (e & (G - 1));
+            const int src = op == ZA_COOP_IFFT ? (int)za_fft_iperm[nl + i] : i;      // ifft: the position that holds bin i
             vr[u] = ZA_G(2 * src); vi[u] = ZA_G(2 * src + 1);
           }
 #pragma unroll
           for (int u = 0; u < ZA_GU; ++u) {
-            const int t = t0 + u * nact;
-            if (t < P) {
-              const uint32_t m = za_bitrev((uint32_t)t, PB);
-              buf[ZA_B(m)] = vr[u]; buf[ZA_B(m) + 1] = vi[u];
+            const int e = e0 + u * nact;
+            if (e < P) {
+              const int loc = ((int)za_bitrev((uint32_t)(e >> gb), a) << gb) + (e & (G - 1));
+              buf[ZA_B2(loc)] = vr[u]; buf[ZA_B2(loc) + 1] = vi[u];
             }
           }
         }
         __builtin_amdgcn_wave_barrier();
-        za_fft_lds_stages(buf, tw, P, sign, rank, nact);
-        for (int m = rank; m < P; m += nact) {
-          ZA_S(2 * (P * b + m)) = buf[ZA_B(m)];
-          ZA_S(2 * (P * b + m) + 1) = buf[ZA_B(m) + 1];
+        auto twa = [&](int jl, int lhb, double& wr, double& wi) __attribute__((always_inline)) {
+          const int ix = (jl >> gb) << (9 - (lhb - gb));
+          wr = za_fft_twc[2 * ix]; wi = za_fft_twc[2 * ix + 1];
+        };
+        if (a == 6) za_fft_lds_pass_v<3>(buf, 16, sign, rank, nact, twa);
+        else za_fft_lds_pass_v<2>(buf, 32, sign, rank, nact, twa);
+        za_fft_lds_pass_v<3>(buf, 128, sign, rank, nact, twa);
+        for (int e0 = rank; e0 < P; e0 += ZA_GU * nact) {
+          double vr[ZA_GU], vi[ZA_GU];
+#pragma unroll
+          for (int u = 0; u < ZA_GU; ++u) {
+            const int e = e0 + u * nact < P ? e0 + u * nact : e0;
+            const int m = ((e >> (4 + gb)) << 4) + (e & 15), loc = m * G + ((e >> 4) & (G - 1));
+            vr[u] = buf[ZA_B2(loc)]; vi[u] = buf[ZA_B2(loc) + 1];
+          }
+#pragma unroll
+          for (int u = 0; u < ZA_GU; ++u) {
+            const int e = e0 + u * nact;
+            if (e < P) {
+              const int m = ((e >> (4 + gb)) << 4) + (e & 15), c = G * C + ((e >> 4) & (G - 1));
+              const int d = ((m >> 4) << 10) + ((int)za_bitrev((uint32_t)c, 6) << 4) + (m & 15);
+              ZA_S(2 * d) = vr[u]; ZA_S(2 * d + 1) = vi[u];
+            }
+          }
         }
         __builtin_amdgcn_wave_barrier();
       }
       ZA_SLICE_SYNC();
-      // the last q passes (len = 2P [, 4P]) on the B elements j, j + P, ... of the scratch, from registers: four columns per
-      // trip, every load of the trip (16 values and their twiddles) issued before the first store -- one memory latency per
-      // trip, and a lane makes P / 256 trips
-      constexpr int JU = 4;
-      for (int j0 = rank; j0 < P; j0 += JU * nact) {
-        double er[JU][4], ei[JU][4], w1r[JU], w1i[JU], w2r[JU], w2i[JU], w3r[JU], w3i[JU];
-        int dst[JU][4];
+      for (int D = 0; D < (A >> 4); ++D) {
+        for (int e0 = rank; e0 < P; e0 += ZA_GU * nact) {
+          double vr[ZA_GU], vi[ZA_GU];
 #pragma unroll
-        for (int u = 0; u < JU; ++u) {
-          const int j = j0 + u * nact < P ? j0 + u * nact : j0;
+          for (int u = 0; u < ZA_GU; ++u) {
+            const int e = e0 + u * nact < P ? e0 + u * nact : e0;
+            vr[u] = ZA_S(2 * (D * P + e)); vi[u] = ZA_S(2 * (D * P + e) + 1);
+          }
 #pragma unroll
-          for (int k = 0; k < 4; ++k)
-            if (k < B) {
-              er[u][k] = ZA_S(2 * (j + P * k)); ei[u][k] = ZA_S(2 * (j + P * k) + 1);
-              const int pbin = j + P * k;                      // natural index of the result
-              dst[u][k] = op == ZA_COOP_FFT ? (int)za_fft_iperm[nl + pbin] : pbin;   // fft alone: stored in WDL_fft_permute order
-            }
-          const int st1 = ZA_FFT_MAX / (2 * P), st2 = ZA_FFT_MAX / (4 * P);
-          w1r[u] = za_fft_cos[j * st1]; w1i[u] = za_fft_sin[j * st1];
-          if (B == 4) {
-            w2r[u] = za_fft_cos[j * st2]; w2i[u] = za_fft_sin[j * st2];
-            w3r[u] = za_fft_cos[(j + P) * st2]; w3i[u] = za_fft_sin[(j + P) * st2];
+          for (int u = 0; u < ZA_GU; ++u) {
+            const int e = e0 + u * nact;
+            if (e < P) { buf[ZA_B2(e)] = vr[u]; buf[ZA_B2(e) + 1] = vi[u]; }
           }
         }
+        __builtin_amdgcn_wave_barrier();
+        auto twb = [&](int jl, int lhb, double& wr, double& wi) __attribute__((always_inline)) {
+          const int ix = ((jl & 15) + 16 * D + ((jl >> 4) << a)) << (11 - (lhb - 4 + a));
+          wr = za_fft_tw4[2 * ix]; wi = za_fft_tw4[2 * ix + 1];
+        };
+        za_fft_lds_pass_v<3>(buf, 16, sign, rank, nact, twb);
+        za_fft_lds_pass_v<3>(buf, 128, sign, rank, nact, twb);
+        for (int e0 = rank; e0 < P; e0 += ZA_GU * nact) {
+          int dst[ZA_GU];
 #pragma unroll
-        for (int u = 0; u < JU; ++u) {
-          auto bfly = [&](int a, int c, double wr, double wi0) __attribute__((always_inline)) {   // (a, c) <- (a + w c, a - w c)
-            const double w_i = sign < 0 ? -wi0 : wi0;
-            const double tr = er[u][c] * wr - ei[u][c] * w_i, ti = er[u][c] * w_i + ei[u][c] * wr;
-            const double xr = er[u][a], xi = ei[u][a];
-            er[u][a] = xr + tr; ei[u][a] = xi + ti;
-            er[u][c] = xr - tr; ei[u][c] = xi - ti;
-          };
-          bfly(0, 1, w1r[u], w1i[u]);                          // len = 2P, half = P: butterflies (j, j + P) [and (j + 2P, j + 3P)]
-          if (B == 4) bfly(2, 3, w1r[u], w1i[u]);
-          if (B == 4) {                                        // len = 4P, half = 2P: (j, j + 2P) and (j + P, j + 3P)
-            bfly(0, 2, w2r[u], w2i[u]);
-            bfly(1, 3, w3r[u], w3i[u]);
+          for (int u = 0; u < ZA_GU; ++u) {
+            const int e = e0 + u * nact < P ? e0 + u * nact : e0;
+            const int pbin = 16 * D + (e & 15) + ((e >> 4) << a);                    // natural index of the result
+            dst[u] = op == ZA_COOP_FFT ? (int)za_fft_iperm[nl + pbin] : pbin;        // fft alone: stored in WDL_fft_permute order
+          }
+#pragma unroll
+          for (int u = 0; u < ZA_GU; ++u) {
+            const int e = e0 + u * nact;
+            if (e < P) { ZA_G(2 * dst[u]) = buf[ZA_B2(e)]; ZA_G(2 * dst[u] + 1) = buf[ZA_B2(e) + 1]; }
           }
         }
-#pragma unroll
-        for (int u = 0; u < JU; ++u) {
-          if (j0 + u * nact < P) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-              if (k < B) { ZA_G(2 * dst[u][k]) = er[u][k]; ZA_G(2 * dst[u][k] + 1) = ei[u][k]; }
-          }
-        }
+        __builtin_amdgcn_wave_barrier();
       }
       ZA_SLICE_SYNC();
 #undef ZA_S

@@ -264,7 +264,7 @@ def build_module(jsfx_path, name: Optional[str] = None, force=False, verbose=Fal
         deps.append(CSRC / FAST_KERNELS[prog.name])
         deps += [CSRC / d for d in FAST_KERNEL_DEPS.get(prog.name, [])]
     for extra in ("zart_fft.h", "zart_gmem.h", "zart_pool.h", "zart_file.h", "zart_msg.h"):
-        if (CSRC / extra).exists():
+        if f'#include "{extra}"' in text:      # (only the leaves that include a runtime header are stale when it changes)
             deps.append(CSRC / extra)
     lb_note = LIB / f"{prog.name}.longbranch"      # "<count>\n<sha1 of the module text whose time-parallel kernel was refused>"
     allow_lb = bool(os.environ.get("ZA_TPAR_ALLOW_LONG_BRANCHES"))
