@@ -96,6 +96,53 @@ spl1 = lp(spl1);
     assert p.io["inputs"] == 2 and p.io["outputs"] == 2
 
 
+def test_named_constants_become_literals_outside_init():
+    """A script's named constants (one unconditional top-level `name = <numbers>` in @init, no other store anywhere) are read as
+    literals by @slider / @block / @sample and the functions specialised for them; @init and the variable table stay as they
+    were (zajit/program.py named_constants)."""
+    from zajit import program, syntax as S
+    text = """desc:t
+slider1:gain_db=0<-60,12,1>gain
+@init
+STRIDE = 8; N = STRIDE * 4 - 2; HALF = N / 4;
+twice = 1; twice = 2;
+cond ? guarded = 3;
+compound = 1; compound += 1;
+outarg = 0;
+late = early_read + 1; early_read = 5;
+gain_db = 1;
+gfx_w = 640;
+function scale(x, N) ( x * N * STRIDE );
+function peek() ( file_var(0, outarg); N );
+base = 100;
+@slider
+k = N;
+@sample
+i = 0; loop(N, base[i * STRIDE] = scale(spl0, 3) + HALF; i += 1;);
+peek(); spl1 = twice + guarded + compound + outarg + early_read + gain_db + gfx_w;
+"""
+    p = program.analyse(text)
+    prog, fns = p.sections, p.fns
+    texts = {sec: repr(prog[sec]) for sec in prog}
+    # established: STRIDE = 8, N = 30, HALF = 7.5, base = 100, early_read = 5 (its read in @init comes first and sees 0, untouched)
+    assert "Var(name='N')" not in texts["slider"] and "Num(value=30.0)" in texts["slider"]
+    for nm in ("STRIDE", "N", "HALF", "base", "early_read"):
+        assert f"Var(name='{nm}')" not in texts["sample"], nm
+        assert f"Var(name='{nm}')" in texts["init"], nm            # @init still stores (and reads) the table cells
+        assert nm in p.vars
+    assert "Num(value=7.5)" in texts["sample"] and "Num(value=100.0)" in texts["sample"] and "Num(value=5.0)" in texts["sample"]
+    # not constants: two stores, a store under a condition, a compound assignment, a builtin's output argument, a slider alias,
+    # a host variable
+    for nm in ("twice", "guarded", "compound", "outarg", "gain_db", "gfx_w"):
+        assert f"Var(name='{nm}')" in texts["sample"], nm
+    # a parameter shadows the global of the same name inside its function; the global STRIDE next to it is folded
+    body = repr(fns["__fn__sample__scale"].body)
+    assert "Var(name='N')" in body and "Var(name='STRIDE')" not in body and "Num(value=8.0)" in body
+    assert "Num(value=30.0)" in repr(fns["__fn__sample__peek"].body)
+    # `late` was computed from a variable that was still 0 when @init read it: not derivable, stays a variable
+    assert program.named_constants({"init": prog["init"], "sample": []}, {}, {}).get("late") is None
+
+
 def test_slider_declarations_and_quantiser():
     from zajit import sliders
     text = "slider1:30<0,100,1:sqr>Distance\nslider5:2<0,4,1{Eco,Moderate,High}>Quality\nslider7:0<-12,12,0.1:log>Out\nslider3:thr=-40<-80,0,0.1>-Hidden\n"

@@ -128,8 +128,8 @@ def test_rare_heavy_branches_become_events():
         assert kinds.count("cut") == 1
         before = plan.top.items[:kinds.index("cut")]
         assert all(it[0] in ("par", "scan", "shift", "spec", "serial") for it in before)       # no loads, stores or loops before the cut
-        with pytest.raises(NotImplementedError):
-            plan.simulate({}, np.zeros((2, 64), dtype=np.float32))
+        with pytest.raises(NotImplementedError):      # (the simulator stops where an event is due: within a hop of the start --
+            plan.simulate({}, np.zeros((2, 4096), dtype=np.float32))      # the hop sizes are literals now, not zeroed variables)
     # nested in a block-constant conditional: the event's condition carries the path's
     plan, msg = _plan_of_text("on ? ( buf[n] = spl0; n += 1; n >= 256 ? ( fft(buf, 256); n = 0; ); ); spl0 = buf[0];")
     assert plan is not None and plan.stats["events"] == 1, msg
@@ -180,7 +180,7 @@ def test_statements_the_lowering_cannot_take_become_events():
     assert "zpg" in text and "zt_frame(" in text
     # ... where the condition differs from frame to frame the loop itself is the event
     plan, msg = _plan_of_text("k = 0; loop(nb, abs(spl0) > thr[k] ? ( fft(buf + 64 * k, 64); ); k += 1; ); spl0 = buf[0];",
-                              init="thr = 500; buf = 1000; nb = 4;")
+                              init="thr = 500; buf = 1000; nb = 2; nb = 4;")      # (two stores: a count the planner knows as an invariant, not as a number)
     assert plan is not None and plan.stats["loops"] == 0 and plan.stats["events"] == 1, msg
     # a statement that runs in every frame is no event
     plan, msg = _plan_of_text("k = 0; loop(4, buf[pos + k] = spl0; k += 1; ); pos += 1; spl0 = buf[pos - 9];", init="buf = 1000; pos = 50;")

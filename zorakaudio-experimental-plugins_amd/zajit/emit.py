@@ -721,7 +721,7 @@ class Emitter:
         tab = self.t("m")
         return f"const ZaMapAcc {tab}[] = {{ {', '.join(rows)} }};", f"za_map_ok({tab}, {len(rows)}, {c})"
 
-    MAP_GROUP = 4      # (8 was measured: NeuroCV x1024 108 -> 178 ms, STFT x1024 17.0 -> 17.9 ms, PsychoConvolver with an impulse response unchanged)
+    MAP_GROUP = int(os.environ.get("ZA_MAP_GROUP", "4"))      # (8 was measured: NeuroCV x1024 108 -> 178 ms, STFT x1024 17.0 -> 17.9 ms, PsychoConvolver with an impulse response unchanged)
 
     def _map_loop(self, plan, c, body_node, last_value=None):
         """The shared form of a planned map loop of `c` trips: lane r of the instance's R replica lanes runs trips r, r + R, ...

@@ -14,6 +14,8 @@ are interchangeable with the reference's generated header (SURVEY ยง8 a-2/a-3, ย
 """
 from __future__ import annotations
 
+import math
+import os
 import re
 from dataclasses import dataclass, field
 from pathlib import Path
@@ -373,6 +375,102 @@ def infer_io(programs, fns, hints) -> Dict[str, int]:
     return {"inputs": n_in, "outputs": n_out, "process": max(n_in, n_out), "max_read": max_r, "max_write": max_w}
 
 
+# ----------------------------------------------------------------------------------------------
+# named constants
+# ----------------------------------------------------------------------------------------------
+# JSFX has no `const`: a script names its record offsets, table sizes and enumerations by assigning them once at the top of
+# @init (Sample: VC_ACTIVE = 0; VC_STRIDE = 96; MAX_VOICES = 16; ... several hundred of them) and every v[VC_ACTIVE] of the
+# per-sample code is then a load of the variable table plus a floating-point add and a rounding for the address. A variable
+#   * with exactly ONE write site in the whole program (sections and specialised functions; compound assignments and the
+#     output arguments of builtins count as writes), which is
+#   * a plain top-level statement of @init `name = <constant expression>` (numbers, + - * /, constants established by the
+#     statements before it), and
+#   * neither a slider alias nor one of the host's variables
+# holds that value whenever @slider, @block or @sample run: @init has run to its end before any of them, nothing else stores
+# to it, and a state image of the same script carries the same number. Reads of it in those sections (and in the functions
+# specialised for them) become the literal; @init itself is left alone, so the table cell is written as before and reads
+# that come before the assignment there still see 0. (IEEE double arithmetic folded here is the arithmetic EEL2 would do.)
+_OUT_ARG_BUILTINS = ("midirecv", "midisyx", "msg_recv", "file_", "sample_read2", "slider_next_chg", "get_", "str", "sprintf",
+                     "match", "gfx_")
+
+
+# variables a host or the @gfx side may store to (this engine never does; left alone all the same)
+_HOST_VARS = {"tempo", "play_state", "play_position", "beat_position", "ts_num", "ts_denom", "trigger", "num_ch", "pdc_delay",
+              "pdc_bot_ch", "pdc_top_ch", "pdc_midi"}
+
+
+def _writes(n, shadow, out: Dict[str, int]):
+    if isinstance(n, S.Assign) and isinstance(n.target, S.Var) and n.target.name not in shadow:
+        out[n.target.name] = out.get(n.target.name, 0) + 1
+    if isinstance(n, S.Call) and n.fn.startswith(_OUT_ARG_BUILTINS):
+        for a in n.args:
+            if isinstance(a, S.Var) and a.name not in shadow:
+                out[a.name] = out.get(a.name, 0) + 2          # (never a constant)
+    for c in S.children(n):
+        _writes(c, shadow, out)
+
+
+def _const_value(n, known: Dict[str, float]) -> Optional[float]:
+    if isinstance(n, S.Num):
+        return float(n.value)
+    if isinstance(n, S.Var):
+        return known.get(n.name)
+    if isinstance(n, S.Unary) and n.op == "-":
+        a = _const_value(n.a, known)
+        return None if a is None else -a
+    if isinstance(n, S.Binary) and n.op in ("+", "-", "*", "/"):
+        l, r = _const_value(n.l, known), _const_value(n.r, known)
+        if l is None or r is None or (n.op == "/" and r == 0.0):
+            return None
+        v = l + r if n.op == "+" else l - r if n.op == "-" else l * r if n.op == "*" else l / r
+        return v if math.isfinite(v) else None
+    return None
+
+
+def named_constants(programs, fns, aliases) -> Dict[str, float]:
+    counts: Dict[str, int] = {}
+    for prog in programs.values():
+        for st in prog:
+            _writes(st, frozenset(), counts)
+    for f in fns.values():
+        _writes(f.body, frozenset(f.params) | frozenset(f.locals), counts)
+    skip = set(aliases.values()) | BUILTIN_VARS | _HOST_VARS
+    known: Dict[str, float] = {}
+    for st in programs.get("init", []):
+        if not (isinstance(st, S.Assign) and st.op == "=" and isinstance(st.target, S.Var)):
+            continue
+        nm = st.target.name
+        if counts.get(nm) != 1 or nm in skip or nm.startswith(("$", "#", "gfx_", "mouse_", "ext_", "pdc_")) or is_spl_name(nm) is not None \
+                or is_slider_name(nm) is not None:
+            continue
+        v = _const_value(st.value, known)
+        if v is not None:
+            known[nm] = v
+    return known
+
+
+def fold_named_constants(programs, fns, consts: Dict[str, float]):
+    if not consts:
+        return programs, fns
+
+    def sub(n, shadow):
+        if isinstance(n, S.Var):
+            if n.name in consts and n.name not in shadow:
+                return S.Num(consts[n.name], line=n.line, col=n.col)
+            return n
+        return S.rebuild(n, lambda c: sub(c, shadow))
+
+    out = {sec: (prog if sec == "init" else [sub(st, frozenset()) for st in prog]) for sec, prog in programs.items()}
+    out_f = {}
+    for name, f in fns.items():
+        m = re.match(r"__fn__(init|slider|block|sample)__", name)
+        if m and m.group(1) != "init":
+            shadow = frozenset(f.params) | frozenset(f.locals)
+            f = S.FuncDef(f.name, f.params, f.locals, f.instances, sub(f.body, shadow), line=f.line, col=f.col)
+        out_f[name] = f
+    return out, out_f
+
+
 @dataclass
 class Program:
     name: str
@@ -449,6 +547,8 @@ def analyse(text: str, name: str = "jsfx") -> Program:
     vars_ = collect_vars(progs, fns)
     opts = parse_options(text)
     decls = parse_slider_decls(text)
+    consts = {} if os.environ.get("ZA_NO_CONSTS") else named_constants(progs, fns, slider_aliases(decls))
+    progs, fns = fold_named_constants(progs, fns, consts)
     return Program(name=name, text=text, sections=progs, fns=fns, vars=vars_, options=opts,
                    memtop=memtop_slots(opts), io=infer_io(progs, fns, pin_hints(text)),
                    slider_decls=decls, aliases=slider_aliases(decls), calls=called_names(progs, fns))
