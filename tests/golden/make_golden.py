@@ -76,6 +76,8 @@ CASES = [
     ("TextureXY", "default", {}, 2048, 512),
     ("fx_convkat", "default", {}, 3072, 512),         # fft_real / ifft_real / convolve_c on the audio path, through the reference VM
     ("fx_convkat", "dense", {0: 0.9, 1: 3}, 2500, 500),
+    ("fx_realperm", "default", {}, 3072, 512),        # fft_real; fft_permute / fft_ipermute; ifft_real as adjacent calls (fused by the translator)
+    ("fx_realperm", "alt", {0: 0.85, 1: 0}, 2500, 500),
     # round 3: one setting away from the defaults per catalog leaf -- the other side of its mode / flavor switches, detector
     # filters on, extremes of times and amounts -- so that a translation error on a branch the defaults never take shows against
     # the reference VM, not only device-vs-port

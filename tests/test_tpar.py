@@ -18,7 +18,7 @@ REF_PLUGINS = Path("/root/reference/plugins")
 FIXTURES = ROOT / "tests" / "fixtures"
 TPAR_CATALOG = ["ADS", "ATTACK", "RTT", "SaliencePush", "BedRock", "DPT", "Roomalizer", "EasyExpander", "SOMA"]
 # leaves whose @sample has a rare heavy branch (tpar.split_events): the frame it falls on runs with the serial section code
-TPAR_EVENT_LEAVES = ["PsychoConvolver", "PsychoConvolver+IR", "NeuroCV", "fx_evtkat", "fx_evtkat2", "fx_guardkat", "fx_stft", "fx_stft4k", "fx_stftparts", "fx_convkat", "fx_mapkat", "fx_ringio"]
+TPAR_EVENT_LEAVES = ["PsychoConvolver", "PsychoConvolver+IR", "NeuroCV", "fx_evtkat", "fx_evtkat2", "fx_guardkat", "fx_stft", "fx_stft4k", "fx_stftparts", "fx_convkat", "fx_realperm", "fx_mapkat", "fx_ringio"]
 TPAR_BLOCK_CATALOG = ["ERBTilt", "SpectralStabilizer", "TSEQ"]        # leaves with @block: the kernel runs it between the blocks
 TPAR_FIXTURES = ["fx_dynkat_default", "fx_dynkat_hot", "fx_randkat_default", "fx_ringkat_default", "fx_ringkat_long",
                  "fx_delaytaps_default", "fx_delaytaps_far",

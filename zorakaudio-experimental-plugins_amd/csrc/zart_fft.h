@@ -168,7 +168,9 @@ __shared__ int za_fft_tw_ready;
 enum { ZA_COOP_FFT = 0, ZA_COOP_IFFT = 1, ZA_COOP_PERMUTE = 2, ZA_COOP_IPERMUTE = 3, ZA_COOP_FFT_REAL = 4, ZA_COOP_IFFT_REAL = 5,
        ZA_COOP_CONVOLVE = 6,
        ZA_COOP_FFT_NAT = 7,      // fft(b, n); fft_permute(b, n)    -> natural order in, natural-order spectrum out
-       ZA_COOP_IFFT_NAT = 8 };   // fft_ipermute(b, n); ifft(b, n)  -> natural-order spectrum in, natural order out
+       ZA_COOP_IFFT_NAT = 8,     // fft_ipermute(b, n); ifft(b, n)  -> natural-order spectrum in, natural order out
+       ZA_COOP_FFT_REAL_NAT = 9,     // fft_real(b, n); fft_permute(b, n / 2)    -> packed spectrum, bin k at position k
+       ZA_COOP_IFFT_REAL_NAT = 10 }; // fft_ipermute(b, n / 2); ifft_real(b, n) -> the same layout in, n reals out
 __device__ __forceinline__ int64_t za_readlane64(int64_t v, int l) {
   const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffff), l), hi = __builtin_amdgcn_readlane((int)(v >> 32), l);
   return ((int64_t)hi << 32) | (uint32_t)lo;
@@ -335,7 +337,7 @@ ZA_NOINLINE bool za_fft_coop(S& s, bool ok, int64_t base, int n, int op, int64_t
 #else
   const double* const tw = za_fft_twc;
 #endif
-  const bool is_real = op == ZA_COOP_FFT_REAL || op == ZA_COOP_IFFT_REAL;
+  const bool is_real = op == ZA_COOP_FFT_REAL || op == ZA_COOP_IFFT_REAL || op == ZA_COOP_FFT_REAL_NAT || op == ZA_COOP_IFFT_REAL_NAT;
   // what runs here: anything that fits the LDS buffer; complex transforms and permutations beyond it run sliced (below);
   // real transforms beyond it take the serial path
   const bool coop = ok && (op == ZA_COOP_CONVOLVE || (is_real ? n <= 2 * ZA_FFT_LDS_POINTS : n <= ZA_FFT_COOP_MAX));
@@ -539,18 +541,20 @@ ZA_NOINLINE bool za_fft_coop(S& s, bool ok, int64_t base, int n, int op, int64_t
       uint32_t pm[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int i = i0 + u * nact;
-        const bool in = i < nl;
-        vr[u] = in ? ZA_G(2 * i) : 0.0;
-        vi[u] = in ? ZA_G(2 * i + 1) : 0.0;
-        pm[u] = (in && (op == ZA_COOP_IFFT || op == ZA_COOP_PERMUTE || op == ZA_COOP_IFFT_REAL)) ? za_fft_perm[nl + i] : 0;
+        // (a trip past the end reads the lane's first element again instead of branching around its loads: a load under a lane
+        //  condition is a branch, and the compiler closes every such block with a full wait -- the eight reads went out in two
+        //  or three waited groups)
+        const int i = i0 + u * nact < nl ? i0 + u * nact : i0;
+        vr[u] = ZA_G(2 * i);
+        vi[u] = ZA_G(2 * i + 1);
+        pm[u] = (op == ZA_COOP_IFFT || op == ZA_COOP_PERMUTE || op == ZA_COOP_IFFT_REAL) ? za_fft_perm[nl + i] : 0;
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int i = i0 + u * nact;
         if (i < nl) {
           uint32_t dst;
-          if (op == ZA_COOP_FFT || op == ZA_COOP_FFT_REAL || is_nat) dst = za_bitrev((uint32_t)i, bits);
+          if (op == ZA_COOP_FFT || op == ZA_COOP_FFT_REAL || op == ZA_COOP_FFT_REAL_NAT || is_nat) dst = za_bitrev((uint32_t)i, bits);
           else if (op == ZA_COOP_IFFT) dst = za_bitrev(pm[u], bits);
           else if (op == ZA_COOP_PERMUTE || op == ZA_COOP_IFFT_REAL) dst = pm[u];      // (ifft_real: natural bin order first)
           else dst = (uint32_t)i;
@@ -560,7 +564,7 @@ ZA_NOINLINE bool za_fft_coop(S& s, bool ok, int64_t base, int n, int op, int64_t
       }
     }
     __builtin_amdgcn_wave_barrier();
-    if (op == ZA_COOP_IFFT_REAL) {
+    if (op == ZA_COOP_IFFT_REAL || op == ZA_COOP_IFFT_REAL_NAT) {
       // packed spectrum (natural order in buf) -> Z of the half-size complex transform, in place: bins k and h - k only need
       // each other; then the in-place bit reversal the butterflies want
       const int h = nl, step = ZA_FFT_MAX / nreq;
@@ -599,14 +603,15 @@ ZA_NOINLINE bool za_fft_coop(S& s, bool ok, int64_t base, int n, int op, int64_t
       __builtin_amdgcn_wave_barrier();
     }
     if (op == ZA_COOP_FFT || op == ZA_COOP_IFFT || is_real || is_nat) {
-      const int sign = (op == ZA_COOP_FFT || op == ZA_COOP_FFT_REAL || op == ZA_COOP_FFT_NAT) ? -1 : +1;
+      const int sign = (op == ZA_COOP_FFT || op == ZA_COOP_FFT_REAL || op == ZA_COOP_FFT_NAT || op == ZA_COOP_FFT_REAL_NAT) ? -1 : +1;
       za_fft_lds_stages(buf, tw, nl, sign, rank, nact);
     }
-    if (op == ZA_COOP_FFT_REAL) {
+    if (op == ZA_COOP_FFT_REAL || op == ZA_COOP_FFT_REAL_NAT) {
       // Z (natural order in buf) -> the packed spectrum of the real input, position i holds bin perm_h(i), scaled by 2
+      // (fused with fft_permute: bin i)
       const int h = nl, step = ZA_FFT_MAX / nreq;
       for (int i = rank; i < h; i += nact) {
-        const int k = (int)za_fft_perm[h + i];
+        const int k = op == ZA_COOP_FFT_REAL ? (int)za_fft_perm[h + i] : i;
         double re, im;
         if (k == 0) {
           re = 2.0 * (buf[0] + buf[1]);
@@ -630,16 +635,19 @@ ZA_NOINLINE bool za_fft_coop(S& s, bool ok, int64_t base, int n, int op, int64_t
       uint32_t src[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int i = i0 + u * nact;
+        const int i = i0 + u * nact < nl ? i0 + u * nact : i0;
         src[u] = (uint32_t)i;
-        if (i < nl && (op == ZA_COOP_FFT || op == ZA_COOP_IPERMUTE)) src[u] = za_fft_perm[nl + i];
+        if (op == ZA_COOP_FFT || op == ZA_COOP_IPERMUTE) src[u] = za_fft_perm[nl + i];
       }
+      double wr_[8], wi_[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { wr_[u] = buf[ZA_B(src[u])]; wi_[u] = buf[ZA_B(src[u]) + 1]; }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int i = i0 + u * nact;
         if (i < nl) {
-          ZA_G(2 * i) = buf[ZA_B(src[u])];
-          ZA_G(2 * i + 1) = buf[ZA_B(src[u]) + 1];
+          ZA_G(2 * i) = wr_[u];
+          ZA_G(2 * i + 1) = wi_[u];
         }
       }
     }
@@ -743,6 +751,38 @@ template <class S> ZA_NOINLINE double za_ifft_nat_o(S& s, double baseD, double s
   za_fft_ipermute_o(s, baseD, sizeD);
   za_fft_inv_core(s, base, (int)n);
   return 0.0;
+}
+// fft_real(b, n); fft_permute(b, m) and fft_ipermute(b, m); ifft_real(b, n) as adjacent calls with the same plain arguments
+// (zajit/emit.py _fuse_fft_pairs; how PsychoConvolver calls them, m = n / 2): where m is half of n and the pair fits the
+// wave-cooperative real transform, ONE operation that leaves / takes the packed spectrum in natural bin order -- the permutation
+// is an exact move, so the bits are those of the two calls; anything else (other sizes, the CPU port) runs the two builtins.
+template <class S> ZA_NOINLINE double za_fft_real_o(S& s, double baseD, double sizeD);
+template <class S> ZA_NOINLINE double za_ifft_real_o(S& s, double baseD, double sizeD);
+template <class S> ZA_NOINLINE double za_fft_real_nat_o(S& s, double baseD, double sizeD, double halfD) {
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+  const int64_t n = za_round_idx(sizeD), m = za_round_idx(halfD);
+  if (2 * m == n && m >= ZA_FFT_MIN && n <= 2 * ZA_FFT_LDS_POINTS) {       // both builtins would accept their size
+    int64_t base = 0;
+    const bool ok = za_fft_pow2(n) && za_fft_region(s, baseD, n, base, 2 * n);
+    if (za_fft_coop(s, ok, base, (int)n, ZA_COOP_FFT_REAL_NAT)) return 0.0;
+    return 0.0;                                                              // (!ok: both calls would have done nothing)
+  }
+#endif
+  za_fft_real_o(s, baseD, sizeD);
+  return za_fft_permute_o(s, baseD, halfD);
+}
+template <class S> ZA_NOINLINE double za_ifft_real_nat_o(S& s, double baseD, double sizeD, double halfD) {
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+  const int64_t n = za_round_idx(sizeD), m = za_round_idx(halfD);
+  if (2 * m == n && m >= ZA_FFT_MIN && n <= 2 * ZA_FFT_LDS_POINTS) {
+    int64_t base = 0;
+    const bool ok = za_fft_pow2(n) && za_fft_region(s, baseD, n, base, 2 * n);
+    if (za_fft_coop(s, ok, base, (int)n, ZA_COOP_IFFT_REAL_NAT)) return 0.0;
+    return 0.0;
+  }
+#endif
+  za_fft_ipermute_o(s, baseD, halfD);
+  return za_ifft_real_o(s, baseD, sizeD);
 }
 template <class S> ZA_NOINLINE double za_fft_permute_o(S& s, double baseD, double sizeD) {   // WDL order -> natural
   const int64_t n = za_round_idx(sizeD);
@@ -886,6 +926,8 @@ struct ZaFftEnv {
 ZA_X(za_fft) ZA_X(za_ifft) ZA_X(za_fft_permute) ZA_X(za_fft_ipermute) ZA_X(za_fft_nat) ZA_X(za_ifft_nat) ZA_X(za_fft_real) ZA_X(za_ifft_real)
 #undef ZA_X
 template <class S> ZA_FN double za_convolve_c(S& s, double destD, double srcD, double sizeD) { ZA_FFT_OUT(za_convolve_c_o(e, destD, srcD, sizeD)); }
+template <class S> ZA_FN double za_fft_real_nat(S& s, double baseD, double sizeD, double halfD) { ZA_FFT_OUT(za_fft_real_nat_o(e, baseD, sizeD, halfD)); }
+template <class S> ZA_FN double za_ifft_real_nat(S& s, double baseD, double sizeD, double halfD) { ZA_FFT_OUT(za_ifft_real_nat_o(e, baseD, sizeD, halfD)); }
 #undef ZA_FFT_OUT
 
 #undef ZA_M

@@ -339,6 +339,16 @@ class Emitter:
                 out.append(S.Call("__fft_nat" if a.fn == "fft" else "__ifft_nat", a.args, line=a.line, col=a.col))
                 i += 2
                 continue
+            # fft_real(b, n); fft_permute(b, m)  ->  __fft_real_nat(b, n, m);  fft_ipermute(b, m); ifft_real(b, n)  ->  __ifft_real_nat(b, n, m)
+            # (the run time checks m = n / 2 and otherwise makes the two calls: za_fft_real_nat)
+            if (isinstance(a, S.Call) and isinstance(b, S.Call) and len(a.args) == 2 and len(b.args) == 2
+                    and (a.fn, b.fn) in (("fft_real", "fft_permute"), ("fft_ipermute", "ifft_real"))
+                    and repr(a.args[0]) == repr(b.args[0]) and all(self._plain_arg(x) for x in a.args + b.args)):
+                real, perm = (a, b) if a.fn == "fft_real" else (b, a)
+                out.append(S.Call("__fft_real_nat" if a.fn == "fft_real" else "__ifft_real_nat",
+                                  [real.args[0], real.args[1], perm.args[1]], line=a.line, col=a.col))
+                i += 2
+                continue
             out.append(a)
             i += 1
         return out
@@ -971,7 +981,7 @@ class Emitter:
             self.nargs(n, 2)
             self.features.add("fft")
             return self.call_rt(n, "za_" + fn)
-        if fn in ("__fft_nat", "__ifft_nat"):          # fused pairs (_fuse_fft_pairs)
+        if fn in ("__fft_nat", "__ifft_nat", "__fft_real_nat", "__ifft_real_nat"):          # fused pairs (_fuse_fft_pairs)
             self.features.add("fft")
             return self.call_rt(n, "za_" + fn[2:])
         if fn == "convolve_c":
@@ -999,7 +1009,7 @@ class Emitter:
 
     def section(self, sec: str) -> str:
         self.cur_sec = sec
-        body = " ".join(self.stmt(st) for st in self.p.sections.get(sec, []))
+        body = " ".join(self.stmt(st) for st in self._fuse_fft_pairs(list(self.p.sections.get(sec, []))))
         return f"template <class S> ZA_SECTION_FN void za_section_{sec}(S& s) {{ {body} }}"
 
     def emit(self) -> str:
