@@ -124,13 +124,15 @@ peek(); spl1 = twice + guarded + compound + outarg + early_read + gain_db + gfx_
     p = program.analyse(text)
     prog, fns = p.sections, p.fns
     texts = {sec: repr(prog[sec]) for sec in prog}
-    # established: STRIDE = 8, N = 30, HALF = 7.5, base = 100, early_read = 5 (its read in @init comes first and sees 0, untouched)
+    # established: STRIDE = 8, N = 30, base = 100, early_read = 5 (its read in @init comes first and sees 0, untouched)
     assert "Var(name='N')" not in texts["slider"] and "Num(value=30.0)" in texts["slider"]
-    for nm in ("STRIDE", "N", "HALF", "base", "early_read"):
+    for nm in ("STRIDE", "N", "base", "early_read"):
         assert f"Var(name='{nm}')" not in texts["sample"], nm
         assert f"Var(name='{nm}')" in texts["init"], nm            # @init still stores (and reads) the table cells
         assert nm in p.vars
-    assert "Num(value=7.5)" in texts["sample"] and "Num(value=100.0)" in texts["sample"] and "Num(value=5.0)" in texts["sample"]
+    assert "Num(value=100.0)" in texts["sample"] and "Num(value=5.0)" in texts["sample"]
+    # only whole numbers become literals (addresses, counts, enumerations): HALF = 7.5 stays a variable the kernels keep in a register
+    assert "Var(name='HALF')" in texts["sample"] and "Num(value=7.5)" not in texts["sample"]
     # not constants: two stores, a store under a condition, a compound assignment, a builtin's output argument, a slider alias,
     # a host variable
     for nm in ("twice", "guarded", "compound", "outarg", "gain_db", "gfx_w"):
