@@ -13,4 +13,4 @@ for k, r in sorted(new.items()):
     o = old.get(k, {})
     print(f"{k:22s} {r.get('kernel_ms')!s:>10.9} ms (r04 {o.get('kernel_ms')!s:>10.9}) {r.get('kernel','')} {r.get('status','')[:60]}")
 PY
-timeout -k 10 400 python tools/fft_bench.py 2>&1 | tail -5
+
