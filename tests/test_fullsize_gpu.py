@@ -136,6 +136,20 @@ def test_checkpoint_resume_continues_bit_identically(leaf, tmp_path):
         assert np.array_equal(e2.read_vars(), want_vars)
 
 
+def test_restore_refuses_a_checkpoint_of_another_script_text():
+    """A script's named constants are literals in its kernels (zajit/program.py): a state image must come from the same text.
+    The checkpoint carries the variable table's hash and restore() compares it."""
+    import zabatch
+    with zabatch.Engine("fx_delaytaps", 2) as e:
+        e.set_sliders(zabatch.leaf_meta("fx_delaytaps")["default_sliders"]); e.prepare()
+        ck = e.checkpoint()
+        assert str(ck["vars_sha1"]) == zabatch.leaf_meta("fx_delaytaps")["vars_sha1"]
+        e.restore(ck)                                            # its own image: accepted
+        bad = dict(ck); bad["vars_sha1"] = np.array("0" * 40)
+        with pytest.raises(zabatch.ZabError, match="another text"):
+            e.restore(bad)
+
+
 @pytest.mark.parametrize("leaf", ["SOMA", "fx_delaytaps"])
 def test_checkpoint_chain_and_rollback_into_a_used_engine(leaf, tmp_path):
     """Checkpoints survive being taken from a restored engine (the arena's write high-water mark travels with them), and

@@ -463,7 +463,10 @@ class Engine:
                "vars": np.zeros((n, nv)), "masks": np.zeros((n, 3), np.int64), "mt": np.zeros((n, 624), np.uint32),
                "mti": np.zeros(n, np.uint32), "vis": np.zeros(n, np.int64), "visi": np.zeros(n, np.int32),
                "mem_high": high.astype(np.int64), "flags": np.zeros(n, np.uint32), "mem_cap": np.array(self.mem_cap, np.int64),
-               "changes": np.zeros(n, np.uint64)}      # (slider masks raised but not yet consumed by the host)
+               "changes": np.zeros(n, np.uint64),      # (slider masks raised but not yet consumed by the host)
+               # the script this state belongs to: its variable table's hash (a script's named constants are literals in the
+               # kernels, zajit/program.py -- an image of another script text would carry cells the kernels do not read)
+               "vars_sha1": np.array(str(leaf_meta(self.leaf).get("vars_sha1", "")))}
         mems = []
         for i in range(n):
             a = {k: out[k][i:i + 1].reshape(-1) if out[k].ndim > 1 else out[k][i:i + 1] for k in ("spl", "sliders", "vars", "masks", "mt", "mti", "vis", "visi", "flags", "changes")}
@@ -482,6 +485,8 @@ class Engine:
         write high-water marks and pending-@slider flags are the checkpoint's -- and the next zab_process continues from it."""
         if str(ck["leaf"]) != self.leaf or ck["vars"].shape[0] != self.n:
             raise ZabError(-1, "checkpoint does not match this engine (leaf / instance count)")
+        if "vars_sha1" in ck and str(ck["vars_sha1"]) != str(leaf_meta(self.leaf).get("vars_sha1", "")):
+            raise ZabError(-1, "checkpoint was taken from another text of this script (variable tables differ)")
         if float(ck["srate"]) != self.srate:
             raise ZabError(-1, f"checkpoint was taken at srate {float(ck['srate'])}, this engine runs at {self.srate}")
         if "mem_cap" in ck and int(ck["mem_cap"]) != self.mem_cap:
