@@ -366,7 +366,9 @@ extern "C" __global__ void __launch_bounds__(64) ZA_KERNEL(section)(ZabBatch b, 
   }
   za_state_store(s, b, inst);
 }
+static void za_fft_tables_once(hipStream_t st);
 static hipError_t za_launch_section(const ZabBatch* b, int which, double samplesblock, hipStream_t st) {
+  za_fft_tables_once(st);
   hipLaunchKernelGGL(ZA_KERNEL(section), dim3((b->n_inst + b->ipw - 1) / b->ipw), dim3(64), 0, st, *b, which, samplesblock);
   return hipGetLastError();
 }
@@ -381,22 +383,34 @@ static hipError_t za_launch_msg_flush(const ZabBatch* b, hipStream_t st) {
 #endif
 
 static hipError_t za_launch_slider(const ZabBatch* b, hipStream_t st) {
+  za_fft_tables_once(st);
   hipLaunchKernelGGL(ZA_KERNEL(slider), dim3((b->n_inst + b->ipw - 1) / b->ipw), dim3(64), 0, st, *b);
   return hipGetLastError();
 }
-static hipError_t za_launch_prepare(const ZabBatch* b, hipStream_t st) {
+// The FFT builtins' twiddle / permutation tables are __device__ globals of the module (one copy per GPU), filled once per device
+// before the first kernel that can reach a builtin. EVERY launch path asks: the single-instance jsfx_* shim enters through
+// za_launch_section / za_launch_process and never calls prepare -- with the tables only filled there, a host whose first FFT
+// leaf ran through the shim transformed with zeros (round 4: tests/test_shim.py[DOT] run on its own; in the whole suite an
+// engine of the same module had always prepared first).
+static void za_fft_tables_once(hipStream_t st) {
 #if ZA_USES_FFT
-  static ZaPerDevice za_fft_once;        // (the twiddle / permutation tables are __device__ globals: one copy per GPU)
+  static ZaPerDevice za_fft_once;
   za_fft_once.once([st] {       // (waited for here: another engine of this leaf on the same device runs on its own stream and must
                                 //  not read the tables before this kernel has written them; once per device and module)
     hipLaunchKernelGGL(za_fft_table_kernel, dim3(ZA_FFT_MAX / 2 / 256), dim3(256), 0, st);
     (void)hipStreamSynchronize(st);
   });
+#else
+  (void)st;
 #endif
+}
+static hipError_t za_launch_prepare(const ZabBatch* b, hipStream_t st) {
+  za_fft_tables_once(st);
   hipLaunchKernelGGL(ZA_KERNEL(prepare), dim3((b->n_inst + b->ipw - 1) / b->ipw), dim3(64), 0, st, *b);
   return hipGetLastError();
 }
 static hipError_t za_launch_process(const ZabBatch* b, const ZabAudio* a, hipStream_t st) {
+  za_fft_tables_once(st);
   size_t lds = 0;
 #if ZA_USES_LMEM
   lds = (size_t)b->lmem_words * (size_t)b->ipw * sizeof(double);

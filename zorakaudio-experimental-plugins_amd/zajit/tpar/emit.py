@@ -365,6 +365,7 @@ class _Emit:
             self.emit_tail()
         L.append("static int32_t za_fast_applies(const ZabBatch* b, const ZabAudio* a) { (void)b; return a->frames > 0 ? 1 : 0; }")
         L.append("static hipError_t za_launch_fast(const ZabBatch* b, const ZabAudio* a, hipStream_t st) {")
+        L.append("  za_fft_tables_once(st);      // (a host may reach this launch without a prepare of this module: zab_generic.hip.h)")
         L.append(f"  hipLaunchKernelGGL({km}, dim3(b->n_inst), dim3(64), 0, st, *b, *a);")
         if self.has_abort:
             L.append(f"  hipLaunchKernelGGL({km[:-1]}_tail), dim3((b->n_inst + 63) / 64), dim3(64), 0, st, *b, *a);")
