@@ -638,3 +638,27 @@ def test_tpar_kernel_serial_fallback_of_switched_recurrences(case):
         v = e.read_vars()
     assert np.abs(y.astype(np.float64) - g["out"].astype(np.float64)[None]).max() <= AUDIO_EPS
     assert_state_close(names, v[2], g["vars"], what=f"{case} vars")
+
+
+def test_generated_module_text_does_not_depend_on_the_process(tmp_path):
+    """Two builds of one script must write the same module text: a time-parallel plan whose node order followed the iteration order
+    of a set of state names came out differently in every process (Python hashes strings per process), so TextureXY, BedRock,
+    EasyExpander and a fixture were recompiled by every build() -- and a hazard of the device compiler that depends on the exact text
+    (DESIGN.md "Compiler hazards") could come and go between builds. Same text under different hash seeds."""
+    import subprocess, sys
+    prog = (
+        "import sys, hashlib\n"
+        f"sys.path[:0] = [{str(ROOT / 'zorakaudio-experimental-plugins_amd')!r}, {str(ROOT)!r}]\n"
+        "from zajit import build as zb, program, codegen\n"
+        "from pathlib import Path\n"
+        "for fx in sys.argv[1:]:\n"
+        "    p = program.analyse_file(Path(fx)); p.name = 'fx_' + Path(fx).stem\n"
+        "    print(hashlib.sha1(zb.module_source(codegen.make_unit(p)).encode()).hexdigest())\n")
+    files = [str(FIXTURES / f"{n}.jsfx") for n in ("statekat", "dynkat", "voicekat", "stft", "ringkat")]
+    outs = []
+    for seed in ("1", "2", "777"):
+        import os
+        r = subprocess.run([sys.executable, "-c", prog] + files, capture_output=True, text=True, env={**os.environ, "PYTHONHASHSEED": seed})
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.split())
+    assert outs[0] == outs[1] == outs[2] and len(outs[0]) == len(files)

@@ -52,16 +52,43 @@ FAST_KERNEL_DEPS = {"DDT": ["kernels/ddt_fast.hip.h"]}     # headers the hand-wr
 LEAF_FLAGS = {"fx_dynkat_s1": ["-DZT_SPEC_MAX=1"],       # test variant: switched recurrences mostly fall back to their serial loop
               # FFT builtins with the whole 4096-point transform in LDS (zart_fft.h: ZA_FFT_LDS_POINTS; default 1024 + slicing)
               "fx_fftkat_full": ["-DZA_FFT_LDS_POINTS=4096"], "fx_fftbench_full": ["-DZA_FFT_LDS_POINTS=4096"]}
-# Compiler-hazard workarounds (DESIGN.md "Compiler hazards"): modules whose parity tests caught hipcc 7.2 storing ONE script variable
-# from a register pair whose high half a temporary had taken over -- kernels at the 512-register ceiling with spills (RTT in round
-# 2; TextureXY in round 4: `attack_sc` came back as 0x00000000_b9d438c5 for 0x3fc272ad_b9d438c5, low dword right, high dword zero,
-# while every value computed FROM it was right; tests/test_tpar.py ...long_run...[TextureXY+IR]). The same text compiled with the
-# scheduler's GCN pressure trackers is correct. That is a perturbation, not a fix -- a scheduler option cannot repair an allocator --
-# so it is applied where a test showed the hazard and nowhere else (on for every module it was measured: 690 tests green, NeuroCV,
-# Texture, ERBTilt 6-9 % faster, TSEQ 11 %, SOMA, BedRock, DPT 5-6 % slower, and 3DPanner's time-parallel kernel grew past the
-# long-branch limit). The guard stays what it was: every variable of every leaf is compared after processing.
+# Compiler-hazard rule (DESIGN.md "Compiler hazards"): twice the parity tests caught hipcc 7.2 storing ONE script variable from a
+# register pair whose high half a temporary had taken over, both times in a kernel at the 512-register ceiling with kilobytes of
+# spills (RTT in round 2; TextureXY in round 4: `attack_sc` came back as 0x00000000_b9d438c5 for 0x3fc272ad_b9d438c5, low dword right,
+# high dword zero, while every value computed FROM it was right; tests/test_tpar.py ...long_run...[TextureXY+IR]). The same text
+# compiled with the scheduler's GCN pressure trackers is correct. That is a perturbation, not a fix -- a scheduler option cannot
+# repair an allocator -- so it is not on everywhere (measured on every module: 690 tests green, NeuroCV, Texture, ERBTilt 6-9 %
+# faster, TSEQ 11 %, SOMA, BedRock, DPT 5-6 % slower, 3DPanner's time-parallel kernel past the long-branch limit); it goes where the
+# fault was seen: a module whose generic process kernel sits at the ceiling and spills HAZARD_SPILL_BYTES or more per lane is
+# compiled again with it (TextureXY 8.9 KB, Texture 10.5 KB today; the next heaviest, 3DPanner, 7.3 KB). The guard stays what it was: every variable of
+# every leaf is compared after processing.
 GCN_TRACKERS = ["-mllvm", "-amdgpu-use-amdgpu-trackers=1"]
-HAZARD_FLAGS = {"TextureXY": GCN_TRACKERS}
+HAZARD_SPILL_BYTES = int(os.environ.get("ZA_HAZARD_SPILL_BYTES", "8192"))
+
+
+def ceiling_spill_bytes(so: Path) -> int:
+    """Private segment (spills + scratch arrays, bytes per lane) of a built module's generic process kernel if it uses all 512
+    registers (256 VGPRs + 256 AGPRs); 0 otherwise."""
+    import re
+    import tempfile
+    llvm = Path("/opt/rocm/lib/llvm/bin")
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "dev.co")
+            subprocess.run([str(llvm / "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", str(so), fat], check=True)
+            subprocess.run([str(llvm / "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={fat}", f"--output={co}",
+                            f"--targets=hipv4-amdgcn-amd-amdhsa--{ARCH}"], check=True, capture_output=True)
+            notes = subprocess.run([str(llvm / "llvm-readelf"), "--notes", co], capture_output=True, text=True, check=True).stdout
+    except (OSError, subprocess.CalledProcessError) as ex:          # (no disassembly tools: the rule cannot be evaluated -- say so, build on)
+        print(f"warning: {so.name}: kernel resources not readable ({ex}); hazard rule skipped", file=sys.stderr)
+        return 0
+    worst = 0
+    for m in re.finditer(r"\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+).*?\.vgpr_count:\s+(\d+)", notes, re.S):
+        if m.group(1).endswith("_process") and int(m.group(3)) >= 512:      # the generic process kernel: where the fault was seen
+            worst = max(worst, int(m.group(2)))
+    return worst
+
+
 # leaves that could take a time-parallel kernel but keep the generic one, with the reason (none at present: a leaf whose @sample
 # does nothing is recognised by the lowering itself)
 NO_TPAR: Dict[str, str] = {}
@@ -262,11 +289,14 @@ def build_module(jsfx_path, name: Optional[str] = None, force=False, verbose=Fal
     src = GEN / f"{prog.name}_module.hip"
     so = LIB / f"libzab_{prog.name}.so"
     leaf_flags = list(LEAF_FLAGS.get(prog.name, []))
-    leaf_flags += GCN_TRACKERS if os.environ.get("ZA_GCN_TRACKERS") else HAZARD_FLAGS.get(prog.name, [])
     if unit.defines.get("ZA_USES_FFT") == "1" and unit.defines.get("ZA_OUTLINE_FNS") != "1" and not os.environ.get("ZA_FFT_CALLS"):
         # FFT leaves: the transform code inlined into its kernels, so that the kernels' register cap (ZA_OCC: two wavefronts per
         # SIMD) covers it -- a function that is called keeps its own, larger allocation and the kernel inherits it
         leaf_flags.append("-DZA_INLINE_ALL")
+    base_sha = hashlib.sha1((module_source(unit) + " ".join(leaf_flags)).encode()).hexdigest()
+    tr_note = LIB / f"{prog.name}.trackers"        # "<bytes>\n<sha1 of the module text the hazard rule fired on>"
+    if os.environ.get("ZA_GCN_TRACKERS") or (tr_note.exists() and tr_note.read_text().split()[-1:] == [base_sha]):
+        leaf_flags += GCN_TRACKERS
     text = module_source(unit) + (f"// leaf build flags: {' '.join(leaf_flags)}\n" if leaf_flags else "")
     deps = [CSRC / "zart.h", CSRC / "zab_generic.hip.h", CSRC / "zab_module.h"]
     if "zart_tpar.h" in text:
@@ -294,6 +324,17 @@ def build_module(jsfx_path, name: Optional[str] = None, force=False, verbose=Fal
             _run([HIPCC] + HIP_FLAGS + leaf_flags + ["-I", str(CSRC), "-o", str(so), str(src)])
             if verbose:
                 print(f"  hipcc {prog.name}: {time.time() - t0:.1f}s")
+            if "-amdgpu-use-amdgpu-trackers=1" not in leaf_flags and prog.name not in FAST_KERNELS:
+                spill = ceiling_spill_bytes(so)
+                if spill >= HAZARD_SPILL_BYTES:            # the hazard rule (above): once more, with the GCN trackers
+                    tr_note.write_text(f"{spill}\n{base_sha}")
+                    leaf_flags += GCN_TRACKERS
+                    text = module_source(unit) + f"// leaf build flags: {' '.join(leaf_flags)}\n"
+                    text_sha = hashlib.sha1(text.encode()).hexdigest()
+                    src.write_text(text)
+                    _run([HIPCC] + HIP_FLAGS + leaf_flags + ["-I", str(CSRC), "-o", str(so), str(src)])
+                    if verbose:
+                        print(f"  hipcc {prog.name}: {spill} B of spills at the register ceiling -> rebuilt with the GCN trackers")
             lb_note.unlink(missing_ok=True)
             if "ZA_FAST_KERNEL_NAME \"zab_" in text and "_tpar\"" in text and prog.name not in NO_TPAR:
                 nlb = long_branches(so, f"zab_{_cid(prog.name)}_tpar")

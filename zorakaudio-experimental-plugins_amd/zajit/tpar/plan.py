@@ -1032,7 +1032,7 @@ def _classify(g: FrameGraph, reg: Region, c: Component, ci: int = 0, live=None):
             return gn
 
         def pick(cnd: N, a, b):
-            co = {k: g.sel(cnd, a[0].get(k, g.ZERO), b[0].get(k, g.ZERO)) for k in set(a[0]) | set(b[0])}
+            co = {k: g.sel(cnd, a[0].get(k, g.ZERO), b[0].get(k, g.ZERO)) for k in sorted(set(a[0]) | set(b[0]))}
             return (co, g.sel(cnd, a[1], b[1]))
 
         def aff(n: N):
@@ -1049,7 +1049,7 @@ def _classify(g: FrameGraph, reg: Region, c: Component, ci: int = 0, live=None):
                     a, b = aff(n.args[0]), aff(n.args[1])
                     if a and b:
                         f = add if op == "+" else sub
-                        co = {k: f(a[0].get(k, g.ZERO), b[0].get(k, g.ZERO)) for k in set(a[0]) | set(b[0])}
+                        co = {k: f(a[0].get(k, g.ZERO), b[0].get(k, g.ZERO)) for k in sorted(set(a[0]) | set(b[0]))}
                         r = (co, f(a[1], b[1]))
                 elif op == "neg":
                     a = aff(n.args[0])
