@@ -79,3 +79,24 @@ def test_correctness_check_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setenv("ZA_GOLDEN_DIR", str(tmp_path))
     rows = check.check_leaf("fx_dynkat", verbose=False)
     assert rows and not any(r["ok"] for r in rows) and all(-61 < r["max_dbfs"] < -59 for r in rows)
+
+
+def test_hazard_rule_reads_the_process_kernel_and_marks_what_it_rebuilt():
+    """zajit/build.py: a module whose generic process kernel sits at the 512-register ceiling with HAZARD_SPILL_BYTES or more of
+    spills per lane is compiled again with the GCN pressure trackers (DESIGN.md "Compiler hazards"); the choice is recorded beside
+    the module and in its text, so that the next build does not compile twice and a reader can see which build a leaf got."""
+    from zajit import build as zb
+    lib = zb.LIB
+    if not (lib / "libzab_DDT.so").exists():
+        pytest.skip("modules not built")
+    assert zb.ceiling_spill_bytes(lib / "libzab_DDT.so") < zb.HAZARD_SPILL_BYTES        # (its generic kernel: 512 registers, a few bytes)
+    marked = sorted(p.stem for p in lib.glob("*.trackers"))
+    for leaf in marked:
+        text = (zb.GEN / f"{leaf}_module.hip").read_text()
+        assert "-amdgpu-use-amdgpu-trackers=1" in text.rsplit("// leaf build flags:", 1)[-1], leaf
+        note = (lib / f"{leaf}.trackers").read_text().split()
+        assert len(note) == 2 and int(note[0]) >= zb.HAZARD_SPILL_BYTES, (leaf, note)
+    for so in lib.glob("libzab_*.so"):             # nothing the rule would take was left on the default build
+        leaf = so.stem[len("libzab_"):]
+        if leaf not in marked and leaf not in zb.FAST_KERNELS and (zb.GEN / f"{leaf}_module.hip").exists():
+            assert zb.ceiling_spill_bytes(so) < zb.HAZARD_SPILL_BYTES, leaf
