@@ -280,7 +280,22 @@ def main() -> int:
                              mem_cap=args.mem_cap)
         nch = eng.nch
         eng.set_sliders(meta["default_sliders"])
-        eng.prepare()
+        try:
+            eng.prepare()
+        except zabatch.ZabError as ex:
+            # the leaf's @init stores past the default arena (a fixed arena reports what it would have needed: DESIGN.md section 3):
+            # size it from the report, once, unless the caller chose a size
+            import re as _re
+            m = _re.search(r"needed >= (\d+)", str(ex))
+            if args.mem_cap or not m:
+                raise
+            eng.close()
+            args.mem_cap = 1 << (int(m.group(1)) + 64).bit_length()
+            print(f"bench.py: {leaf} needs an arena of {int(m.group(1))} cells: mem_cap = {args.mem_cap}", file=sys.stderr)
+            eng = zabatch.Engine(leaf, n_inst, srate=SRATE, max_block=BLOCK, device=local_rank, path=path, first_instance_id=1 + lo,
+                                 mem_cap=args.mem_cap)
+            eng.set_sliders(meta["default_sliders"])
+            eng.prepare()
         nbytes = n_inst * nch * frames * 4
         d_in, d_out = eng.device_alloc(nbytes), eng.device_alloc(nbytes)
         eng.device_noise(d_in, frames, id_offset=lo)      # synthetic white noise, generated in HBM; noise id = global instance index
