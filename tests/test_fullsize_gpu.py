@@ -150,6 +150,29 @@ def test_restore_refuses_a_checkpoint_of_another_script_text():
             e.restore(bad)
 
 
+def test_a_named_constant_cell_is_not_read_by_the_kernels():
+    """a script's named constants (`N = 1024; HOP = 256;` once in @init) are numbers in the per-sample
+    code. Their cells still exist and hold the value after @init; a host that pokes another number into one -- here through a state
+    image -- changes nothing the kernels do, and the cell keeps what the host wrote (no section stores to it)."""
+    import zabatch
+    from zajit import noise
+    n, frames = 3, 2048
+    x = noise.white_noise(range(n), frames)
+    outs, cells = [], []
+    for poke in (False, True):
+        with zabatch.Engine("fx_stft", n) as e:
+            e.set_sliders(zabatch.leaf_meta("fx_stft")["default_sliders"]); e.prepare()
+            names = e.var_names(); k = names.index("HOP")
+            assert e.read_vars()[0][k] == 256.0
+            if poke:
+                ck = e.checkpoint(); ck["vars"][:, k] = 64.0; e.restore(ck)
+                assert e.read_vars()[0][k] == 64.0
+            outs.append(e.process_host(x, block=512))
+            cells.append(e.read_vars()[:, k].copy())
+    assert np.array_equal(outs[0], outs[1])
+    assert (cells[0] == 256.0).all() and (cells[1] == 64.0).all()
+
+
 @pytest.mark.parametrize("leaf", ["SOMA", "fx_delaytaps"])
 def test_checkpoint_chain_and_rollback_into_a_used_engine(leaf, tmp_path):
     """Checkpoints survive being taken from a restored engine (the arena's write high-water mark travels with them), and
