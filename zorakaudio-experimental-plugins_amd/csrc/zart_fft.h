@@ -49,6 +49,9 @@ __device__ double za_fft_cos[ZA_FFT_MAX / 2];
 __device__ double za_fft_sin[ZA_FFT_MAX / 2];
 __device__ double za_fft_twc[ZA_FFT_LDS_POINTS];     // (cos, sin)(2 pi j / ZA_FFT_LDS_POINTS), j < ZA_FFT_LDS_POINTS / 2
 __device__ double za_fft_tw4[ZA_FFT_COOP_MAX];       // (cos, sin)(2 pi j / ZA_FFT_COOP_MAX), j < ZA_FFT_COOP_MAX / 2: the sliced transforms' second stage
+#ifdef ZA_FFT_STAMPS
+__device__ int za_fft_stamp_once;
+#endif
 __device__ uint16_t za_fft_perm[2 * ZA_FFT_COOP_MAX];     // [n + i] = natural bin stored at position i of an n-point transform
 __device__ uint16_t za_fft_iperm[2 * ZA_FFT_COOP_MAX];    // [n + k] = position that holds natural bin k
 #else
@@ -534,6 +537,11 @@ ZA_NOINLINE bool za_fft_coop(S& s, bool ok, int64_t base, int n, int op, int64_t
 #undef ZA_SLICE_SYNC
       continue;
     }
+#ifdef ZA_FFT_STAMPS
+    // (-DZA_FFT_STAMPS: one wavefront of the launch prints the s_memtime ticks of its first in-LDS transform's phases -- staging
+    //  loads, LDS passes, write-back -- tools/probes/fft_phase_clock.py; 100 MHz ticks)
+    const uint64_t zs0 = __builtin_readcyclecounter();
+#endif
     // ---- stage the request's buffer in LDS, in the order its transform wants ----------------------------------------
     // (eight HBM reads in flight per lane: one read per trip would cost a full memory latency per element)
     for (int i0 = rank; i0 < nl; i0 += 8 * nact) {
@@ -602,10 +610,16 @@ ZA_NOINLINE bool za_fft_coop(S& s, bool ok, int64_t base, int n, int op, int64_t
       }
       __builtin_amdgcn_wave_barrier();
     }
+#ifdef ZA_FFT_STAMPS
+    const uint64_t zs1 = __builtin_readcyclecounter();
+#endif
     if (op == ZA_COOP_FFT || op == ZA_COOP_IFFT || is_real || is_nat) {
       const int sign = (op == ZA_COOP_FFT || op == ZA_COOP_FFT_REAL || op == ZA_COOP_FFT_NAT || op == ZA_COOP_FFT_REAL_NAT) ? -1 : +1;
       za_fft_lds_stages(buf, tw, nl, sign, rank, nact);
     }
+#ifdef ZA_FFT_STAMPS
+    const uint64_t zs2 = __builtin_readcyclecounter();
+#endif
     if (op == ZA_COOP_FFT_REAL || op == ZA_COOP_FFT_REAL_NAT) {
       // Z (natural order in buf) -> the packed spectrum of the real input, position i holds bin perm_h(i), scaled by 2
       // (fused with fft_permute: bin i)
@@ -652,6 +666,15 @@ ZA_NOINLINE bool za_fft_coop(S& s, bool ok, int64_t base, int n, int op, int64_t
       }
     }
     __builtin_amdgcn_wave_barrier();
+#ifdef ZA_FFT_STAMPS
+    {
+      __builtin_amdgcn_s_waitcnt(0);
+      const uint64_t zs3 = __builtin_readcyclecounter();
+      if (rank == 0 && blockIdx.x == 7 && op == ZA_COOP_FFT_NAT && atomicAdd(&za_fft_stamp_once, 1) < 4)
+        printf("za_fft_coop n=%d nact=%d: stage %llu, passes %llu, write-back %llu cycles\n", nl, nact,
+               (unsigned long long)(zs1 - zs0), (unsigned long long)(zs2 - zs1), (unsigned long long)(zs3 - zs2));
+    }
+#endif
 #undef ZA_G
   }
   return coop;
